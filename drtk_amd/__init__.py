@@ -1,0 +1,11 @@
+"""drtk_amd -- MI355X-native differentiable rasterization hot path
+(rasterize -> render -> interpolate -> edge_grad), drop-in for the `drtk.*` functions of
+facebookresearch/DRTK on PyTorch-ROCm.  Kernels: hand-written HIP for gfx950 in
+`drtk_amd/csrc`, C ABI in `include/drtk_amd.h`."""
+from drtk_amd.edge_grad_estimator import edge_grad_estimator  # noqa: F401
+from drtk_amd.interpolate import interpolate  # noqa: F401
+from drtk_amd.rasterize import rasterize, rasterize_with_depth  # noqa: F401
+from drtk_amd.render import render  # noqa: F401
+from drtk_amd.transform import transform, transform_with_v_cam  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Build the drtk_amd native libraries in-tree (gfx950 only).
+
+  drtk_amd/libdrtk_amd.so        HIP kernels + C ABI (include/drtk_amd.h); hipcc, no torch dependency
+  drtk_amd/drtk_amd_torch_ops.so torch-op shim (rasterize_ext / render_ext / interpolate_ext /
+                                 edge_grad_ext schemas + autograd), g++ against libtorch, links the above
+
+`python -m drtk_amd.build` builds both; __graft_entry__.build() calls build_all().
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(ROOT, "include")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+KERNEL_SRCS = ["rasterize.hip", "render.hip", "interpolate.hip", "edge_grad.hip", "capi.hip"]
+HEADERS = ["common.hpp", "segscatter.hpp"]
+LIB = os.path.join(PKG, "libdrtk_amd.so")
+OPS = os.path.join(PKG, "drtk_amd_torch_ops.so")
+
+# No fast-math, no FMA contraction: coverage/depth/classification are exact float decisions.
+HIP_FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}",
+]
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed:\n" + " ".join(cmd) + "\n" + r.stdout[-6000:])
+    return r.stdout
+
+
+def _newer(target, deps):
+    return os.path.isfile(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
+
+
+def build_kernels(force=False, verbose=True):
+    deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
+    if not force and _newer(LIB, deps):
+        return LIB
+    objs, cmds = [], []
+    for s in KERNEL_SRCS:
+        o = os.path.join(CSRC, s + ".o")
+        objs.append(o)
+        cmds.append([HIPCC, *HIP_FLAGS, "-c", os.path.join(CSRC, s), "-o", o])
+    with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
+        outs = list(ex.map(_run, cmds))
+    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        msg = "".join(outs).strip()
+        print(f"[drtk_amd] built {LIB}" + (("\n" + msg) if msg else ""))
+    return LIB
+
+
+def build_torch_ops(force=False, verbose=True):
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    deps = [src, os.path.join(INC, "drtk_amd.h"), LIB, __file__]
+    if not force and _newer(OPS, deps):
+        return OPS
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{INC}", "-I/opt/rocm/include"]
+    cmd = [
+        os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall",
+        "-Wno-unknown-pragmas", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+        f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", *inc, src, "-o", OPS,
+        f"-L{PKG}", "-ldrtk_amd", "-Wl,-rpath,$ORIGIN", f"-L{libdir}", "-ltorch", "-ltorch_cpu",
+        "-lc10", "-ltorch_hip", "-lc10_hip", f"-Wl,-rpath,{libdir}",
+    ]
+    out = _run(cmd)
+    if verbose:
+        print(f"[drtk_amd] built {OPS}" + (("\n" + out.strip()) if out.strip() else ""))
+    return OPS
+
+
+def build_all(force=False, verbose=True):
+    build_kernels(force=force, verbose=verbose)
+    build_torch_ops(force=force, verbose=verbose)
+    return LIB, OPS
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

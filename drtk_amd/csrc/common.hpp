@@ -1,0 +1,83 @@
+// Shared device/host helpers of the drtk_amd HIP kernels (gfx950 only).
+//
+// Everything here is compiled with -ffp-contract=off and without fast-math: coverage tests,
+// depth ordering and the "was clamped" / pix_in_tri decisions of the reference are exact float
+// comparisons (SURVEY.md §7 hard parts 1 and 3b), so what is written is what must be evaluated.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "drtk_amd.h"
+
+namespace drtk_amd {
+
+constexpr int kWave = 64;   // CDNA4 wavefront
+constexpr int kBlock = 256; // 4 waves per workgroup, one per SIMD
+
+template <typename T>
+struct Eps;
+template <>
+struct Eps<float> {
+  // cuda_math_helper.h:62-64
+  static __host__ __device__ constexpr float value() { return 1e-8f; }
+};
+template <>
+struct Eps<double> {
+  // cuda_math_helper.h:67-69
+  static __host__ __device__ constexpr double value() { return 1e-16; }
+};
+
+// cuda_math_helper.h:1036-1041 : v<0 ? min(v,-eps) : max(v,eps)   (epsclamp(+-0) = +eps)
+template <typename T>
+__device__ __forceinline__ T epsclamp(T v) {
+  const T eps = Eps<T>::value();
+  if (v < T(0)) {
+    return v < -eps ? v : -eps;
+  }
+  return v > eps ? v : eps;
+}
+
+// Explicit float->int conversion of the bounding box: out-of-range -> INT_MIN, matching the x86
+// reference build and the oracle (oracle/drtk_oracle_body.inc, trunc_i32).
+template <typename T>
+__device__ __forceinline__ int32_t trunc_i32(T x) {
+  if (!(x > T(-2147483904.0) && x < T(2147483648.0))) return INT32_MIN;
+  return static_cast<int32_t>(x);
+}
+
+template <typename T>
+__device__ __forceinline__ T min3(T a, T b, T c) {
+  T m = a;
+  if (b < m) m = b;
+  if (c < m) m = c;
+  return m;
+}
+template <typename T>
+__device__ __forceinline__ T max3(T a, T b, T c) {
+  T m = a;
+  if (m < b) m = b;
+  if (m < c) m = c;
+  return m;
+}
+
+__device__ __forceinline__ int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Unordered float/double atomic add on global memory (hardware global_atomic_add_f32 / _f64).
+template <typename T>
+__device__ __forceinline__ void atomic_add_global(T* p, T v) {
+  unsafeAtomicAdd(p, v);
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) {
+  return (a + b - 1) / b;
+}
+
+#define DRTK_RETURN_IF_LAUNCH_FAILED()                      \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return DRTK_ERR_LAUNCH; \
+  } while (0)
+
+} // namespace drtk_amd

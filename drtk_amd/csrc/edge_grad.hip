@@ -1,0 +1,424 @@
+// edge_grad backward -- gradients of the rasterized image at visibility discontinuities
+// (Pidhorskyi et al., arXiv 2405.02508), written per pixel into grad_v_pix_img [N,3,H,W].
+//
+// Reference: src/edge_grad/edge_grad_kernel.cu:217-449.  There every interior pixel acts as the
+// centre of a (centre, right, down) stencil, reads img / grad_output for both pixels of a pair
+// only where the triangle index changes (sparse 4-byte loads), and scatters 9 atomicAdds per
+// pixel (zeros included) into a zero-filled output.
+//
+// CDNA4 mapping, two passes, no atomics, no zero-fill:
+//   A. edge_dots_kernel  -- dense stream over img and grad_output with 16-byte loads: for every
+//      pixel the two pair terms  gdx = sum_c (img_R - img_C) * 0.5 (g_R + g_C)  and the same
+//      downwards (gdy).  A wave walks a 256-pixel-wide strip down R rows keeping the previous row in
+//      registers, so each row is read (R+1)/R times instead of twice.  8 B/px of scratch out.
+//   B. edge_gather_kernel -- every pixel OWNS its output: it classifies the four pairs it takes
+//      part in (as centre of its own stencil, as the right pixel of its left neighbour's, as the
+//      down pixel of its upper neighbour's) exactly like the reference and sums the at most four
+//      contributions in the single-threaded reference order.
+// Pairs are classified twice (once by each member), which costs ALU only.
+#include "common.hpp"
+
+namespace drtk_amd {
+namespace {
+
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  using type = float4;
+};
+template <>
+struct Vec4<double> {
+  using type = double4;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Pass A
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+struct Row {
+  T v[VEC];
+  T next; // pixel x + VEC (first pixel of the next lane)
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ Row<T, VEC> load_row(
+    const T* __restrict__ plane, int64_t row_off, int x, int W, bool x_ok, int lane) {
+  Row<T, VEC> r;
+  if (x_ok) {
+    if constexpr (VEC == 4) {
+      using V4 = typename Vec4<T>::type;
+      const V4 q = *reinterpret_cast<const V4*>(plane + row_off + x);
+      r.v[0] = q.x, r.v[1] = q.y, r.v[2] = q.z, r.v[3] = q.w;
+    } else {
+      r.v[0] = plane[row_off + x];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) r.v[j] = T(0);
+  }
+  r.next = __shfl_down(r.v[0], 1);
+  if (lane == kWave - 1 && x + VEC < W) r.next = plane[row_off + x + VEC];
+  return r;
+}
+
+// One wave = strip of 64*VEC pixels x R rows.  gdx[y][x] pairs (x,y)-(x+1,y), gdy[y][x] pairs
+// (x,y)-(x,y+1); accumulation over channels in ascending order (edge_grad_kernel.cu:353-380).
+template <typename T, int VEC, int R>
+__global__ __launch_bounds__(kBlock) void edge_dots_kernel(
+    const T* __restrict__ img, const T* __restrict__ grad_output, int C, int H, int W,
+    int strips_x, T* __restrict__ gdx, T* __restrict__ gdy) {
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int wave_global = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int sy = wave_global / strips_x, sx = wave_global - sy * strips_x;
+  const int y0 = sy * R;
+  if (y0 >= H) return;
+  const int x = (sx * kWave + lane) * VEC;
+  const bool x_ok = x < W;
+  const T* img_n = img + int64_t(n) * C * HW;
+  const T* go_n = grad_output + int64_t(n) * C * HW;
+
+  T ax[R][VEC], ay[R][VEC];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ax[r][j] = ay[r][j] = T(0);
+
+  for (int c = 0; c < C; ++c) {
+    const T* ip = img_n + int64_t(c) * HW;
+    const T* gp = go_n + int64_t(c) * HW;
+    Row<T, VEC> pi = load_row<T, VEC>(ip, int64_t(y0) * W, x, W, x_ok, lane);
+    Row<T, VEC> pg = load_row<T, VEC>(gp, int64_t(y0) * W, x, W, x_ok, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int y = y0 + r;
+      if (y >= H) break;
+      // horizontal pairs of row y
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const T ir = (j + 1 < VEC) ? pi.v[(j + 1) % VEC] : pi.next;
+        const T gr = (j + 1 < VEC) ? pg.v[(j + 1) % VEC] : pg.next;
+        ax[r][j] += (ir - pi.v[j]) * (T(0.5) * (gr + pg.v[j]));
+      }
+      if (y + 1 < H) {
+        Row<T, VEC> ci = load_row<T, VEC>(ip, int64_t(y + 1) * W, x, W, x_ok, lane);
+        Row<T, VEC> cg = load_row<T, VEC>(gp, int64_t(y + 1) * W, x, W, x_ok, lane);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          ay[r][j] += (ci.v[j] - pi.v[j]) * (T(0.5) * (cg.v[j] + pg.v[j]));
+        pi = ci;
+        pg = cg;
+      }
+    }
+  }
+  if (!x_ok) return;
+  T* ox = gdx + int64_t(n) * HW;
+  T* oy = gdy + int64_t(n) * HW;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int y = y0 + r;
+    if (y >= H) break;
+    const int64_t o = int64_t(y) * W + x;
+    if constexpr (VEC == 4) {
+      using V4 = typename Vec4<T>::type;
+      *reinterpret_cast<V4*>(ox + o) = V4{ax[r][0], ax[r][1], ax[r][2], ax[r][3]};
+      *reinterpret_cast<V4*>(oy + o) = V4{ay[r][0], ay[r][1], ay[r][2], ay[r][3]};
+    } else {
+      ox[o] = ax[r][0];
+      oy[o] = ay[r][0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass B
+// ---------------------------------------------------------------------------------------------
+// edge_grad_kernel.cu:18-28,72-87
+template <typename T>
+struct TriInfo {
+  T p0x, p0y, p1x, p1y;
+  T v01x, v01y, v02x, v02y, v12x, v12y;
+  T den;
+  T nx, ny, nz; // face normal, filled lazily
+  int32_t i0, i1, i2;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_tri(
+    const T* __restrict__ v_n, const int32_t* __restrict__ vi_n, int32_t idx, TriInfo<T>& t) {
+  // invalid triangles use vertex (0,0,0) like the reference (edge_grad_kernel.cu:296-301)
+  t.i0 = t.i1 = t.i2 = 0;
+  if (idx >= 0) {
+    const int32_t* f = vi_n + int64_t(idx) * 3;
+    t.i0 = f[0], t.i1 = f[1], t.i2 = f[2];
+  }
+  t.p0x = v_n[3 * (int64_t)t.i0 + 0];
+  t.p0y = v_n[3 * (int64_t)t.i0 + 1];
+  t.p1x = v_n[3 * (int64_t)t.i1 + 0];
+  t.p1y = v_n[3 * (int64_t)t.i1 + 1];
+  const T p2x = v_n[3 * (int64_t)t.i2 + 0], p2y = v_n[3 * (int64_t)t.i2 + 1];
+  t.v01x = t.p1x - t.p0x;
+  t.v01y = t.p1y - t.p0y;
+  t.v02x = p2x - t.p0x;
+  t.v02y = p2y - t.p0y;
+  t.v12x = p2x - t.p1x;
+  t.v12y = p2y - t.p1y;
+  t.den = t.v01x * t.v02y - t.v01y * t.v02x;
+}
+
+// edge_grad_kernel.cu:30-70 : rasterizer's top-left rule on NON-canonical edge functions
+template <typename T>
+__device__ __forceinline__ bool pix_in_tri(const TriInfo<T>& t, int x, int y) {
+  if (t.den != T(0)) {
+    const T px = static_cast<T>(x), py = static_cast<T>(y);
+    const T vp0x = px - t.p0x, vp0y = py - t.p0y;
+    const T vp1x = px - t.p1x, vp1y = py - t.p1y;
+    T b0 = vp1y * t.v12x - vp1x * t.v12y;
+    T b1 = vp0x * t.v02y - vp0y * t.v02x;
+    T b2 = vp0y * t.v01x - vp0x * t.v01y;
+    const T s = t.den > T(0) ? T(1) : (t.den < T(0) ? T(-1) : T(0));
+    b0 *= s;
+    b1 *= s;
+    b2 *= s;
+    const bool inside = (b0 >= T(0)) && (b1 >= T(0)) && (b2 >= T(0));
+    const bool on0 = b0 == T(0), on1 = b1 == T(0), on2 = b2 == T(0);
+    const bool pos = t.den > T(0);
+    const bool tl0 = pos ? (t.v12y < T(0) || (t.v12y == T(0) && t.v12x > T(0)))
+                         : (t.v12y > T(0) || (t.v12y == T(0) && t.v12x < T(0)));
+    const bool tl1 = pos ? (t.v02y > T(0) || (t.v02y == T(0) && t.v02x < T(0)))
+                         : (t.v02y < T(0) || (t.v02y == T(0) && t.v02x > T(0)));
+    const bool tl2 = pos ? (t.v01y < T(0) || (t.v01y == T(0) && t.v01x > T(0)))
+                         : (t.v01y > T(0) || (t.v01y == T(0) && t.v01x < T(0)));
+    return inside && !((on0 && !tl0) || (on1 && !tl1) || (on2 && !tl2));
+  }
+  return false;
+}
+
+__device__ __forceinline__ float sqrt_t(float x) {
+  return __fsqrt_rn(x);
+}
+__device__ __forceinline__ double sqrt_t(double x) {
+  return __dsqrt_rn(x);
+}
+
+// edge_grad_kernel.cu:89-100 ; normalize = v * (1 / sqrt(dot)) as on the reference's host path
+template <typename T>
+__device__ __forceinline__ void tri_normal(const T* __restrict__ v_n, TriInfo<T>& t) {
+  const T* p0 = v_n + 3 * (int64_t)t.i0;
+  const T* p1 = v_n + 3 * (int64_t)t.i1;
+  const T* p2 = v_n + 3 * (int64_t)t.i2;
+  const T ax = p0[0] - p2[0], ay = p0[1] - p2[1], az = p0[2] - p2[2];
+  const T bx = p1[0] - p0[0], by = p1[1] - p0[1], bz = p1[2] - p0[2];
+  const T cx = ay * bz - az * by;
+  const T cy = az * bx - ax * bz;
+  const T cz = ax * by - ay * bx;
+  const T inv = T(1.0) / sqrt_t(cx * cx + cy * cy + cz * cz);
+  t.nx = cx * inv;
+  t.ny = cy * inv;
+  t.nz = cz * inv;
+}
+
+// edge_grad_kernel.cu:102-203
+template <typename T>
+__device__ __forceinline__ void get_dp_dr(T nvx, T nvy, T nfx, T nfy, T M, T& ox, T& oy) {
+  const T inv_v = T(1.0) / sqrt_t(nvx * nvx + nvy * nvy);
+  const T nv_x = nvx * inv_v, nv_y = nvy * inv_v;
+  const T inv_f = T(1.0) / sqrt_t(nfx * nfx + nfy * nfy);
+  const T nf_x = nfx * inv_f, nf_y = nfy * inv_f;
+  const T bx = -nf_y, by = nf_x;
+  const T d = bx * nv_x + by * nv_y;
+  T q;
+  if (M > T(0)) {
+    const T abs_d = d < T(0) ? -d : d;
+    const T abs_bx = bx < T(0) ? -bx : bx;
+    const T lim = abs_bx / M;
+    const T m = abs_d < lim ? lim : abs_d;
+    const T safe_d = (d >= T(0) ? T(1) : T(-1)) * epsclamp(m);
+    q = bx / safe_d;
+  } else {
+    q = bx / epsclamp(d);
+  }
+  ox = q * nv_x;
+  oy = q * nv_y;
+}
+
+// Contributions of one pixel pair A (centre role) - B (right/down role).
+//   AXIS 0: B = A + (1,0), normals use (x,z);  AXIS 1: B = A + (0,1), normals use (y,z).
+// gA/gB: in-plane component (x or y), zA/zB: z component.  edge_grad_kernel.cu:303-425.
+template <typename T, int AXIS>
+__device__ __forceinline__ void eval_pair(
+    const T* __restrict__ v_n, TriInfo<T>& tA, TriInfo<T>& tB, int32_t idxA, int32_t idxB, int xa,
+    int ya, T grad_dot, T M, T& gA, T& zA, T& gB, T& zB) {
+  gA = zA = gB = zB = T(0);
+  const bool a_valid = idxA >= 0, b_valid = idxB >= 0;
+  const bool both = a_valid && b_valid;
+  const int xb = xa + (AXIS == 0 ? 1 : 0), yb = ya + (AXIS == 1 ? 1 : 0);
+  const bool a_in_b = both && pix_in_tri(tB, xa, ya);
+  const bool b_in_a = both && pix_in_tri(tA, xb, yb);
+  const bool a_over_b = a_in_b && !b_in_a;
+  const bool b_over_a = b_in_a && !a_in_b;
+  const bool inter = a_in_b && b_in_a;
+  const bool adjacent = both && !a_in_b && !b_in_a;
+  if (!inter) {
+    gA = (!a_valid || b_over_a || adjacent) ? T(0) : grad_dot;
+    gB = (!b_valid || a_over_b || adjacent) ? T(0) : grad_dot;
+  } else {
+    tri_normal(v_n, tA);
+    tri_normal(v_n, tB);
+    const T a_in = AXIS == 0 ? tA.nx : tA.ny;
+    const T b_in = AXIS == 0 ? tB.nx : tB.ny;
+    T dx, dz;
+    get_dp_dr<T>(a_in, tA.nz, b_in, tB.nz, M, dx, dz);
+    gA = grad_dot * dx;
+    zA = grad_dot * dz;
+    get_dp_dr<T>(b_in, tB.nz, a_in, tA.nz, M, dx, dz);
+    gB = grad_dot * dx;
+    zB = grad_dot * dz;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void edge_gather_kernel(
+    const T* __restrict__ v_pix, const int32_t* __restrict__ vi,
+    const int32_t* __restrict__ index_img, const T* __restrict__ gdx, const T* __restrict__ gdy,
+    int64_t V, int64_t vi_sN, int H, int W, T M, T* __restrict__ out) {
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int64_t pix = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (pix >= HW) return;
+  const int y = static_cast<int>(pix / W);
+  const int x = static_cast<int>(pix - int64_t(y) * W);
+  const int32_t* idx_n = index_img + int64_t(n) * HW;
+  const T* v_n = v_pix + int64_t(n) * V * 3;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  const T* gdx_n = gdx + int64_t(n) * HW;
+  const T* gdy_n = gdy + int64_t(n) * HW;
+
+  // stencil domain of the reference: centres with x < W-1 && y < H-1 (edge_grad_kernel.cu:270)
+  const bool own = (x < W - 1) && (y < H - 1);
+  const bool left = (x >= 1) && (y < H - 1); // pair (x-1,y)-(x,y), centre (x-1,y)
+  const bool up = (y >= 1) && (x < W - 1);   // pair (x,y-1)-(x,y), centre (x,y-1)
+
+  const int32_t ic = idx_n[pix];
+  const int32_t ir = own ? idx_n[pix + 1] : ic;
+  const int32_t id = own ? idx_n[pix + W] : ic;
+  const int32_t il = left ? idx_n[pix - 1] : ic;
+  const int32_t iu = up ? idx_n[pix - W] : ic;
+
+  T cx = T(0), cy = T(0), cz = T(0); // own centre contributions (gc)
+  T rx = T(0), rz = T(0);            // as right pixel of the left neighbour's stencil (gr)
+  T dy = T(0), dz = T(0);            // as down pixel of the upper neighbour's stencil (gd)
+
+  if (ic != ir || ic != id || ic != il || ic != iu) {
+    TriInfo<T> tc;
+    load_tri<T>(v_n, vi_n, ic, tc);
+    T gA, zA, gB, zB;
+    if (ic != ir) {
+      TriInfo<T> tn;
+      load_tri<T>(v_n, vi_n, ir, tn);
+      eval_pair<T, 0>(v_n, tc, tn, ic, ir, x, y, gdx_n[pix], M, gA, zA, gB, zB);
+      cx += gA;
+      cz += zA;
+    }
+    if (ic != id) {
+      TriInfo<T> tn;
+      load_tri<T>(v_n, vi_n, id, tn);
+      eval_pair<T, 1>(v_n, tc, tn, ic, id, x, y, gdy_n[pix], M, gA, zA, gB, zB);
+      cy += gA;
+      cz += zA;
+    }
+    if (il != ic) {
+      TriInfo<T> tn;
+      load_tri<T>(v_n, vi_n, il, tn);
+      eval_pair<T, 0>(v_n, tn, tc, il, ic, x - 1, y, gdx_n[pix - 1], M, gA, zA, gB, zB);
+      rx += gB;
+      rz += zB;
+    }
+    if (iu != ic) {
+      TriInfo<T> tn;
+      load_tri<T>(v_n, vi_n, iu, tn);
+      eval_pair<T, 1>(v_n, tn, tc, iu, ic, x, y - 1, gdy_n[pix - W], M, gA, zA, gB, zB);
+      dy += gB;
+      dz += zB;
+    }
+  }
+  // edge_grad_kernel.cu:427-445 negates and accumulates; order = the single-threaded reference
+  // order (upper neighbour's stencil, left neighbour's stencil, own stencil).
+  T* o = out + int64_t(n) * 3 * HW + pix;
+  o[0] = (T(0) + (-rx)) + (-cx);
+  o[HW] = (T(0) + (-dy)) + (-cy);
+  o[2 * HW] = ((T(0) + (-dz)) + (-rz)) + (-cz);
+}
+
+constexpr int kStripRows = 8;
+
+template <typename T>
+int edge_grad_backward_impl(
+    const T* v_pix, const T* img, const int32_t* index_img, const int32_t* vi, const T* grad_output,
+    int64_t N, int64_t V, int64_t C, int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, T* out,
+    void* workspace, hipStream_t stream) {
+  const int64_t HW = H * W;
+  if (N * HW == 0) return DRTK_OK;
+  T* gdx = static_cast<T*>(workspace);
+  T* gdy = gdx + N * HW;
+  const bool vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(img) % (4 * sizeof(T)) == 0) &&
+      (reinterpret_cast<uintptr_t>(grad_output) % (4 * sizeof(T)) == 0) &&
+      (reinterpret_cast<uintptr_t>(workspace) % (4 * sizeof(T)) == 0);
+  const int px_per_wave = kWave * (vec ? 4 : 1);
+  const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
+  const int strips_y = static_cast<int>(ceil_div(H, kStripRows));
+  const int64_t waves = int64_t(strips_x) * strips_y;
+  const dim3 gridA(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
+  if (vec) {
+    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows>), gridA, dim3(kBlock), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+  } else {
+    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows>), gridA, dim3(kBlock), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+  }
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  const dim3 gridB(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
+  hipLaunchKernelGGL((edge_gather_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out);
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}
+
+} // namespace
+} // namespace drtk_amd
+
+using namespace drtk_amd;
+
+extern "C" int drtk_amd_edge_grad_backward_workspace_bytes(
+    drtk_dtype_t dtype, int64_t N, int64_t H, int64_t W, size_t* bytes) {
+  if (!bytes || N < 0 || H < 0 || W < 0 || (dtype != DRTK_F32 && dtype != DRTK_F64)) return DRTK_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype == DRTK_F32 ? 4 : 8;
+  const size_t b = size_t(2) * N * H * W * es;
+  *bytes = b > 0 ? b : 16;
+  return DRTK_OK;
+}
+
+extern "C" int drtk_amd_edge_grad_backward(
+    drtk_dtype_t dtype, const void* v_pix, const void* img, const int32_t* index_img,
+    const int32_t* vi, const void* grad_output, int64_t N, int64_t V, int64_t C, int64_t F,
+    int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix_img, void* workspace,
+    size_t workspace_bytes, drtk_stream_t stream) {
+  if (N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || N > 65535 ||
+      (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31))
+    return DRTK_ERR_INVALID_ARGUMENT;
+  size_t need = 0;
+  if (drtk_amd_edge_grad_backward_workspace_bytes(dtype, N, H, W, &need) != DRTK_OK) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W > 0) {
+    if (!v_pix || !index_img || !vi || !grad_v_pix_img || !workspace) return DRTK_ERR_INVALID_ARGUMENT;
+    if (C > 0 && (!img || !grad_output)) return DRTK_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < need) return DRTK_ERR_WORKSPACE_TOO_SMALL;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case DRTK_F32:
+      return edge_grad_backward_impl<float>(static_cast<const float*>(v_pix), static_cast<const float*>(img), index_img, vi, static_cast<const float*>(grad_output), N, V, C, vi_sN, H, W, max_dp_dr, static_cast<float*>(grad_v_pix_img), workspace, s);
+    case DRTK_F64:
+      return edge_grad_backward_impl<double>(static_cast<const double*>(v_pix), static_cast<const double*>(img), index_img, vi, static_cast<const double*>(grad_output), N, V, C, vi_sN, H, W, max_dp_dr, static_cast<double*>(grad_v_pix_img), workspace, s);
+    default:
+      return DRTK_ERR_INVALID_ARGUMENT;
+  }
+}

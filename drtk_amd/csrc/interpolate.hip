@@ -1,0 +1,325 @@
+// interpolate -- barycentric interpolation of per-vertex attributes, forward and backward.
+//
+// Reference: src/interpolate/interpolate_kernel.cu:38-111 (forward), :113-299 (backward).
+// Forward: one lane = 4 adjacent pixels, so index/bary loads and every channel-plane store are
+// 16-byte vectors; attribute rows are gathered through L1/L2 as float4 when C % 4 == 0.
+// Backward: bary_grad is a per-pixel dot product; the vertex-attribute gradient goes through the
+// wave-level run reduction of segscatter.hpp in chunks of 16 channels (3*16 = 48 of the wave's 64
+// lanes own one (corner, channel) pair each), replacing the reference's per-channel
+// WarpReduce + __syncthreads + atomics loop.
+#include "common.hpp"
+#include "segscatter.hpp"
+
+namespace drtk_amd {
+namespace {
+
+constexpr int kChunk = 16; // channels per scatter chunk
+
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  using type = float4;
+};
+template <>
+struct Vec4<double> {
+  using type = double4;
+};
+
+template <typename T, int VEC, int CV>
+__global__ __launch_bounds__(kBlock) void interpolate_kernel(
+    const T* __restrict__ attrs, const int32_t* __restrict__ vi,
+    const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
+    int64_t vi_sN, int H, int W, T* __restrict__ out) {
+  using V4 = typename Vec4<T>::type;
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int64_t pix0 = (int64_t(blockIdx.x) * kBlock + threadIdx.x) * VEC;
+  if (pix0 >= HW) return;
+  const T* attrs_n = attrs + int64_t(n) * V * C;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  const int32_t* idx_p = index_img + int64_t(n) * HW + pix0;
+  const T* bary_p = bary_img + int64_t(n) * 3 * HW + pix0;
+  T* out_p = out + int64_t(n) * C * HW + pix0;
+
+  int32_t tr[VEC];
+  T B0[VEC], B1[VEC], B2[VEC];
+  if constexpr (VEC == 4) {
+    const int4 t4 = *reinterpret_cast<const int4*>(idx_p);
+    tr[0] = t4.x, tr[1] = t4.y, tr[2] = t4.z, tr[3] = t4.w;
+    const V4 a = *reinterpret_cast<const V4*>(bary_p);
+    const V4 b = *reinterpret_cast<const V4*>(bary_p + HW);
+    const V4 c = *reinterpret_cast<const V4*>(bary_p + 2 * HW);
+    B0[0] = a.x, B0[1] = a.y, B0[2] = a.z, B0[3] = a.w;
+    B1[0] = b.x, B1[1] = b.y, B1[2] = b.z, B1[3] = b.w;
+    B2[0] = c.x, B2[1] = c.y, B2[2] = c.z, B2[3] = c.w;
+  } else {
+    tr[0] = idx_p[0];
+    B0[0] = bary_p[0], B1[0] = bary_p[HW], B2[0] = bary_p[2 * HW];
+  }
+  const int y = static_cast<int>(pix0 / W);
+  const int x0 = static_cast<int>(pix0 - int64_t(y) * W);
+
+  const T* a0[VEC];
+  const T* a1[VEC];
+  const T* a2[VEC];
+  T bgx[VEC];
+  // "undefined region" sweep (interpolate_kernel.cu:104-108, CPU twin interpolate_kernel_cpu.cpp:99-104)
+  const T bgy = (static_cast<T>(y) * T(2.0) + T(1.0)) / static_cast<T>(H) - T(1.0);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    if (tr[j] != -1) {
+      const int32_t* face = vi_n + int64_t(tr[j]) * 3;
+      a0[j] = attrs_n + int64_t(face[0]) * C;
+      a1[j] = attrs_n + int64_t(face[1]) * C;
+      a2[j] = attrs_n + int64_t(face[2]) * C;
+    } else {
+      a0[j] = a1[j] = a2[j] = attrs_n;
+    }
+    bgx[j] = (static_cast<T>(x0 + j) * T(2.0) + T(1.0)) / static_cast<T>(W) - T(1.0);
+  }
+
+  for (int c0 = 0; c0 < C; c0 += CV) {
+    T r[CV][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (tr[j] != -1) {
+        T u0[CV], u1[CV], u2[CV];
+        if constexpr (CV == 4) {
+          const V4 q0 = *reinterpret_cast<const V4*>(a0[j] + c0);
+          const V4 q1 = *reinterpret_cast<const V4*>(a1[j] + c0);
+          const V4 q2 = *reinterpret_cast<const V4*>(a2[j] + c0);
+          u0[0] = q0.x, u0[1] = q0.y, u0[2] = q0.z, u0[3] = q0.w;
+          u1[0] = q1.x, u1[1] = q1.y, u1[2] = q1.z, u1[3] = q1.w;
+          u2[0] = q2.x, u2[1] = q2.y, u2[2] = q2.z, u2[3] = q2.w;
+        } else {
+          u0[0] = a0[j][c0], u1[0] = a1[j][c0], u2[0] = a2[j][c0];
+        }
+#pragma unroll
+        for (int cc = 0; cc < CV; ++cc) r[cc][j] = u0[cc] * B0[j] + u1[cc] * B1[j] + u2[cc] * B2[j];
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < CV; ++cc) r[cc][j] = ((c0 + cc) & 1) ? bgy : bgx[j];
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < CV; ++cc) {
+      T* o = out_p + int64_t(c0 + cc) * HW;
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<V4*>(o) = V4{r[cc][0], r[cc][1], r[cc][2], r[cc][3]};
+      } else {
+        o[0] = r[cc][0];
+      }
+    }
+  }
+}
+
+// Backward.  lane = pixel; 64 consecutive pixels of one view per wave.
+template <typename T, bool HAS_VERT, bool HAS_BARY, int CV>
+__global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
+    const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
+    const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
+    int64_t vi_sN, int H, int W, T* __restrict__ attr_grad, T* __restrict__ bary_grad) {
+  using V4 = typename Vec4<T>::type;
+  constexpr int kWaves = kBlock / kWave;
+  __shared__ T s_g[HAS_VERT ? kWaves : 1][HAS_VERT ? kChunk * kRunPad : 1];
+  __shared__ T s_b[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
+  __shared__ int32_t s_vidx[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
+
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int wave = threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t pix = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = pix < HW;
+  const T* attrs_n = attrs + int64_t(n) * V * C;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  const T* go_p = grad_out + int64_t(n) * C * HW + pix;
+
+  const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
+  const bool covered = tr != -1;
+  int32_t vid0 = 0, vid1 = 0, vid2 = 0;
+  if (covered) {
+    const int32_t* face = vi_n + int64_t(tr) * 3;
+    vid0 = face[0], vid1 = face[1], vid2 = face[2];
+  }
+  unsigned long long heads = 0, cov = 0;
+  if constexpr (HAS_VERT) {
+    T B0 = T(0), B1 = T(0), B2 = T(0);
+    if (covered) {
+      const T* bp = bary_img + int64_t(n) * 3 * HW + pix;
+      B0 = bp[0], B1 = bp[HW], B2 = bp[2 * HW];
+    }
+    s_b[wave][0 * kRunPad + lane] = B0;
+    s_b[wave][1 * kRunPad + lane] = B1;
+    s_b[wave][2 * kRunPad + lane] = B2;
+    s_vidx[wave][0 * kRunPad + lane] = vid0;
+    s_vidx[wave][1 * kRunPad + lane] = vid1;
+    s_vidx[wave][2 * kRunPad + lane] = vid2;
+    run_masks(tr, heads, cov);
+  }
+  const T* a0 = attrs_n + int64_t(vid0) * C;
+  const T* a1 = attrs_n + int64_t(vid1) * C;
+  const T* a2 = attrs_n + int64_t(vid2) * C;
+
+  T bg0 = T(0), bg1 = T(0), bg2 = T(0);
+  for (int c0 = 0; c0 < C; c0 += kChunk) {
+    const int CC = min(kChunk, C - c0);
+    if (covered) {
+      for (int cb = 0; cb < CC; cb += CV) {
+        T g[CV];
+#pragma unroll
+        for (int cc = 0; cc < CV; ++cc) g[cc] = go_p[int64_t(c0 + cb + cc) * HW];
+        if constexpr (HAS_VERT) {
+#pragma unroll
+          for (int cc = 0; cc < CV; ++cc) s_g[wave][(cb + cc) * kRunPad + lane] = g[cc];
+        }
+        if constexpr (HAS_BARY) {
+          T u0[CV], u1[CV], u2[CV];
+          if constexpr (CV == 4) {
+            const V4 q0 = *reinterpret_cast<const V4*>(a0 + c0 + cb);
+            const V4 q1 = *reinterpret_cast<const V4*>(a1 + c0 + cb);
+            const V4 q2 = *reinterpret_cast<const V4*>(a2 + c0 + cb);
+            u0[0] = q0.x, u0[1] = q0.y, u0[2] = q0.z, u0[3] = q0.w;
+            u1[0] = q1.x, u1[1] = q1.y, u1[2] = q1.z, u1[3] = q1.w;
+            u2[0] = q2.x, u2[1] = q2.y, u2[2] = q2.z, u2[3] = q2.w;
+          } else {
+            u0[0] = a0[c0 + cb], u1[0] = a1[c0 + cb], u2[0] = a2[c0 + cb];
+          }
+#pragma unroll
+          for (int cc = 0; cc < CV; ++cc) { // interpolate_kernel.cu:238-246 accumulation order
+            bg0 += g[cc] * u0[cc];
+            bg1 += g[cc] * u1[cc];
+            bg2 += g[cc] * u2[cc];
+          }
+        }
+      }
+    }
+    if constexpr (HAS_VERT) {
+      __syncthreads();
+      if (cov != 0) {
+        const T* sg = s_g[wave];
+        const T* sb = s_b[wave];
+        scatter_runs<T>(
+            heads, cov, s_vidx[wave], 3 * CC, CC, attr_grad + int64_t(n) * V * C, C, c0,
+            [sg, sb](int k, int c, int p) { return sg[c * kRunPad + p] * sb[k * kRunPad + p]; });
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr (HAS_BARY) {
+    if (in_range) {
+      T* bgp = bary_grad + int64_t(n) * 3 * HW + pix;
+      bgp[0] = bg0;
+      bgp[HW] = bg1;
+      bgp[2 * HW] = bg2;
+    }
+  }
+}
+
+template <typename T>
+int interpolate_impl(
+    const T* attrs, const int32_t* vi, const int32_t* index_img, const T* bary_img, int64_t N,
+    int64_t V, int64_t C, int64_t vi_sN, int64_t H, int64_t W, T* out, hipStream_t stream) {
+  const int64_t HW = H * W;
+  if (N * HW * C == 0) return DRTK_OK;
+  const bool pvec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(index_img) % 16 == 0) &&
+      (reinterpret_cast<uintptr_t>(bary_img) % (4 * sizeof(T)) == 0) &&
+      (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0);
+  const bool cvec = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(attrs) % (4 * sizeof(T)) == 0);
+  const dim3 block(kBlock);
+#define LAUNCH(VEC, CV)                                                                         \
+  hipLaunchKernelGGL(                                                                           \
+      (interpolate_kernel<T, VEC, CV>),                                                         \
+      dim3(static_cast<unsigned>(ceil_div(HW / VEC, kBlock)), static_cast<unsigned>(N)), block, \
+      0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out)
+  if (pvec && cvec)
+    LAUNCH(4, 4);
+  else if (pvec)
+    LAUNCH(4, 1);
+  else if (cvec)
+    LAUNCH(1, 4);
+  else
+    LAUNCH(1, 1);
+#undef LAUNCH
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}
+
+template <typename T>
+int interpolate_backward_impl(
+    const T* grad_out, const T* attrs, const int32_t* vi, const int32_t* index_img,
+    const T* bary_img, int64_t N, int64_t V, int64_t C, int64_t vi_sN, int64_t H, int64_t W,
+    T* attr_grad, T* bary_grad, hipStream_t stream) {
+  if (attr_grad && N * V * C > 0) {
+    if (hipMemsetAsync(attr_grad, 0, sizeof(T) * N * V * C, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+  }
+  const int64_t HW = H * W;
+  if (N * HW == 0) return DRTK_OK;
+  if (C == 0) {
+    if (bary_grad && hipMemsetAsync(bary_grad, 0, sizeof(T) * N * 3 * HW, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+    return DRTK_OK;
+  }
+  const bool cvec = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(attrs) % (4 * sizeof(T)) == 0);
+  const dim3 grid(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
+  const dim3 block(kBlock);
+#define LAUNCH(HV, HB, CV)                                                                      \
+  hipLaunchKernelGGL(                                                                           \
+      (interpolate_backward_kernel<T, HV, HB, CV>), grid, block, 0, stream, grad_out, attrs, vi, \
+      index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, attr_grad, bary_grad)
+  if (attr_grad && bary_grad) {
+    if (cvec) LAUNCH(true, true, 4); else LAUNCH(true, true, 1);
+  } else if (attr_grad) {
+    LAUNCH(true, false, 1);
+  } else {
+    if (cvec) LAUNCH(false, true, 4); else LAUNCH(false, true, 1);
+  }
+#undef LAUNCH
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}
+
+bool bad_common(int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H, int64_t W) {
+  return N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || N > 65535 || C >= (1 << 20) ||
+      (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31);
+}
+
+} // namespace
+} // namespace drtk_amd
+
+using namespace drtk_amd;
+
+extern "C" int drtk_amd_interpolate(
+    drtk_dtype_t dtype, const void* attrs, const int32_t* vi, const int32_t* index_img,
+    const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H,
+    int64_t W, void* out, drtk_stream_t stream) {
+  if (bad_common(N, V, C, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W * C > 0 && (!attrs || !vi || !index_img || !bary_img || !out)) return DRTK_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case DRTK_F32:
+      return interpolate_impl<float>(static_cast<const float*>(attrs), vi, index_img, static_cast<const float*>(bary_img), N, V, C, vi_sN, H, W, static_cast<float*>(out), s);
+    case DRTK_F64:
+      return interpolate_impl<double>(static_cast<const double*>(attrs), vi, index_img, static_cast<const double*>(bary_img), N, V, C, vi_sN, H, W, static_cast<double*>(out), s);
+    default:
+      return DRTK_ERR_INVALID_ARGUMENT;
+  }
+}
+
+extern "C" int drtk_amd_interpolate_backward(
+    drtk_dtype_t dtype, const void* grad_out, const void* attrs, const int32_t* vi,
+    const int32_t* index_img, const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F,
+    int64_t vi_sN, int64_t H, int64_t W, void* attr_grad, void* bary_grad, drtk_stream_t stream) {
+  if (bad_common(N, V, C, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (!attr_grad && !bary_grad) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W * C > 0 && (!grad_out || !attrs || !vi || !index_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case DRTK_F32:
+      return interpolate_backward_impl<float>(static_cast<const float*>(grad_out), static_cast<const float*>(attrs), vi, index_img, static_cast<const float*>(bary_img), N, V, C, vi_sN, H, W, static_cast<float*>(attr_grad), static_cast<float*>(bary_grad), s);
+    case DRTK_F64:
+      return interpolate_backward_impl<double>(static_cast<const double*>(grad_out), static_cast<const double*>(attrs), vi, index_img, static_cast<const double*>(bary_img), N, V, C, vi_sN, H, W, static_cast<double*>(attr_grad), static_cast<double*>(bary_grad), s);
+    default:
+      return DRTK_ERR_INVALID_ARGUMENT;
+  }
+}

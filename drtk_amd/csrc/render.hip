@@ -1,0 +1,305 @@
+// render -- per-pixel perspective-correct barycentrics + depth, and its analytic backward.
+//
+// Reference: src/render/render_kernel.cu:19-117 (forward), :119-281 (backward).  Forward is a
+// pure stream: 4 B/px of index in, 16 B/px out, triangle data gathered through L2.  Each lane
+// handles 4 horizontally adjacent pixels so that every global access is a 16-byte vector
+// (index int4 in; depth + three bary planes float4 out).
+// Backward produces 9 values per covered pixel that the reference scatters with 9 atomics per
+// pixel; here they go through the wave-level run reduction of segscatter.hpp.
+#include "common.hpp"
+#include "segscatter.hpp"
+
+namespace drtk_amd {
+namespace {
+
+// Everything the forward and the backward share (render_kernel.cu:68-101 == :174-218).
+template <typename T>
+struct RenderPix {
+  int32_t vi0, vi1, vi2;
+  T v01x, v01y, v02x, v02y;
+  T den_raw, den;
+  T vp0x, vp0y;
+  T b0, b1, b2;
+  T z0e, z1e, z2e;
+  bool z0c, z1c, z2c;
+  T dinv0, dinv1, dinv2;
+  T depth_inverse, depth_inverse_eps, depth;
+};
+
+template <typename T>
+__device__ __forceinline__ void render_pix(
+    const T* __restrict__ v_n, const int32_t* __restrict__ face, int x, int y, RenderPix<T>& r) {
+  r.vi0 = face[0];
+  r.vi1 = face[1];
+  r.vi2 = face[2];
+  const T* q0 = v_n + 3 * (int64_t)r.vi0;
+  const T* q1 = v_n + 3 * (int64_t)r.vi1;
+  const T* q2 = v_n + 3 * (int64_t)r.vi2;
+  const T p0x = q0[0], p0y = q0[1], p0z = q0[2];
+  const T p1x = q1[0], p1y = q1[1], p1z = q1[2];
+  const T p2x = q2[0], p2y = q2[1], p2z = q2[2];
+  r.v01x = p1x - p0x;
+  r.v01y = p1y - p0y;
+  r.v02x = p2x - p0x;
+  r.v02y = p2y - p0y;
+  r.den_raw = r.v01x * r.v02y - r.v01y * r.v02x;
+  r.den = epsclamp(r.den_raw);
+  r.vp0x = static_cast<T>(x) - p0x;
+  r.vp0y = static_cast<T>(y) - p0y;
+  const T b1_pre = r.vp0x * r.v02y - r.vp0y * r.v02x;
+  const T b2_pre = r.vp0y * r.v01x - r.vp0x * r.v01y;
+  r.b1 = b1_pre / r.den;
+  r.b2 = b2_pre / r.den;
+  r.b0 = T(1.0) - r.b1 - r.b2;
+  r.z0e = epsclamp(p0z);
+  r.z1e = epsclamp(p1z);
+  r.z2e = epsclamp(p2z);
+  r.z0c = r.z0e != p0z;
+  r.z1c = r.z1e != p1z;
+  r.z2c = r.z2e != p2z;
+  r.dinv0 = T(1.0) / r.z0e;
+  r.dinv1 = T(1.0) / r.z1e;
+  r.dinv2 = T(1.0) / r.z2e;
+  r.depth_inverse = r.dinv0 * r.b0 + r.dinv1 * r.b1 + r.dinv2 * r.b2;
+  r.depth_inverse_eps = epsclamp(r.depth_inverse);
+  r.depth = T(1.0) / r.depth_inverse_eps;
+}
+
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  using type = float4;
+};
+template <>
+struct Vec4<double> {
+  using type = double4;
+};
+
+// VEC = 4: W % 4 == 0, one lane = 4 adjacent pixels of a row; VEC = 1: generic fallback.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void render_kernel(
+    const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
+    int64_t V, int64_t vi_sN, int H, int W, T* __restrict__ depth_img, T* __restrict__ bary_img) {
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int64_t pix0 = (int64_t(blockIdx.x) * kBlock + threadIdx.x) * VEC; // pixel within the view
+  if (pix0 >= HW) return;
+  const T* v_n = v + int64_t(n) * V * 3;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  const int32_t* idx_p = index_img + int64_t(n) * HW + pix0;
+  T* depth_p = depth_img + int64_t(n) * HW + pix0;
+  T* bary_p = bary_img + int64_t(n) * 3 * HW + pix0;
+
+  int32_t tr[VEC];
+  if constexpr (VEC == 4) {
+    const int4 t4 = *reinterpret_cast<const int4*>(idx_p);
+    tr[0] = t4.x;
+    tr[1] = t4.y;
+    tr[2] = t4.z;
+    tr[3] = t4.w;
+  } else {
+    tr[0] = idx_p[0];
+  }
+  const int y = static_cast<int>(pix0 / W);
+  const int x0 = static_cast<int>(pix0 - int64_t(y) * W);
+
+  T d[VEC], b0[VEC], b1[VEC], b2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    if (tr[j] != -1) {
+      RenderPix<T> r;
+      render_pix<T>(v_n, vi_n + int64_t(tr[j]) * 3, x0 + j, y, r);
+      b0[j] = r.dinv0 * r.b0 * r.depth;
+      b1[j] = r.dinv1 * r.b1 * r.depth;
+      b2[j] = r.dinv2 * r.b2 * r.depth;
+      d[j] = r.depth;
+    } else {
+      b0[j] = b1[j] = b2[j] = d[j] = T(0);
+    }
+  }
+  if constexpr (VEC == 4) {
+    using V4 = typename Vec4<T>::type;
+    *reinterpret_cast<V4*>(depth_p) = V4{d[0], d[1], d[2], d[3]};
+    *reinterpret_cast<V4*>(bary_p) = V4{b0[0], b0[1], b0[2], b0[3]};
+    *reinterpret_cast<V4*>(bary_p + HW) = V4{b1[0], b1[1], b1[2], b1[3]};
+    *reinterpret_cast<V4*>(bary_p + 2 * HW) = V4{b2[0], b2[1], b2[2], b2[3]};
+  } else {
+    depth_p[0] = d[0];
+    bary_p[0] = b0[0];
+    bary_p[HW] = b1[0];
+    bary_p[2 * HW] = b2[0];
+  }
+}
+
+// Backward: lane = pixel (64 consecutive pixels of one view per wave).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void render_backward_kernel(
+    const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
+    const T* __restrict__ grad_depth_img, const T* __restrict__ grad_bary_img, int64_t V,
+    int64_t vi_sN, int H, int W, T* __restrict__ grad_v) {
+  constexpr int kWaves = kBlock / kWave;
+  __shared__ T s_val[kWaves][9 * kRunPad];
+  __shared__ int32_t s_vidx[kWaves][3 * kRunPad];
+
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int wave = threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t pix = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = pix < HW;
+  const T* v_n = v + int64_t(n) * V * 3;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+
+  const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
+  T g[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) g[j] = T(0);
+  int32_t vid[3] = {0, 0, 0};
+
+  if (tr != -1) {
+    const int y = static_cast<int>(pix / W);
+    const int x = static_cast<int>(pix - int64_t(y) * W);
+    RenderPix<T> r;
+    render_pix<T>(v_n, vi_n + int64_t(tr) * 3, x, y, r);
+    vid[0] = r.vi0;
+    vid[1] = r.vi1;
+    vid[2] = r.vi2;
+    const bool den_clamped = r.den != r.den_raw;
+    const bool dinv_clamped = r.depth_inverse_eps != r.depth_inverse;
+
+    const T* gb = grad_bary_img + int64_t(n) * 3 * HW + pix;
+    const T dL_B0 = gb[0], dL_B1 = gb[HW], dL_B2 = gb[2 * HW];
+    // render_kernel.cu:225 : *grad_depth + dot(dL_bary_3D * d_inv, bary)
+    const T dL_depth = grad_depth_img[int64_t(n) * HW + pix] + dL_B0 * r.dinv0 * r.b0 +
+        dL_B1 * r.dinv1 * r.b1 + dL_B2 * r.dinv2 * r.b2;
+    const T dL_dinv_s =
+        dinv_clamped ? T(0) : (-dL_depth / (r.depth_inverse * r.depth_inverse));
+
+    const T dL_dinv0 = dL_B0 * r.b0 * r.depth + dL_dinv_s * r.b0;
+    const T dL_dinv1 = dL_B1 * r.b1 * r.depth + dL_dinv_s * r.b1;
+    const T dL_dinv2 = dL_B2 * r.b2 * r.depth + dL_dinv_s * r.b2;
+    g[2] = r.z0c ? T(0) : (-dL_dinv0 / (r.z0e * r.z0e));
+    g[5] = r.z1c ? T(0) : (-dL_dinv1 / (r.z1e * r.z1e));
+    g[8] = r.z2c ? T(0) : (-dL_dinv2 / (r.z2e * r.z2e));
+
+    const T dL_b0 = dL_B0 * r.dinv0 * r.depth + dL_dinv_s * r.dinv0;
+    const T dL_b1 = dL_B1 * r.dinv1 * r.depth + dL_dinv_s * r.dinv1;
+    const T dL_b2 = dL_B2 * r.dinv2 * r.depth + dL_dinv_s * r.dinv2;
+    const T dL_b12x = -dL_b0 + dL_b1;
+    const T dL_b12y = -dL_b0 + dL_b2;
+    const T prex = dL_b12x / r.den;
+    const T prey = dL_b12y / r.den;
+    const T dL_den = den_clamped ? T(0) : -(prex * r.b1 + prey * r.b2);
+
+    const T dL_vp0x = prex * r.v02y - prey * r.v01y;
+    const T dL_vp0y = -prex * r.v02x + prey * r.v01x;
+    const T dL_v02x = -prex * r.vp0y - dL_den * r.v01y;
+    const T dL_v02y = prex * r.vp0x + dL_den * r.v01x;
+    const T dL_v01x = prey * r.vp0y + dL_den * r.v02y;
+    const T dL_v01y = -prey * r.vp0x - dL_den * r.v02x;
+
+    g[0] = -dL_v02x - dL_v01x - dL_vp0x;
+    g[1] = -dL_v02y - dL_v01y - dL_vp0y;
+    g[3] = dL_v01x;
+    g[4] = dL_v01y;
+    g[6] = dL_v02x;
+    g[7] = dL_v02y;
+  }
+
+#pragma unroll
+  for (int j = 0; j < 9; ++j) s_val[wave][j * kRunPad + lane] = g[j];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s_vidx[wave][k * kRunPad + lane] = vid[k];
+
+  unsigned long long heads, cov;
+  run_masks(tr, heads, cov);
+  __syncthreads();
+  if (cov == 0) return;
+
+  const T* sv = s_val[wave];
+  scatter_runs<T>(
+      heads, cov, s_vidx[wave], 9, 3, grad_v + int64_t(n) * V * 3, 3, 0,
+      [sv](int k, int c, int p) { return sv[(k * 3 + c) * kRunPad + p]; });
+}
+
+template <typename T>
+int render_impl(
+    const T* v, const int32_t* vi, const int32_t* index_img, int64_t N, int64_t V, int64_t vi_sN,
+    int64_t H, int64_t W, T* depth_img, T* bary_img, hipStream_t stream) {
+  const int64_t HW = H * W;
+  if (N * HW == 0) return DRTK_OK;
+  const bool vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(index_img) % 16 == 0) &&
+      (reinterpret_cast<uintptr_t>(depth_img) % (4 * sizeof(T)) == 0) &&
+      (reinterpret_cast<uintptr_t>(bary_img) % (4 * sizeof(T)) == 0);
+  if (vec) {
+    dim3 grid(static_cast<unsigned>(ceil_div(HW / 4, kBlock)), static_cast<unsigned>(N));
+    hipLaunchKernelGGL((render_kernel<T, 4>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img);
+  } else {
+    dim3 grid(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
+    hipLaunchKernelGGL((render_kernel<T, 1>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img);
+  }
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}
+
+template <typename T>
+int render_backward_impl(
+    const T* v, const int32_t* vi, const int32_t* index_img, const T* grad_depth_img,
+    const T* grad_bary_img, int64_t N, int64_t V, int64_t vi_sN, int64_t H, int64_t W, T* grad_v,
+    hipStream_t stream) {
+  if (N * V > 0) {
+    if (hipMemsetAsync(grad_v, 0, sizeof(T) * N * V * 3, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+  }
+  const int64_t HW = H * W;
+  if (N * HW == 0) return DRTK_OK;
+  dim3 grid(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
+  hipLaunchKernelGGL((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, grad_v);
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}
+
+bool bad_common(int64_t N, int64_t V, int64_t F, int64_t vi_sN, int64_t H, int64_t W) {
+  return N < 0 || V < 0 || F < 0 || H < 0 || W < 0 || N > 65535 || (vi_sN != 0 && vi_sN != F * 3) ||
+      H * W >= (int64_t(1) << 31);
+}
+
+} // namespace
+} // namespace drtk_amd
+
+using namespace drtk_amd;
+
+extern "C" int drtk_amd_render(
+    drtk_dtype_t dtype, const void* v, const int32_t* vi, const int32_t* index_img, int64_t N,
+    int64_t V, int64_t F, int64_t vi_sN, int64_t H, int64_t W, void* depth_img, void* bary_img,
+    drtk_stream_t stream) {
+  if (bad_common(N, V, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W > 0 && (!v || !vi || !index_img || !depth_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case DRTK_F32:
+      return render_impl<float>(static_cast<const float*>(v), vi, index_img, N, V, vi_sN, H, W, static_cast<float*>(depth_img), static_cast<float*>(bary_img), s);
+    case DRTK_F64:
+      return render_impl<double>(static_cast<const double*>(v), vi, index_img, N, V, vi_sN, H, W, static_cast<double*>(depth_img), static_cast<double*>(bary_img), s);
+    default:
+      return DRTK_ERR_INVALID_ARGUMENT;
+  }
+}
+
+extern "C" int drtk_amd_render_backward(
+    drtk_dtype_t dtype, const void* v, const int32_t* vi, const int32_t* index_img,
+    const void* grad_depth_img, const void* grad_bary_img, int64_t N, int64_t V, int64_t F,
+    int64_t vi_sN, int64_t H, int64_t W, void* grad_v, drtk_stream_t stream) {
+  if (bad_common(N, V, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * V > 0 && !grad_v) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W > 0 && (!v || !vi || !index_img || !grad_depth_img || !grad_bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case DRTK_F32:
+      return render_backward_impl<float>(static_cast<const float*>(v), vi, index_img, static_cast<const float*>(grad_depth_img), static_cast<const float*>(grad_bary_img), N, V, vi_sN, H, W, static_cast<float*>(grad_v), s);
+    case DRTK_F64:
+      return render_backward_impl<double>(static_cast<const double*>(v), vi, index_img, static_cast<const double*>(grad_depth_img), static_cast<const double*>(grad_bary_img), N, V, vi_sN, H, W, static_cast<double*>(grad_v), s);
+    default:
+      return DRTK_ERR_INVALID_ARGUMENT;
+  }
+}

@@ -1,0 +1,599 @@
+// Torch-operator shim over the drtk_amd C ABI (include/drtk_amd.h).
+//
+// Registers the reference's four operator schemas VERBATIM, under the same namespaces, with the
+// same dispatch keys and the same autograd contracts, so that `drtk.*` Python code and any caller
+// of `torch.ops.<name>_ext.<op>` runs unchanged under PyTorch-ROCm:
+//
+//   rasterize_ext::rasterize          src/rasterize/rasterize_module.cpp:16-95
+//   render_ext::render                src/render/render_module.cpp:16-107
+//   interpolate_ext::interpolate      src/interpolate/interpolate_module.cpp:376-433,584-669
+//   edge_grad_ext::edge_grad_estimator   src/edge_grad/edge_grad_module.cpp:18-224
+//
+// This file is host-only C++ (no device code); the kernels live in libdrtk_amd.so.  There is NO
+// CPU compute path: the CPU key is registered only to fail with a clear message.
+#include <ATen/ATen.h>
+#include <ATen/autocast_mode.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/library.h>
+
+#include "drtk_amd.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::tensor_list;
+
+drtk_dtype_t dtype_of(const Tensor& t, const char* op) {
+  switch (t.scalar_type()) {
+    case at::kFloat:
+      return DRTK_F32;
+    case at::kDouble:
+      return DRTK_F64;
+    default:
+      // src/include/kernel_utils.h:35-57 : float and double only
+      TORCH_CHECK(false, "\"", op, "\" not implemented for '", toString(t.scalar_type()), "'");
+  }
+}
+
+drtk_stream_t current_stream(const Tensor& t) {
+  return static_cast<drtk_stream_t>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
+
+void check_status(int status, const char* op) {
+  TORCH_CHECK(status == DRTK_OK, op, "(): ", drtk_amd_status_string(status), " [drtk_amd status ", status, "]");
+}
+
+// vi arrives as [N,F,3]; the Python wrappers build it with a stride-0 expand from [F,3]
+// (drtk/rasterize.py:61-62).  Keep that broadcast instead of materialising N copies.
+struct ViArg {
+  Tensor holder;
+  const int32_t* ptr;
+  int64_t sN;
+};
+ViArg prep_vi(const Tensor& vi) {
+  ViArg a;
+  if (vi.size(0) > 1 && vi.stride(0) == 0) {
+    a.holder = vi.select(0, 0).contiguous();
+    a.sN = 0;
+  } else {
+    a.holder = vi.contiguous();
+    a.sN = vi.size(1) * 3;
+  }
+  a.ptr = a.holder.data_ptr<int32_t>();
+  return a;
+}
+
+Tensor alloc_workspace(size_t bytes, const Tensor& like) {
+  return at::empty({static_cast<int64_t>(bytes)}, like.options().dtype(at::kByte));
+}
+
+[[noreturn]] void no_cpu(const char* op) {
+  TORCH_CHECK(false, op, "(): drtk_amd implements the MI355X (HIP) path only; got CPU tensors");
+}
+
+// ---------------------------------------------------------------------------------------------
+// rasterize
+// ---------------------------------------------------------------------------------------------
+std::vector<Tensor> rasterize_hip(
+    const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {
+  // checks and messages follow rasterize_kernel.cu:423-468
+  TORCH_CHECK(v.defined() && vi.defined(), "rasterize(): expected all inputs to be defined");
+  TORCH_CHECK(
+      (v.device() == vi.device()) && v.is_cuda(),
+      "rasterize(): expected all inputs to be on same cuda device");
+  TORCH_CHECK(v.is_floating_point(), "rasterize(): expected v to have floating point type, but v has ", v.dtype());
+  TORCH_CHECK(vi.dtype() == at::kInt, "rasterize(): expected vi to have int32 type, but vi has ", vi.dtype());
+  TORCH_CHECK(
+      v.layout() == at::kStrided && vi.layout() == at::kStrided,
+      "rasterize(): expected all inputs to have torch.strided layout");
+  TORCH_CHECK(
+      (v.dim() == 3) && (vi.dim() == 3),
+      "rasterize(): expected v.ndim == 3, vi.ndim == 3, but got v with sizes ", v.sizes(),
+      " and vi with sizes ", vi.sizes());
+  TORCH_CHECK(
+      v.size(2) == 3 && vi.size(2) == 3,
+      "rasterize(): expected third dim of v and last dim of vi to be 3, but got ", v.size(2), " and ", vi.size(2));
+  TORCH_CHECK(
+      vi.size(0) == v.size(0),
+      "rasterize(): expected first dim of vi to match first dim of v, but got ", v.size(0), " and ", vi.size(0));
+  TORCH_CHECK(
+      v.size(1) < 0x10000000LL,
+      "rasterize(): expected second dim of v to be less than 268435456, but got ", v.size(1));
+  TORCH_CHECK(
+      height > 0 && width > 0,
+      "rasterize(): both height and width must be > 0, but got height: ", height, ", width: ", width);
+  TORCH_CHECK(!wireframe, "rasterize(): wireframe mode is not implemented by drtk_amd yet");
+  const drtk_dtype_t dt = dtype_of(v, "rasterize");
+
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
+  const auto v_c = v.contiguous();
+  const ViArg via = prep_vi(vi);
+  const int64_t N = v.size(0), V = v.size(1), F = vi.size(1);
+  auto depth_img = at::empty({N, height, width}, v.options().dtype(at::kFloat));
+  auto index_img = at::empty({N, height, width}, v.options().dtype(at::kInt));
+  size_t ws_bytes = 0;
+  check_status(drtk_amd_rasterize_workspace_bytes(N, F, height, width, &ws_bytes), "rasterize");
+  auto ws = alloc_workspace(ws_bytes, v);
+  check_status(
+      drtk_amd_rasterize(
+          dt, v_c.data_ptr(), via.ptr, N, V, F, via.sN, height, width, 0, depth_img.data_ptr<float>(),
+          index_img.data_ptr<int32_t>(), ws.data_ptr(), ws_bytes, current_stream(v)),
+      "rasterize");
+  return {depth_img, index_img};
+}
+
+std::vector<Tensor> rasterize_cpu(const Tensor&, const Tensor&, int64_t, int64_t, bool) {
+  no_cpu("rasterize");
+}
+
+tensor_list rasterize_op(const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("rasterize_ext::rasterize", "")
+                       .typed<decltype(rasterize_op)>();
+  return op.call(v, vi, height, width, wireframe);
+}
+
+class RasterizeFunction : public torch::autograd::Function<RasterizeFunction> {
+ public:
+  static tensor_list forward(
+      AutogradContext* ctx, const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {
+    ctx->set_materialize_grads(false);
+    at::AutoDispatchBelowADInplaceOrView g;
+    auto outputs = rasterize_op(v, vi, height, width, wireframe);
+    ctx->mark_non_differentiable(outputs); // rasterize_module.cpp:43
+    return outputs;
+  }
+  static tensor_list backward(AutogradContext*, const tensor_list&) {
+    return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+tensor_list rasterize_autograd(const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {
+  return RasterizeFunction::apply(v, vi, height, width, wireframe);
+}
+
+tensor_list rasterize_autocast(const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {
+  c10::impl::ExcludeDispatchKeyGuard no_autocast(c10::DispatchKey::Autocast);
+  return rasterize_op(at::autocast::cached_cast(at::kFloat, v), vi, height, width, wireframe);
+}
+
+// ---------------------------------------------------------------------------------------------
+// render
+// ---------------------------------------------------------------------------------------------
+void render_checks(const Tensor& v, const Tensor& vi, const Tensor& index_img) {
+  // render_kernel.cu:285-336
+  TORCH_CHECK(v.defined() && vi.defined() && index_img.defined(), "render(): expected all inputs to be defined");
+  TORCH_CHECK(
+      (v.device() == vi.device()) && (v.device() == index_img.device()) && v.is_cuda(),
+      "render(): expected all inputs to be on same cuda device");
+  TORCH_CHECK(v.is_floating_point(), "render(): expected v to have floating point type, but v has ", v.dtype());
+  TORCH_CHECK(vi.dtype() == at::kInt, "render(): expected vi to have int32 type, but vi has ", vi.dtype());
+  TORCH_CHECK(
+      index_img.dtype() == at::kInt,
+      "render(): expected index_img to have int32 type, but index_img has ", index_img.dtype());
+  TORCH_CHECK(
+      v.layout() == at::kStrided && vi.layout() == at::kStrided && index_img.layout() == at::kStrided,
+      "render(): expected all inputs to have torch.strided layout");
+  TORCH_CHECK(
+      (v.dim() == 3) && (vi.dim() == 3) && (index_img.dim() == 3),
+      "render(): expected v.ndim == 3, vi.ndim == 3, index_img.ndim == 3, but got v with sizes ", v.sizes(),
+      " and vi with sizes ", vi.sizes(), " and index_img with sizes ", index_img.sizes());
+  TORCH_CHECK(
+      v.size(0) == index_img.size(0),
+      "render(): expected v and index_img to have same batch size, but got v with sizes ", v.sizes(),
+      " and index_img with sizes ", index_img.sizes());
+  TORCH_CHECK(
+      vi.size(0) == v.size(0),
+      "render(): expected first dim of vi to match first dim of v but got ", v.size(0),
+      " in first dim of v, and ", vi.size(0), " in the first dim of vi");
+  TORCH_CHECK(
+      v.size(2) == 3 && vi.size(2) == 3,
+      "render(): expected third dim of v and vi to be 3, but got ", v.size(2), " and ", vi.size(2));
+}
+
+std::vector<Tensor> render_hip(const Tensor& v, const Tensor& vi, const Tensor& index_img) {
+  render_checks(v, vi, index_img);
+  const drtk_dtype_t dt = dtype_of(v, "render");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
+  const auto v_c = v.contiguous();
+  const auto idx_c = index_img.contiguous();
+  const ViArg via = prep_vi(vi);
+  const int64_t N = v.size(0), V = v.size(1), F = vi.size(1), H = index_img.size(1), W = index_img.size(2);
+  auto depth_img = at::empty({N, H, W}, v.options());
+  auto bary_img = at::empty({N, 3, H, W}, v.options());
+  check_status(
+      drtk_amd_render(
+          dt, v_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), N, V, F, via.sN, H, W,
+          depth_img.data_ptr(), bary_img.data_ptr(), current_stream(v)),
+      "render");
+  return {depth_img, bary_img};
+}
+
+Tensor render_backward_hip(
+    const Tensor& v, const Tensor& vi, const Tensor& index_img, const Tensor& grad_depth_img,
+    const Tensor& grad_bary_img) {
+  const drtk_dtype_t dt = dtype_of(v, "render_backward");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
+  const auto v_c = v.contiguous();
+  const auto idx_c = index_img.contiguous();
+  const ViArg via = prep_vi(vi);
+  const int64_t N = v.size(0), V = v.size(1), F = vi.size(1), H = index_img.size(1), W = index_img.size(2);
+  const auto gd = grad_depth_img.to(v.scalar_type()).contiguous();
+  const auto gb = grad_bary_img.to(v.scalar_type()).contiguous();
+  auto grad_v = at::empty({N, V, 3}, v.options()); // zero-filled by the call
+  check_status(
+      drtk_amd_render_backward(
+          dt, v_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), gd.data_ptr(), gb.data_ptr(), N, V,
+          F, via.sN, H, W, grad_v.data_ptr(), current_stream(v)),
+      "render_backward");
+  return grad_v;
+}
+
+std::vector<Tensor> render_cpu(const Tensor&, const Tensor&, const Tensor&) {
+  no_cpu("render");
+}
+
+tensor_list render_op(const Tensor& v, const Tensor& vi, const Tensor& index_img) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("render_ext::render", "")
+                       .typed<decltype(render_op)>();
+  return op.call(v, vi, index_img);
+}
+
+class RenderFunction : public torch::autograd::Function<RenderFunction> {
+ public:
+  static tensor_list forward(AutogradContext* ctx, const Tensor& v, const Tensor& vi, const Tensor& index_img) {
+    // grads stay materialised: an unused depth/bary output arrives as zeros (render_module.cpp:34)
+    ctx->save_for_backward({v, vi, index_img});
+    ctx->saved_data["requires_grad"] = v.requires_grad(); // render_module.cpp:41
+    at::AutoDispatchBelowADInplaceOrView g;
+    return render_op(v, vi, index_img);
+  }
+  static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+    if (!ctx->saved_data["requires_grad"].toBool()) return {Tensor(), Tensor(), Tensor()};
+    const auto saved = ctx->get_saved_variables();
+    auto grad_v = render_backward_hip(saved[0], saved[1], saved[2], grad_outputs[0], grad_outputs[1]);
+    return {grad_v, Tensor(), Tensor()};
+  }
+};
+
+tensor_list render_autograd(const Tensor& v, const Tensor& vi, const Tensor& index_img) {
+  return RenderFunction::apply(v, vi, index_img);
+}
+
+tensor_list render_autocast(const Tensor& v, const Tensor& vi, const Tensor& index_img) {
+  c10::impl::ExcludeDispatchKeyGuard no_autocast(c10::DispatchKey::Autocast);
+  return render_op(at::autocast::cached_cast(at::kFloat, v), vi, index_img);
+}
+
+// ---------------------------------------------------------------------------------------------
+// interpolate
+// ---------------------------------------------------------------------------------------------
+void interpolate_checks(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  // interpolate_kernel.cu:459-526
+  TORCH_CHECK(
+      a.defined() && vi.defined() && index_img.defined() && bary_img.defined(),
+      "interpolate(): expected all inputs to be defined");
+  TORCH_CHECK(
+      (a.device() == vi.device()) && (a.device() == index_img.device()) &&
+          (a.device() == bary_img.device()) && a.is_cuda(),
+      "interpolate(): expected all inputs to be on same cuda device");
+  TORCH_CHECK(
+      a.dtype() == bary_img.dtype(),
+      "interpolate(): expected vert_attributes and bary_img to have same dtype, but vert_attributes has ",
+      a.dtype(), " and bary_img has ", bary_img.dtype());
+  TORCH_CHECK(
+      a.is_floating_point(),
+      "interpolate(): expected vert_attributes to have floating point type, but vert_attributes has ", a.dtype());
+  TORCH_CHECK(vi.dtype() == at::kInt, "interpolate(): expected vi to have int32 type, but vi has ", vi.dtype());
+  TORCH_CHECK(
+      index_img.dtype() == at::kInt,
+      "interpolate(): expected index_img to have int32 type, but index_img has ", index_img.dtype());
+  TORCH_CHECK(
+      a.layout() == at::kStrided && vi.layout() == at::kStrided && index_img.layout() == at::kStrided &&
+          bary_img.layout() == at::kStrided,
+      "interpolate(): expected all inputs to have torch.strided layout");
+  TORCH_CHECK(
+      (a.dim() == 3) && (vi.dim() == 3) && (index_img.dim() == 3) && (bary_img.dim() == 4),
+      "interpolate(): expected vert_attributes.ndim == 3, vi.ndim == 3, index_img.ndim == 3, bary_img.ndim == 4, "
+      "but got vert_attributes with sizes ", a.sizes(), " and vi with sizes ", vi.sizes(),
+      " and index_img with sizes ", index_img.sizes(), " and bary_img with sizes ", bary_img.sizes());
+  TORCH_CHECK(
+      a.size(0) == index_img.size(0) && a.size(0) == bary_img.size(0),
+      "interpolate(): expected vert_attributes, index_img and bary_img to have same batch size, "
+      "but got vert_attributes with sizes ", a.sizes(), ", index_img with sizes ", index_img.sizes(),
+      " and bary_img with sizes ", bary_img.sizes());
+  TORCH_CHECK(
+      vi.size(2) == 3 && bary_img.size(1) == 3,
+      "interpolate(): expected last dim of vi to be 3 and second dim of bary_img to be 3, but got ",
+      vi.size(2), " in the last dim of vi, and ", bary_img.size(1), " in the second dim of bary_img");
+  TORCH_CHECK(
+      vi.size(0) == a.size(0),
+      "interpolate(): expected first dim of vi to match first dim of vert_attributes but got ", a.size(0),
+      " in first dim of vert_attributes, and ", vi.size(0), " in the first dim of vi");
+  TORCH_CHECK(
+      index_img.size(1) == bary_img.size(2) && index_img.size(2) == bary_img.size(3),
+      "interpolate(): expected H and W dims of index_img and bary_img to match");
+}
+
+Tensor interpolate_hip(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  interpolate_checks(a, vi, index_img, bary_img);
+  const drtk_dtype_t dt = dtype_of(a, "interpolate");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(a.device());
+  const auto a_c = a.contiguous();
+  const auto idx_c = index_img.contiguous();
+  const auto bary_c = bary_img.contiguous();
+  const ViArg via = prep_vi(vi);
+  const int64_t N = a.size(0), V = a.size(1), C = a.size(2), F = vi.size(1), H = bary_img.size(2), W = bary_img.size(3);
+  auto out = at::empty({N, C, H, W}, a.options());
+  check_status(
+      drtk_amd_interpolate(
+          dt, a_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), N, V, C, F, via.sN,
+          H, W, out.data_ptr(), current_stream(a)),
+      "interpolate");
+  return out;
+}
+
+std::tuple<Tensor, Tensor> interpolate_backward_hip(
+    const Tensor& grad_out, const Tensor& a, const Tensor& vi, const Tensor& index_img,
+    const Tensor& bary_img, bool vert_requires_grad, bool bary_requires_grad) {
+  const drtk_dtype_t dt = dtype_of(a, "interpolate_backward");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(a.device());
+  const auto a_c = a.contiguous();
+  const auto idx_c = index_img.contiguous();
+  const auto bary_c = bary_img.contiguous();
+  const auto go_c = grad_out.to(a.scalar_type()).contiguous();
+  const ViArg via = prep_vi(vi);
+  const int64_t N = a.size(0), V = a.size(1), C = a.size(2), F = vi.size(1), H = bary_img.size(2), W = bary_img.size(3);
+  // interpolate_kernel.cu:657-663
+  Tensor vert_grad = vert_requires_grad ? at::empty({N, V, C}, a.options()) : Tensor();
+  Tensor bary_grad = bary_requires_grad ? at::empty({N, 3, H, W}, bary_img.options()) : Tensor();
+  check_status(
+      drtk_amd_interpolate_backward(
+          dt, go_c.data_ptr(), a_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), N, V,
+          C, F, via.sN, H, W, vert_requires_grad ? vert_grad.data_ptr() : nullptr,
+          bary_requires_grad ? bary_grad.data_ptr() : nullptr, current_stream(a)),
+      "interpolate_backward");
+  return {vert_grad, bary_grad};
+}
+
+Tensor interpolate_cpu(const Tensor&, const Tensor&, const Tensor&, const Tensor&) {
+  no_cpu("interpolate");
+}
+
+Tensor interpolate_op(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("interpolate_ext::interpolate", "")
+                       .typed<decltype(interpolate_op)>();
+  return op.call(a, vi, index_img, bary_img);
+}
+
+class InterpolateFunction : public torch::autograd::Function<InterpolateFunction> {
+ public:
+  static tensor_list forward(
+      AutogradContext* ctx, const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+    ctx->set_materialize_grads(false);
+    ctx->save_for_backward({a, vi, index_img, bary_img});
+    at::AutoDispatchBelowADInplaceOrView g;
+    return {interpolate_op(a, vi, index_img, bary_img)};
+  }
+  static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor& a = saved[0];
+    const Tensor& bary_img = saved[3];
+    const bool bary_rg = bary_img.requires_grad(), vert_rg = a.requires_grad(); // interpolate_module.cpp:407-408
+    if ((!bary_rg && !vert_rg) || !grad_outputs[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor()};
+    auto g = interpolate_backward_hip(grad_outputs[0], a, saved[1], saved[2], bary_img, vert_rg, bary_rg);
+    return {std::get<0>(g), Tensor(), Tensor(), std::get<1>(g)};
+  }
+};
+
+Tensor interpolate_autograd(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  return InterpolateFunction::apply(a, vi, index_img, bary_img)[0];
+}
+
+Tensor interpolate_autocast(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  c10::impl::ExcludeDispatchKeyGuard no_autocast(c10::DispatchKey::Autocast);
+  return interpolate_op(
+      at::autocast::cached_cast(at::kFloat, a), vi, index_img, at::autocast::cached_cast(at::kFloat, bary_img));
+}
+
+// ---------------------------------------------------------------------------------------------
+// edge_grad_estimator
+// ---------------------------------------------------------------------------------------------
+Tensor edge_grad_fwd_hip(
+    const Tensor& v_pix, const Tensor& v_pix_img, const Tensor& vi, const Tensor& img,
+    const Tensor& index_img, double /*max_dp_dr*/) {
+  // edge_grad_module.cpp:30-112 : validation only, returns img itself
+  TORCH_CHECK(
+      v_pix.defined() && v_pix_img.defined() && vi.defined() && img.defined() && index_img.defined(),
+      "edge_grad_estimator(): expected all inputs to be defined");
+  TORCH_CHECK(
+      (v_pix.device() == v_pix_img.device()) && (v_pix.device() == vi.device()) &&
+          (v_pix.device() == img.device()) && (v_pix.device() == index_img.device()) && v_pix.is_cuda(),
+      "edge_grad_estimator(): expected all inputs to be on same cuda device");
+  TORCH_CHECK(
+      v_pix.is_floating_point() && v_pix_img.is_floating_point() && img.is_floating_point(),
+      "edge_grad_estimator(): expected v_pix, v_pix_img, and img to have floating point type, but v_pix has ",
+      v_pix.dtype(), " v_pix has ", v_pix_img.dtype(), " img has ", img.dtype());
+  TORCH_CHECK(vi.dtype() == at::kInt, "edge_grad_estimator(): expected vi to have int32 type, but vi has ", vi.dtype());
+  TORCH_CHECK(
+      index_img.dtype() == at::kInt,
+      "edge_grad_estimator(): expected index_img to have int32 type, but index_img has ", index_img.dtype());
+  TORCH_CHECK(
+      v_pix.layout() == at::kStrided && v_pix_img.layout() == at::kStrided && vi.layout() == at::kStrided &&
+          img.layout() == at::kStrided && index_img.layout() == at::kStrided,
+      "edge_grad_estimator(): expected all inputs to have torch.strided layout");
+  TORCH_CHECK(
+      (v_pix.dim() == 3) && (v_pix_img.dim() == 4) && (vi.dim() == 3) && (img.dim() == 4) && (index_img.dim() == 3),
+      "edge_grad_estimator(): expected v_pix.ndim == 3, v_pix_img.ndim == 4, vi.ndim == 3, img.ndim == 4, index_img.ndim == 3, "
+      "but got v_pix with sizes ", v_pix.sizes(), " and v_pix_img with sizes ", v_pix_img.sizes(),
+      " and vi with sizes ", vi.sizes(), " and img with sizes ", img.sizes(), " and index_img with sizes ",
+      index_img.sizes());
+  TORCH_CHECK(
+      v_pix.size(0) == v_pix_img.size(0) && v_pix.size(0) == img.size(0) && v_pix.size(0) == index_img.size(0),
+      "edge_grad_estimator(): expected v and index_img to have same batch size, but got v_pix with sizes ",
+      v_pix.sizes(), ", v_pix_img with sizes ", v_pix_img.sizes(), ", img with sizes ", img.sizes(),
+      " and index_img with sizes ", index_img.sizes());
+  TORCH_CHECK(
+      v_pix.size(2) == 3 && v_pix_img.size(1) == 3 && vi.size(2) == 3,
+      "edge_grad_estimator(): expected third dim of v_pix to be of size 3, and third dim of vi to be of size 3, but got ",
+      v_pix.size(2), " in the third dim of v_pix, and ", v_pix_img.size(1), " in the second dim of v_pix_img, and ",
+      vi.size(2), " in the third dim of vi");
+  TORCH_CHECK(
+      v_pix_img.size(3) == img.size(3) && v_pix_img.size(3) == index_img.size(2) &&
+          v_pix_img.size(2) == img.size(2) && v_pix_img.size(2) == index_img.size(1),
+      "edge_grad_estimator(): expected width and height of v_pix_img, img, and index_img to match, but got size of v_pix_img: ",
+      v_pix_img.sizes(), ", size of img: ", img.sizes(), ", size of index_img: ", index_img.sizes());
+  return img;
+}
+
+Tensor edge_grad_backward_hip(
+    const Tensor& v_pix, const Tensor& img, const Tensor& index_img, const Tensor& vi,
+    const Tensor& grad_outputs, double max_dp_dr) {
+  const drtk_dtype_t dt = dtype_of(v_pix, "edge_grad_estimator_backward");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v_pix.device());
+  const auto v_c = v_pix.contiguous();
+  const auto img_c = img.to(v_pix.scalar_type()).contiguous();
+  const auto idx_c = index_img.contiguous();
+  const auto go_c = grad_outputs.to(v_pix.scalar_type()).contiguous();
+  const ViArg via = prep_vi(vi);
+  const int64_t N = img.size(0), C = img.size(1), H = img.size(2), W = img.size(3), V = v_pix.size(1), F = vi.size(1);
+  auto grad_v_pix_img = at::empty({N, 3, H, W}, v_pix.options()); // fully written by the call
+  size_t ws_bytes = 0;
+  check_status(drtk_amd_edge_grad_backward_workspace_bytes(dt, N, H, W, &ws_bytes), "edge_grad_estimator");
+  auto ws = alloc_workspace(ws_bytes, v_pix);
+  check_status(
+      drtk_amd_edge_grad_backward(
+          dt, v_c.data_ptr(), img_c.data_ptr(), idx_c.data_ptr<int32_t>(), via.ptr, go_c.data_ptr(), N, V, C,
+          F, via.sN, H, W, max_dp_dr, grad_v_pix_img.data_ptr(), ws.data_ptr(), ws_bytes, current_stream(v_pix)),
+      "edge_grad_estimator");
+  return grad_v_pix_img;
+}
+
+Tensor edge_grad_cpu(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, double) {
+  no_cpu("edge_grad_estimator");
+}
+
+Tensor edge_grad_op(
+    const Tensor& v_pix, const Tensor& v_pix_img, const Tensor& vi, const Tensor& img,
+    const Tensor& index_img, double max_dp_dr) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("edge_grad_ext::edge_grad_estimator", "")
+                       .typed<decltype(edge_grad_op)>();
+  return op.call(v_pix, v_pix_img, vi, img, index_img, max_dp_dr);
+}
+
+class EdgeGradEstimatorFunction : public torch::autograd::Function<EdgeGradEstimatorFunction> {
+ public:
+  static tensor_list forward(
+      AutogradContext* ctx, const Tensor& v_pix, const Tensor& v_pix_img, const Tensor& vi,
+      const Tensor& img, const Tensor& index_img, double max_dp_dr) {
+    if (v_pix.is_cuda()) {
+      edge_grad_fwd_hip(v_pix, v_pix_img, vi, img, index_img, max_dp_dr);
+    } else {
+      no_cpu("edge_grad_estimator");
+    }
+    ctx->set_materialize_grads(false);
+    ctx->save_for_backward({v_pix, img, index_img, vi});
+    ctx->saved_data["v_pix_img_requires_grad"] = v_pix_img.requires_grad();
+    ctx->saved_data["max_dp_dr"] = max_dp_dr;
+    return {img}; // edge_grad_module.cpp:136
+  }
+  static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+    // edge_grad_module.cpp:143-151 : passthrough when v_pix_img needs no gradient
+    if (!ctx->saved_data["v_pix_img_requires_grad"].toBool() || !grad_outputs[0].defined()) {
+      return {Tensor(), Tensor(), Tensor(), grad_outputs[0], Tensor(), Tensor()};
+    }
+    const auto saved = ctx->get_saved_variables();
+    const double max_dp_dr = ctx->saved_data["max_dp_dr"].toDouble();
+    auto g = edge_grad_backward_hip(saved[0], saved[1], saved[2], saved[3], grad_outputs[0], max_dp_dr);
+    return {Tensor(), g, Tensor(), grad_outputs[0], Tensor(), Tensor()};
+  }
+};
+
+Tensor edge_grad_autograd(
+    const Tensor& v_pix, const Tensor& v_pix_img, const Tensor& vi, const Tensor& img,
+    const Tensor& index_img, double max_dp_dr) {
+  return EdgeGradEstimatorFunction::apply(v_pix, v_pix_img, vi, img, index_img, max_dp_dr)[0];
+}
+
+Tensor edge_grad_autocast(
+    const Tensor& v_pix, const Tensor& v_pix_img, const Tensor& vi, const Tensor& img,
+    const Tensor& index_img, double max_dp_dr) {
+  c10::impl::ExcludeDispatchKeyGuard no_autocast(c10::DispatchKey::Autocast);
+  return edge_grad_op(
+      at::autocast::cached_cast(at::kFloat, v_pix), at::autocast::cached_cast(at::kFloat, v_pix_img), vi,
+      at::autocast::cached_cast(at::kFloat, img), index_img, max_dp_dr);
+}
+
+} // namespace
+
+// ---- schemas: verbatim from the reference ------------------------------------------------------
+TORCH_LIBRARY(rasterize_ext, m) {
+  m.def("rasterize(Tensor v, Tensor vi, int height, int width, bool wireframe) -> Tensor[]");
+}
+TORCH_LIBRARY_IMPL(rasterize_ext, Autograd, m) {
+  m.impl("rasterize", &rasterize_autograd);
+}
+TORCH_LIBRARY_IMPL(rasterize_ext, Autocast, m) {
+  m.impl("rasterize", rasterize_autocast);
+}
+TORCH_LIBRARY_IMPL(rasterize_ext, CUDA, m) {
+  m.impl("rasterize", &rasterize_hip);
+}
+TORCH_LIBRARY_IMPL(rasterize_ext, CPU, m) {
+  m.impl("rasterize", &rasterize_cpu);
+}
+
+TORCH_LIBRARY(render_ext, m) {
+  m.def("render(Tensor v, Tensor vi, Tensor index_img) -> Tensor[]");
+}
+TORCH_LIBRARY_IMPL(render_ext, Autograd, m) {
+  m.impl("render", &render_autograd);
+}
+TORCH_LIBRARY_IMPL(render_ext, Autocast, m) {
+  m.impl("render", render_autocast);
+}
+TORCH_LIBRARY_IMPL(render_ext, CUDA, m) {
+  m.impl("render", &render_hip);
+}
+TORCH_LIBRARY_IMPL(render_ext, CPU, m) {
+  m.impl("render", &render_cpu);
+}
+
+TORCH_LIBRARY(interpolate_ext, m) {
+  m.def("interpolate(Tensor vert_attributes, Tensor vi, Tensor index_img, Tensor bary_img) -> Tensor");
+}
+TORCH_LIBRARY_IMPL(interpolate_ext, Autograd, m) {
+  m.impl("interpolate", &interpolate_autograd);
+}
+TORCH_LIBRARY_IMPL(interpolate_ext, Autocast, m) {
+  m.impl("interpolate", interpolate_autocast);
+}
+TORCH_LIBRARY_IMPL(interpolate_ext, CUDA, m) {
+  m.impl("interpolate", &interpolate_hip);
+}
+TORCH_LIBRARY_IMPL(interpolate_ext, CPU, m) {
+  m.impl("interpolate", &interpolate_cpu);
+}
+
+TORCH_LIBRARY(edge_grad_ext, m) {
+  m.def(
+      "edge_grad_estimator(Tensor v_pix, Tensor v_pix_img, Tensor vi, Tensor img, Tensor index_img, float max_dp_dr=1e4) -> Tensor");
+}
+TORCH_LIBRARY_IMPL(edge_grad_ext, Autograd, m) {
+  m.impl("edge_grad_estimator", &edge_grad_autograd);
+}
+TORCH_LIBRARY_IMPL(edge_grad_ext, Autocast, m) {
+  m.impl("edge_grad_estimator", edge_grad_autocast);
+}
+TORCH_LIBRARY_IMPL(edge_grad_ext, CUDA, m) {
+  m.impl("edge_grad_estimator", &edge_grad_fwd_hip);
+}
+TORCH_LIBRARY_IMPL(edge_grad_ext, CPU, m) {
+  m.impl("edge_grad_estimator", &edge_grad_cpu);
+}

@@ -1,0 +1,50 @@
+"""Pinhole `transform` -- the step before the hot path (drtk/transform.py:13-119,
+drtk/utils/projection.py:33-53,486-540).  Pure PyTorch, runs unchanged on ROCm; only the
+undistorted pinhole model is provided (the distortion models are outside the hot-path scope)."""
+from typing import Optional, Tuple
+
+import torch as th
+
+
+def project_pinhole(v_cam: th.Tensor, focal: th.Tensor, princpt: th.Tensor) -> th.Tensor:
+    z = v_cam[:, :, 2:3]
+    z = th.where(z < 0, z.clamp(max=-1e-8), z.clamp(min=1e-8))
+    v_proj = v_cam[:, :, 0:2] / z
+    return (focal[:, None] @ v_proj[..., None])[..., 0] + princpt[:, None]
+
+
+def transform_with_v_cam(
+    v: th.Tensor,
+    campos: Optional[th.Tensor] = None,
+    camrot: Optional[th.Tensor] = None,
+    focal: Optional[th.Tensor] = None,
+    princpt: Optional[th.Tensor] = None,
+    K: Optional[th.Tensor] = None,
+    Rt: Optional[th.Tensor] = None,
+) -> Tuple[th.Tensor, th.Tensor]:
+    if not ((camrot is not None and campos is not None) ^ (Rt is not None)):
+        raise ValueError("You must provide exactly one of Rt or (campos, camrot).")
+    if not ((focal is not None and princpt is not None) ^ (K is not None)):
+        raise ValueError("You must provide exactly one of K or (focal, princpt).")
+    if campos is None:
+        camrot = Rt[:, :3, :3]
+        campos = -(camrot.transpose(-2, -1) @ Rt[:, :3, 3:4])[..., 0]
+    if focal is None:
+        focal = K[:, :2, :2]
+        princpt = K[:, :2, 2]
+    v_cam = (camrot[:, None] @ (v - campos[:, None])[..., None])[..., 0]
+    v_pix = project_pinhole(v_cam, focal, princpt)
+    return th.cat((v_pix, v_cam[:, :, 2:3]), dim=-1), v_cam
+
+
+def transform(
+    v: th.Tensor,
+    campos: Optional[th.Tensor] = None,
+    camrot: Optional[th.Tensor] = None,
+    focal: Optional[th.Tensor] = None,
+    princpt: Optional[th.Tensor] = None,
+    K: Optional[th.Tensor] = None,
+    Rt: Optional[th.Tensor] = None,
+) -> th.Tensor:
+    """World space `[N,V,3]` -> `(x_pix, y_pix, z_cam)`; `v_cam = camrot @ (v - campos)`."""
+    return transform_with_v_cam(v, campos, camrot, focal, princpt, K, Rt)[0]

@@ -1,0 +1,124 @@
+/* drtk_amd -- C ABI of the MI355X-native rasterize -> render -> interpolate -> edge_grad hot path.
+ *
+ * This is the drop-in boundary below the torch-operator layer.  The reference (facebookresearch/
+ * DRTK) has no extern "C" surface of its own: its extensions are reached through the torch
+ * dispatcher, whose CUDA-key implementations are the C++ host launchers cited on every entry
+ * below.  Each function here replaces exactly one of those launchers (same inputs, outputs and
+ * semantics, contiguous layouts, raw device pointers, an explicit HIP stream) so that the
+ * torch-op shim (drtk_amd/csrc/torch_ops.cpp), a ctypes caller or a C program can all drive the
+ * same kernels.  INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (hipMalloc / torch caching allocator), tensors contiguous:
+ *       v, v_pix        [N,V,3]        vi         [N,F,3] int32, batch stride `vi_sN` elements
+ *                                                 (0 = one [F,3] topology shared by all views)
+ *       index_img       [N,H,W] int32  (-1 = empty)
+ *       depth_img       [N,H,W]        bary_img   [N,3,H,W]   (planar)
+ *       attrs           [N,V,C]        img / out  [N,C,H,W]   (planar)
+ *   - `dtype` selects float or double for every floating tensor of the call (the reference
+ *     dispatches float/double only: src/include/kernel_utils.h:35-57); indices are int32.
+ *   - `stream` is a hipStream_t (NULL = the null stream).  No call synchronises the device or
+ *     allocates memory; all work is enqueued on `stream`.
+ *   - return value: DRTK_OK or a negative drtk_status_t; drtk_amd_status_string() explains it.
+ *     Argument validation mirrors the reference's TORCH_CHECKs where it can be expressed on raw
+ *     sizes; tensor-level checks (dtype, device, ndim) live in the torch shim.
+ *   - thread-safety: re-entrant; no global mutable state.
+ */
+#ifndef DRTK_AMD_H
+#define DRTK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRTK_AMD_VERSION_MAJOR 0
+#define DRTK_AMD_VERSION_MINOR 1
+
+typedef enum { DRTK_F32 = 0, DRTK_F64 = 1 } drtk_dtype_t;
+
+typedef enum {
+  DRTK_OK = 0,
+  DRTK_ERR_INVALID_ARGUMENT = -1, /* bad size / null pointer / unknown dtype */
+  DRTK_ERR_WORKSPACE_TOO_SMALL = -2,
+  DRTK_ERR_LAUNCH = -3,       /* hipGetLastError() after a launch was not hipSuccess */
+  DRTK_ERR_UNSUPPORTED = -4,  /* e.g. wireframe rasterization */
+  DRTK_ERR_TOO_MANY_VERTICES = -5 /* V >= 2^28, rasterize_kernel.cu:459-462 */
+} drtk_status_t;
+
+typedef void* drtk_stream_t; /* hipStream_t */
+
+const char* drtk_amd_status_string(int status);
+/* "major.minor (gfx950)" */
+const char* drtk_amd_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * rasterize        replaces rasterize_cuda            (src/rasterize/rasterize_kernel.cu:417-563)
+ *
+ * Z-buffer rasterization of N views.  Writes index_img (triangle id, -1 where empty; lower id
+ * wins depth ties) and depth_img (ALWAYS float32, 0 where empty, rasterize_kernel.cu:481) --
+ * bit-exact with the reference's arithmetic (rasterize_kernel.cu:69-166).
+ * `workspace` holds the tile bins; query its size first.  `wireframe != 0` -> DRTK_ERR_UNSUPPORTED.
+ */
+int drtk_amd_rasterize_workspace_bytes(int64_t N, int64_t F, int64_t H, int64_t W, size_t* bytes);
+int drtk_amd_rasterize(
+    drtk_dtype_t dtype, const void* v, const int32_t* vi, int64_t N, int64_t V, int64_t F,
+    int64_t vi_sN, int64_t H, int64_t W, int wireframe, float* depth_img, int32_t* index_img,
+    void* workspace, size_t workspace_bytes, drtk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * render           replaces render_cuda               (src/render/render_kernel.cu:283-380)
+ * Perspective-correct barycentrics + depth per pixel; zeros where index_img == -1.
+ */
+int drtk_amd_render(
+    drtk_dtype_t dtype, const void* v, const int32_t* vi, const int32_t* index_img, int64_t N,
+    int64_t V, int64_t F, int64_t vi_sN, int64_t H, int64_t W, void* depth_img, void* bary_img,
+    drtk_stream_t stream);
+
+/* render_backward  replaces render_cuda_backward      (src/render/render_kernel.cu:382-436)
+ * grad_v [N,V,3] is zero-filled by this call (render_kernel.cu:397) and then accumulated.
+ */
+int drtk_amd_render_backward(
+    drtk_dtype_t dtype, const void* v, const int32_t* vi, const int32_t* index_img,
+    const void* grad_depth_img, const void* grad_bary_img, int64_t N, int64_t V, int64_t F,
+    int64_t vi_sN, int64_t H, int64_t W, void* grad_v, drtk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * interpolate      replaces interpolate_cuda          (src/interpolate/interpolate_kernel.cu:454-570)
+ * out[n,c,y,x] = sum_k attrs[n,vi[t,k],c] * bary[n,k,y,x]; background pixels get the
+ * reference's +-1 coordinate sweep (interpolate_kernel.cu:104-108).
+ */
+int drtk_amd_interpolate(
+    drtk_dtype_t dtype, const void* attrs, const int32_t* vi, const int32_t* index_img,
+    const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H,
+    int64_t W, void* out, drtk_stream_t stream);
+
+/* interpolate_backward  replaces interpolate_cuda_backward (interpolate_kernel.cu:642-697)
+ * attr_grad [N,V,C] (NULL = not wanted) is zero-filled then accumulated; bary_grad [N,3,H,W]
+ * (NULL = not wanted) is fully written.  At least one must be non-NULL.
+ */
+int drtk_amd_interpolate_backward(
+    drtk_dtype_t dtype, const void* grad_out, const void* attrs, const int32_t* vi,
+    const int32_t* index_img, const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F,
+    int64_t vi_sN, int64_t H, int64_t W, void* attr_grad, void* bary_grad, drtk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * edge_grad_backward  replaces edge_grad_estimator_cuda_backward (src/edge_grad/edge_grad_kernel.cu:475-506)
+ * grad_v_pix_img [N,3,H,W] is fully written (the reference zero-fills and scatters with
+ * atomics, edge_grad_kernel.cu:430-445,489; this implementation gathers, same values).
+ * `workspace` holds the two per-pixel pair terms (2*N*H*W scalars); query its size first.
+ */
+int drtk_amd_edge_grad_backward_workspace_bytes(
+    drtk_dtype_t dtype, int64_t N, int64_t H, int64_t W, size_t* bytes);
+int drtk_amd_edge_grad_backward(
+    drtk_dtype_t dtype, const void* v_pix, const void* img, const int32_t* index_img,
+    const int32_t* vi, const void* grad_output, int64_t N, int64_t V, int64_t C, int64_t F,
+    int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix_img, void* workspace,
+    size_t workspace_bytes, drtk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRTK_AMD_H */

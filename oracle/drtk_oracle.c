@@ -1,0 +1,45 @@
+/* TEST INFRASTRUCTURE ONLY -- see drtk_oracle.h.  Plain C restatement of the reference's CPU hot
+ * path; the generic body lives in drtk_oracle_body.inc and is instantiated for float and double.
+ * Build: oracle/build.py  (gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC). */
+#include "drtk_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int drtk_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* nthreads: <=0 -> all available, otherwise clamp to what OpenMP offers. */
+static int drtk_oracle_resolve_threads(int nthreads) {
+  const int mx = drtk_oracle_max_threads();
+  if (nthreads <= 0) return mx;
+  return nthreads < mx ? nthreads : mx;
+}
+
+#define REAL float
+#define SFX f32
+#define REAL_EPS 1e-8f /* cuda_math_helper.h:62-64 */
+#define REAL_SQRT sqrtf
+#define REAL_FABS fabsf
+#include "drtk_oracle_body.inc"
+#undef REAL
+#undef SFX
+#undef REAL_EPS
+#undef REAL_SQRT
+#undef REAL_FABS
+
+#define REAL double
+#define SFX f64
+#define REAL_EPS 1e-16 /* cuda_math_helper.h:67-69 */
+#define REAL_SQRT sqrt
+#define REAL_FABS fabs
+#include "drtk_oracle_body.inc"

@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of oracle/libdrtk_oracle.so.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.  The
+product package (drtk_amd/) never imports this module.
+
+All functions take/return CPU torch tensors (float32 or float64, int32 indices) and mirror the
+reference's CPU entry points (file:line in drtk_oracle.h).  `vi` may be [F,3] (shared topology) or
+[N,F,3].  `nthreads=1` is the deterministic parity mode; `nthreads=0` uses every core (baseline).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdrtk_oracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_SO):
+            import importlib.util
+
+            spec = importlib.util.spec_from_file_location("_oracle_build", os.path.join(_HERE, "build.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.build(verbose=False)
+        _lib = ctypes.CDLL(_SO)
+        _lib.drtk_oracle_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def max_threads() -> int:
+    return int(lib().drtk_oracle_max_threads())
+
+
+def _sfx(t: torch.Tensor) -> str:
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise TypeError(f"oracle: unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _i64(x):
+    return ctypes.c_int64(int(x))
+
+
+def _prep_vi(vi: torch.Tensor, N: int):
+    assert vi.dtype == torch.int32
+    if vi.ndim == 2:
+        vi_c = vi.contiguous()
+        return vi_c, 0, vi_c.shape[0]
+    assert vi.ndim == 3
+    if vi.shape[0] == N and vi.stride(0) == 0:
+        vi_c = vi[0].contiguous()
+        return vi_c, 0, vi_c.shape[0]
+    vi_c = vi.contiguous()
+    return vi_c, vi_c.shape[1] * 3, vi_c.shape[1]
+
+
+def _call(name, sfx, *args):
+    fn = getattr(lib(), f"drtk_oracle_{name}_{sfx}")
+    fn.restype = ctypes.c_int
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError(f"drtk_oracle_{name}_{sfx} failed with code {rc}")
+
+
+def rasterize(v, vi, height, width, nthreads=1):
+    v = v.contiguous()
+    N, V, _ = v.shape
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    depth = torch.empty(N, height, width, dtype=torch.float32)
+    index = torch.empty(N, height, width, dtype=torch.int32)
+    _call("rasterize", _sfx(v), _p(v), _p(vi_c), _i64(N), _i64(V), _i64(F), _i64(vi_sN),
+          _i64(height), _i64(width), _p(depth), _p(index), ctypes.c_int(nthreads))
+    return depth, index
+
+
+def render(v, vi, index_img, nthreads=1):
+    v = v.contiguous()
+    index_img = index_img.contiguous()
+    N, V, _ = v.shape
+    H, W = index_img.shape[1:]
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    depth = torch.empty(N, H, W, dtype=v.dtype)
+    bary = torch.empty(N, 3, H, W, dtype=v.dtype)
+    _call("render", _sfx(v), _p(v), _p(vi_c), _p(index_img), _i64(N), _i64(V), _i64(F),
+          _i64(vi_sN), _i64(H), _i64(W), _p(depth), _p(bary), ctypes.c_int(nthreads))
+    return depth, bary
+
+
+def render_backward(v, vi, index_img, grad_depth_img, grad_bary_img, nthreads=1):
+    v = v.contiguous()
+    index_img = index_img.contiguous()
+    gd = grad_depth_img.contiguous()
+    gb = grad_bary_img.contiguous()
+    N, V, _ = v.shape
+    H, W = index_img.shape[1:]
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    grad_v = torch.zeros(N, V, 3, dtype=v.dtype)
+    _call("render_backward", _sfx(v), _p(v), _p(vi_c), _p(index_img), _p(gd), _p(gb), _i64(N),
+          _i64(V), _i64(F), _i64(vi_sN), _i64(H), _i64(W), _p(grad_v), ctypes.c_int(nthreads))
+    return grad_v
+
+
+def interpolate(attrs, vi, index_img, bary_img, nthreads=1):
+    attrs = attrs.contiguous()
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, V, C = attrs.shape
+    H, W = index_img.shape[1:]
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    out = torch.empty(N, C, H, W, dtype=attrs.dtype)
+    _call("interpolate", _sfx(attrs), _p(attrs), _p(vi_c), _p(index_img), _p(bary_img), _i64(N),
+          _i64(V), _i64(C), _i64(F), _i64(vi_sN), _i64(H), _i64(W), _p(out), ctypes.c_int(nthreads))
+    return out
+
+
+def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires_grad=True,
+                         bary_requires_grad=True, nthreads=1):
+    grad_out = grad_out.contiguous()
+    attrs = attrs.contiguous()
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, V, C = attrs.shape
+    H, W = index_img.shape[1:]
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    attr_grad = torch.zeros(N, V, C, dtype=attrs.dtype) if vert_requires_grad else None
+    bary_grad = torch.empty(N, 3, H, W, dtype=attrs.dtype) if bary_requires_grad else None
+    _call("interpolate_backward", _sfx(attrs), _p(grad_out), _p(attrs), _p(vi_c), _p(index_img),
+          _p(bary_img), _i64(N), _i64(V), _i64(C), _i64(F), _i64(vi_sN), _i64(H), _i64(W),
+          _p(attr_grad), _p(bary_grad), ctypes.c_int(nthreads))
+    return attr_grad, bary_grad
+
+
+def edge_grad_backward(v_pix, img, index_img, vi, grad_output, max_dp_dr=1e4, nthreads=1):
+    v_pix = v_pix.contiguous()
+    img = img.contiguous()
+    index_img = index_img.contiguous()
+    grad_output = grad_output.contiguous()
+    N, V, _ = v_pix.shape
+    C, H, W = img.shape[1:]
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    g = torch.zeros(N, 3, H, W, dtype=v_pix.dtype)
+    _call("edge_grad_backward", _sfx(v_pix), _p(v_pix), _p(img), _p(index_img), _p(vi_c),
+          _p(grad_output), _i64(N), _i64(V), _i64(C), _i64(F), _i64(vi_sN), _i64(H), _i64(W),
+          ctypes.c_double(max_dp_dr), _p(g), ctypes.c_int(nthreads))
+    return g
