@@ -1,0 +1,210 @@
+"""ctypes binding of the C ABI (include/drtk_amd.h) on torch device tensors.
+
+This is the same entry-point set the torch-op shim uses, callable without the dispatcher: parity
+tests and the benchmark's per-kernel timing go through here.  Tensors must live on a HIP device;
+every call enqueues on the given stream (default: torch's current stream) and returns new
+output tensors.  There is no CPU path.
+"""
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import torch as th
+
+from drtk_amd.utils import native_library_paths
+
+_lib = None
+
+DRTK_F32, DRTK_F64 = 0, 1
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        path = native_library_paths()[0]
+        if not os.path.isfile(path):
+            raise ImportError(f"{path} is missing: run `python -m drtk_amd.build`")
+        L = ctypes.CDLL(path)
+        L.drtk_amd_status_string.restype = ctypes.c_char_p
+        L.drtk_amd_status_string.argtypes = [ctypes.c_int]
+        L.drtk_amd_version.restype = ctypes.c_char_p
+        for name in EXPORTS:
+            if name not in ("drtk_amd_status_string", "drtk_amd_version"):
+                getattr(L, name).restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+EXPORTS = [
+    "drtk_amd_status_string",
+    "drtk_amd_version",
+    "drtk_amd_rasterize_workspace_bytes",
+    "drtk_amd_rasterize",
+    "drtk_amd_render",
+    "drtk_amd_render_backward",
+    "drtk_amd_interpolate",
+    "drtk_amd_interpolate_backward",
+    "drtk_amd_edge_grad_backward_workspace_bytes",
+    "drtk_amd_edge_grad_backward",
+]
+
+
+class DrtkAmdError(RuntimeError):
+    pass
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        raise DrtkAmdError(f"{what}: {lib().drtk_amd_status_string(status).decode()} (status {status})")
+
+
+def _dt(t: th.Tensor) -> int:
+    if t.dtype == th.float32:
+        return DRTK_F32
+    if t.dtype == th.float64:
+        return DRTK_F64
+    raise TypeError(f"drtk_amd: unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[th.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _i(x) -> ctypes.c_int64:
+    return ctypes.c_int64(int(x))
+
+
+def _stream(t: th.Tensor, stream) -> ctypes.c_void_p:
+    if not t.is_cuda:
+        raise DrtkAmdError("drtk_amd implements the MI355X (HIP) path only; got a CPU tensor")
+    s = th.cuda.current_stream(t.device) if stream is None else stream
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _vi(vi: th.Tensor, n: int):
+    assert vi.dtype == th.int32
+    if vi.ndim == 2:
+        c = vi.contiguous()
+        return c, 0, c.shape[0]
+    if vi.shape[0] > 1 and vi.stride(0) == 0:
+        c = vi[0].contiguous()
+        return c, 0, c.shape[0]
+    c = vi.contiguous()
+    return c, c.shape[1] * 3, c.shape[1]
+
+
+def rasterize_workspace_bytes(N, F, H, W) -> int:
+    out = ctypes.c_size_t(0)
+    _check(lib().drtk_amd_rasterize_workspace_bytes(_i(N), _i(F), _i(H), _i(W), ctypes.byref(out)), "rasterize")
+    return out.value
+
+
+def rasterize(v, vi, height, width, stream=None, workspace=None) -> Tuple[th.Tensor, th.Tensor]:
+    v = v.contiguous()
+    N, V, _ = v.shape
+    vi_c, vi_sN, F = _vi(vi, N)
+    depth = th.empty(N, height, width, dtype=th.float32, device=v.device)
+    index = th.empty(N, height, width, dtype=th.int32, device=v.device)
+    nbytes = rasterize_workspace_bytes(N, F, height, width)
+    ws = workspace if workspace is not None else th.empty(nbytes, dtype=th.uint8, device=v.device)
+    _check(
+        lib().drtk_amd_rasterize(
+            ctypes.c_int(_dt(v)), _p(v), _p(vi_c), _i(N), _i(V), _i(F), _i(vi_sN), _i(height), _i(width),
+            ctypes.c_int(0), _p(depth), _p(index), _p(ws), ctypes.c_size_t(ws.numel()), _stream(v, stream)),
+        "rasterize")
+    return depth, index
+
+
+def render(v, vi, index_img, stream=None):
+    v = v.contiguous()
+    index_img = index_img.contiguous()
+    N, V, _ = v.shape
+    H, W = index_img.shape[1:]
+    vi_c, vi_sN, F = _vi(vi, N)
+    depth = th.empty(N, H, W, dtype=v.dtype, device=v.device)
+    bary = th.empty(N, 3, H, W, dtype=v.dtype, device=v.device)
+    _check(
+        lib().drtk_amd_render(
+            ctypes.c_int(_dt(v)), _p(v), _p(vi_c), _p(index_img), _i(N), _i(V), _i(F), _i(vi_sN), _i(H), _i(W),
+            _p(depth), _p(bary), _stream(v, stream)),
+        "render")
+    return depth, bary
+
+
+def render_backward(v, vi, index_img, grad_depth_img, grad_bary_img, stream=None):
+    v = v.contiguous()
+    index_img = index_img.contiguous()
+    gd, gb = grad_depth_img.contiguous(), grad_bary_img.contiguous()
+    N, V, _ = v.shape
+    H, W = index_img.shape[1:]
+    vi_c, vi_sN, F = _vi(vi, N)
+    grad_v = th.empty(N, V, 3, dtype=v.dtype, device=v.device)
+    _check(
+        lib().drtk_amd_render_backward(
+            ctypes.c_int(_dt(v)), _p(v), _p(vi_c), _p(index_img), _p(gd), _p(gb), _i(N), _i(V), _i(F), _i(vi_sN),
+            _i(H), _i(W), _p(grad_v), _stream(v, stream)),
+        "render_backward")
+    return grad_v
+
+
+def interpolate(attrs, vi, index_img, bary_img, stream=None):
+    attrs = attrs.contiguous()
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, V, C = attrs.shape
+    H, W = index_img.shape[1:]
+    vi_c, vi_sN, F = _vi(vi, N)
+    out = th.empty(N, C, H, W, dtype=attrs.dtype, device=attrs.device)
+    _check(
+        lib().drtk_amd_interpolate(
+            ctypes.c_int(_dt(attrs)), _p(attrs), _p(vi_c), _p(index_img), _p(bary_img), _i(N), _i(V), _i(C), _i(F),
+            _i(vi_sN), _i(H), _i(W), _p(out), _stream(attrs, stream)),
+        "interpolate")
+    return out
+
+
+def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires_grad=True,
+                         bary_requires_grad=True, stream=None):
+    grad_out = grad_out.contiguous()
+    attrs = attrs.contiguous()
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, V, C = attrs.shape
+    H, W = index_img.shape[1:]
+    vi_c, vi_sN, F = _vi(vi, N)
+    ag = th.empty(N, V, C, dtype=attrs.dtype, device=attrs.device) if vert_requires_grad else None
+    bg = th.empty(N, 3, H, W, dtype=attrs.dtype, device=attrs.device) if bary_requires_grad else None
+    _check(
+        lib().drtk_amd_interpolate_backward(
+            ctypes.c_int(_dt(attrs)), _p(grad_out), _p(attrs), _p(vi_c), _p(index_img), _p(bary_img), _i(N), _i(V),
+            _i(C), _i(F), _i(vi_sN), _i(H), _i(W), _p(ag), _p(bg), _stream(attrs, stream)),
+        "interpolate_backward")
+    return ag, bg
+
+
+def edge_grad_backward_workspace_bytes(dtype, N, H, W) -> int:
+    out = ctypes.c_size_t(0)
+    code = DRTK_F32 if dtype == th.float32 else DRTK_F64
+    _check(lib().drtk_amd_edge_grad_backward_workspace_bytes(ctypes.c_int(code), _i(N), _i(H), _i(W), ctypes.byref(out)),
+           "edge_grad_backward")
+    return out.value
+
+
+def edge_grad_backward(v_pix, img, index_img, vi, grad_output, max_dp_dr=1e4, stream=None, workspace=None):
+    v_pix = v_pix.contiguous()
+    img = img.contiguous()
+    index_img = index_img.contiguous()
+    grad_output = grad_output.contiguous()
+    N, V, _ = v_pix.shape
+    C, H, W = img.shape[1:]
+    vi_c, vi_sN, F = _vi(vi, N)
+    out = th.empty(N, 3, H, W, dtype=v_pix.dtype, device=v_pix.device)
+    nbytes = edge_grad_backward_workspace_bytes(v_pix.dtype, N, H, W)
+    ws = workspace if workspace is not None else th.empty(nbytes, dtype=th.uint8, device=v_pix.device)
+    _check(
+        lib().drtk_amd_edge_grad_backward(
+            ctypes.c_int(_dt(v_pix)), _p(v_pix), _p(img), _p(index_img), _p(vi_c), _p(grad_output), _i(N), _i(V),
+            _i(C), _i(F), _i(vi_sN), _i(H), _i(W), ctypes.c_double(max_dp_dr), _p(out), _p(ws),
+            ctypes.c_size_t(ws.numel()), _stream(v_pix, stream)),
+        "edge_grad_backward")
+    return out

@@ -39,7 +39,7 @@ __device__ __forceinline__ T epsclamp(T v) {
 }
 
 // Explicit float->int conversion of the bounding box: out-of-range -> INT_MIN, matching the x86
-// reference build and the oracle (oracle/drtk_oracle_body.inc, trunc_i32).
+// reference build (cvttss2si); the CPU restatement used by the tests defines the same function.
 template <typename T>
 __device__ __forceinline__ int32_t trunc_i32(T x) {
   if (!(x > T(-2147483904.0) && x < T(2147483648.0))) return INT32_MIN;

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz from the REFERENCE's own CPU kernels.
+
+Runs only in the build container: it needs oracle/_ref/ (built by oracle/ref_build.py from
+/root/reference/src).  Every fixture holds the scene inputs (tests/scenes.py) and the outputs of
+the reference's strict-IEEE build for every function on the hot path, single-threaded
+(torch.set_num_threads(1) => deterministic accumulation order), plus the index/depth images of the
+reference built with its own `-O3 --fast-math` flags so that flag-induced differences stay
+documented (SURVEY.md §7 hard part 1).
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch as th
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_build  # noqa: E402
+from backends import RefBackend, make_ops  # noqa: E402
+from scenes import SCENES  # noqa: E402
+
+from drtk_amd import synthetic as S  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def run_scene(B, Bfast, sc):
+    v, vi, H, W = sc["v"], sc["vi"], sc["H"], sc["W"]
+    attr, gd, gb, go = sc["attr"], sc["gd"], sc["gb"], sc["go"]
+    out = {}
+    vi_r = sc.get("vi_raster", vi)
+    depth, index = B.rasterize(v, vi_r, H, W)
+    depth_f, index_f = Bfast.rasterize(v, vi_r, H, W)
+    r_depth, r_bary = B.render(v, vi, index)
+    interp = B.interpolate(attr, vi, index, r_bary)
+    grad_v = B.render_backward(v, vi, index, gd, gb)
+    attr_grad, bary_grad = B.interpolate_backward(go, attr, vi, index, r_bary, True, True)
+    img = interp * (index != -1)[:, None]
+    eg = B.edge_grad_backward(v, img, index, vi, go, 1e4)
+    eg0 = B.edge_grad_backward(v, img, index, vi, go, 0.0)
+    # the C=3 interpolate backward that routes edge gradients to v_pix (edge_grad_estimator.py:172)
+    vpix_grad, _ = B.interpolate_backward(eg, v, vi, index, r_bary, True, False)
+    out.update(
+        depth_img=depth, index_img=index, depth_img_fast=depth_f, index_img_fast=index_f,
+        render_depth=r_depth, render_bary=r_bary, interp=interp, grad_v=grad_v, attr_grad=attr_grad,
+        bary_grad=bary_grad, img=img, edge_grad=eg, edge_grad_noclamp=eg0, v_pix_grad_from_edges=vpix_grad,
+    )
+    return out
+
+
+def save(name, inputs, outputs):
+    arrs = {}
+    for k, val in inputs.items():
+        arrs["in_" + k] = val.numpy() if isinstance(val, th.Tensor) else np.asarray(val)
+    for k, val in outputs.items():
+        arrs["out_" + k] = val.numpy() if isinstance(val, th.Tensor) else np.asarray(val)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def two_triangles_trajectory(ops):
+    """The reference's only 'test' (test/two_triangles.py:14-92) at 64x64 on CPU: GT render,
+    perturbed start, Adam.  Records iteration-0 tensors and the loss at a few iterations."""
+    import torch.nn.functional as thf
+
+    v_gt, vi, vt, tex = S.two_triangles(64, 64)
+    g = th.Generator().manual_seed(10)
+    noise = th.randn(v_gt.shape, generator=g, dtype=th.float32) * (20.0 / 8.0)
+    v = th.nn.Parameter((v_gt + noise).contiguous())
+
+    def shade(vv):
+        index_img = ops.rasterize(vv, vi, 64, 64)
+        _, bary_img = ops.render(vv, vi, index_img)
+        vt_img = ops.interpolate(vt, vi, index_img, bary_img).permute(0, 2, 3, 1)
+        img = thf.grid_sample(tex, vt_img, padding_mode="border", align_corners=False) * (index_img != -1)[:, None]
+        return img, index_img, bary_img
+
+    with th.no_grad():
+        img_gt, index_gt, _ = shade(v_gt)
+    optim = th.optim.Adam([v], lr=0.05, betas=(0.9, 0.999))
+    rec = {"v_gt": v_gt, "v0": v.detach().clone(), "vi": vi, "vt": vt, "tex": tex, "img_gt": img_gt, "index_gt": index_gt}
+    losses = {}
+    for it in range(201):
+        img, index_img, bary_img = shade(v)
+        img = ops.edge_grad_estimator(v_pix=v, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
+        loss = ((img - img_gt) ** 2).mean()
+        optim.zero_grad()
+        loss.backward()
+        if it == 0:
+            rec.update(index0=index_img.clone(), bary0=bary_img.detach().clone(), img0=img.detach().clone(),
+                       grad0=v.grad.detach().clone())
+        if it in (0, 1, 50, 100, 200):
+            losses[it] = float(loss)
+        optim.step()
+    rec["loss_iters"] = np.array(sorted(losses), dtype=np.int64)
+    rec["loss_values"] = np.array([losses[k] for k in sorted(losses)], dtype=np.float64)
+    return rec
+
+
+def main():
+    if not ref_build.available():
+        raise SystemExit("needs /root/reference and triton's cuda_runtime.h (build container only)")
+    ref_build.build(verbose=True)
+    th.set_num_threads(1)
+    os.makedirs(OUT, exist_ok=True)
+    B, Bfast = RefBackend("strict"), RefBackend("fast")
+    for name, fn in SCENES.items():
+        for dtype, tag in ((th.float32, "f32"), (th.float64, "f64")):
+            if dtype == th.float64 and name not in ("tutorial3", "spheres", "edge_cases"):
+                continue
+            sc = fn(dtype)
+            outs = run_scene(B, Bfast, sc)
+            nd = int((outs["index_img"] != outs["index_img_fast"]).sum())
+            print(f"{name}/{tag}: covered {(outs['index_img'] >= 0).sum().item()} px, "
+                  f"index px differing under --fast-math: {nd}")
+            save(f"{name}_{tag}", sc, outs)
+
+    # end-to-end step (SURVEY.md §8d definition) on the sphere scene
+    ops = make_ops(B)
+    sc = SCENES["spheres"](th.float32)
+    v = sc["v"].clone().requires_grad_(True)
+    attr = sc["attr"].clone().requires_grad_(True)
+    loss, index_img = S.fwd_bwd_step(v, sc["vi"], attr, sc["H"], sc["W"], ops=ops)
+    save("step_spheres_f32", dict(v=sc["v"], vi=sc["vi"], attr=sc["attr"], H=sc["H"], W=sc["W"]),
+         dict(loss=loss.detach(), index_img=index_img, v_grad=v.grad, attr_grad=attr.grad))
+
+    rec = two_triangles_trajectory(ops)
+    print("two_triangles trajectory:", dict(zip(rec["loss_iters"].tolist(), rec["loss_values"].tolist())))
+    save("two_triangles_trajectory", {}, rec)
+
+
+if __name__ == "__main__":
+    main()

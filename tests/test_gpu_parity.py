@@ -1,0 +1,253 @@
+"""GPU (-m gpu): the HIP kernels, called through the C ABI (drtk_amd.capi -> include/drtk_amd.h)
+and through the torch operators, against the committed reference fixtures and the CPU oracle.
+
+Bars: index_img and rasterize depth bit-exact; every other float within
+|d| <= 1e-5 + 1e-5 * max|ref| per tensor (SURVEY.md §7 hard part 3), upstream gradients O(1).
+"""
+import pytest
+import torch as th
+from conftest import GOLDEN_SCENES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def close(a, ref, what, atol=1e-5, rtol=1e-5):
+    a = a.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    tol = atol + rtol * float(ref.abs().max()) if ref.numel() else atol
+    err = float((a - ref).abs().max()) if ref.numel() else 0.0
+    assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
+
+
+def dev(x):
+    return x.to(DEV) if isinstance(x, th.Tensor) else x
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_capi_matches_reference_fixture(name):
+    from drtk_amd import capi
+
+    i, o = load_golden(name)
+    v, vi, H, W = dev(i["v"]), dev(i["vi"]), i["H"], i["W"]
+    vi_r = dev(i.get("vi_raster", i["vi"]))
+    depth, index = capi.rasterize(v, vi_r, H, W)
+    assert depth.dtype == th.float32 and index.dtype == th.int32
+    assert th.equal(index.cpu(), o["index_img"]), f"{(index.cpu() != o['index_img']).sum()} index px differ"
+    assert th.equal(depth.cpu(), o["depth_img"])
+    gi = dev(o["index_img"])
+    r_depth, r_bary = capi.render(v, vi, gi)
+    close(r_depth, o["render_depth"], "render depth")
+    close(r_bary, o["render_bary"], "render bary")
+    gb = dev(o["render_bary"])
+    close(capi.interpolate(dev(i["attr"]), vi, gi, gb), o["interp"], "interpolate")
+    close(capi.render_backward(v, vi, gi, dev(i["gd"]), dev(i["gb"])), o["grad_v"], "render backward")
+    ag, bg = capi.interpolate_backward(dev(i["go"]), dev(i["attr"]), vi, gi, gb)
+    close(ag, o["attr_grad"], "interpolate backward (attrs)")
+    close(bg, o["bary_grad"], "interpolate backward (bary)")
+    ag2, none = capi.interpolate_backward(dev(i["go"]), dev(i["attr"]), vi, gi, gb, True, False)
+    assert none is None
+    close(ag2, o["attr_grad"], "interpolate backward (attrs only)")
+    none, bg2 = capi.interpolate_backward(dev(i["go"]), dev(i["attr"]), vi, gi, gb, False, True)
+    assert none is None
+    close(bg2, o["bary_grad"], "interpolate backward (bary only)")
+    img = dev(o["img"])
+    close(capi.edge_grad_backward(v, img, gi, vi, dev(i["go"]), 1e4), o["edge_grad"], "edge_grad backward")
+    close(capi.edge_grad_backward(v, img, gi, vi, dev(i["go"]), 0.0), o["edge_grad_noclamp"], "edge_grad backward M=0")
+    vg, _ = capi.interpolate_backward(dev(o["edge_grad"]), v, vi, gi, gb, True, False)
+    close(vg, o["v_pix_grad_from_edges"], "edge grads routed to v_pix")
+
+
+@pytest.mark.parametrize("dtype", [th.float32, th.float64])
+@pytest.mark.parametrize("shape", [(3, 40, 44, 256, 320, 7), (1, 70, 72, 512, 512, 16), (2, 12, 14, 129, 203, 3)])
+def test_capi_matches_oracle_on_seeded_scenes(dtype, shape):
+    """Larger seeded scenes (two interpenetrating spheres) against the CPU oracle run in-process."""
+    import oracle as O
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    n, nl, no, H, W, C = shape
+    v, vi = S.sphere_views(n, nl, no, H, W, second_sphere=True, dtype=dtype)
+    g = th.Generator().manual_seed(7)
+    attr = th.rand(n, v.shape[1], C, generator=g).to(dtype)
+    gd = (th.rand(n, H, W, generator=g) * 2 - 1).to(dtype)
+    gbar = (th.rand(n, 3, H, W, generator=g) * 2 - 1).to(dtype)
+    go = (th.rand(n, C, H, W, generator=g) * 2 - 1).to(dtype)
+
+    d_o, i_o = O.rasterize(v, vi, H, W, nthreads=0)
+    d_g, i_g = capi.rasterize(dev(v), dev(vi), H, W)
+    assert th.equal(i_g.cpu(), i_o) and th.equal(d_g.cpu(), d_o)
+    rd_o, rb_o = O.render(v, vi, i_o, nthreads=0)
+    rd_g, rb_g = capi.render(dev(v), dev(vi), i_g)
+    close(rd_g, rd_o, "render depth")
+    close(rb_g, rb_o, "render bary")
+    close(capi.interpolate(dev(attr), dev(vi), i_g, dev(rb_o)), O.interpolate(attr, vi, i_o, rb_o, nthreads=0), "interp")
+    close(capi.render_backward(dev(v), dev(vi), i_g, dev(gd), dev(gbar)), O.render_backward(v, vi, i_o, gd, gbar), "render bwd")
+    ag_o, bg_o = O.interpolate_backward(go, attr, vi, i_o, rb_o)
+    ag_g, bg_g = capi.interpolate_backward(dev(go), dev(attr), dev(vi), i_g, dev(rb_o))
+    close(ag_g, ag_o, "attr grad")
+    close(bg_g, bg_o, "bary grad")
+    img = O.interpolate(attr, vi, i_o, rb_o, nthreads=0) * (i_o != -1)[:, None]
+    for M in (1e4, 0.0):
+        close(capi.edge_grad_backward(dev(v), dev(img), i_g, dev(vi), dev(go), M),
+              O.edge_grad_backward(v, img, i_o, vi, go, M), f"edge grad M={M}")
+
+
+def test_torch_ops_end_to_end_step_matches_reference():
+    """Full step through the drtk_amd Python API + torch operators + autograd vs the reference's
+    CPU step (fixture step_spheres_f32)."""
+    import drtk_amd
+    from drtk_amd import synthetic as S
+
+    i, o = load_golden("step_spheres_f32")
+    v = dev(i["v"]).clone().requires_grad_(True)
+    attr = dev(i["attr"]).clone().requires_grad_(True)
+    loss, index_img = S.fwd_bwd_step(v, dev(i["vi"]), attr, i["H"], i["W"], ops=drtk_amd)
+    assert th.equal(index_img.cpu(), o["index_img"])
+    assert abs(float(loss) - float(o["loss"])) <= 1e-6
+    close(v.grad, o["v_grad"], "v.grad")
+    close(attr.grad, o["attr_grad"], "attr.grad")
+
+
+def test_two_triangles_optimisation_matches_reference_curve():
+    """BASELINE config (1) scenario on the GPU path: same start, same Adam, same loss curve."""
+    import torch.nn.functional as thf
+
+    import drtk_amd as ops
+
+    _, r = load_golden("two_triangles_trajectory")
+    vi, vt, tex, img_gt = dev(r["vi"]), dev(r["vt"]), dev(r["tex"]), dev(r["img_gt"])
+    v = th.nn.Parameter(dev(r["v0"]).clone())
+    optim = th.optim.Adam([v], lr=0.05, betas=(0.9, 0.999))
+    want = dict(zip(r["loss_iters"].tolist(), r["loss_values"].tolist()))
+    for it in range(201):
+        index_img = ops.rasterize(v, vi, 64, 64)
+        _, bary_img = ops.render(v, vi, index_img)
+        vt_img = ops.interpolate(vt, vi, index_img, bary_img).permute(0, 2, 3, 1)
+        img = thf.grid_sample(tex, vt_img, padding_mode="border", align_corners=False) * (index_img != -1)[:, None]
+        img = ops.edge_grad_estimator(v_pix=v, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
+        loss = ((img - img_gt) ** 2).mean()
+        optim.zero_grad()
+        loss.backward()
+        if it == 0:
+            assert th.equal(index_img.cpu(), r["index0"])
+            close(bary_img, r["bary0"], "bary0")
+            close(v.grad, r["grad0"], "grad0")
+        if it in want:
+            assert abs(float(loss) - want[it]) <= 2e-2 * want[it], (it, float(loss), want[it])
+        optim.step()
+
+
+def test_autograd_contracts():
+    import drtk_amd as ops
+
+    i, o = load_golden("spheres_f32")
+    v, vi, attr = dev(i["v"]), dev(i["vi"]), dev(i["attr"])
+    H, W = i["H"], i["W"]
+    vr = v.clone().requires_grad_(True)
+    depth, index = ops.rasterize_with_depth(vr, vi, H, W)
+    assert not depth.requires_grad and not index.requires_grad  # non-differentiable outputs
+    # render: no grad node work when v did not require grad
+    d, b = ops.render(v, vi, index)
+    assert not d.requires_grad and not b.requires_grad
+    d, b = ops.render(vr, vi, index)
+    assert d.requires_grad and b.requires_grad
+    b.sum().backward()  # grad_depth undefined -> materialised zeros
+    assert vr.grad is not None and vr.grad.shape == v.shape
+    # interpolate: grads only where requested
+    ar = attr.clone().requires_grad_(True)
+    out = ops.interpolate(ar, vi, index, b.detach())
+    out.sum().backward()
+    assert ar.grad is not None
+    br = b.detach().clone().requires_grad_(True)
+    out = ops.interpolate(attr, vi, index, br)
+    out.sum().backward()
+    assert br.grad is not None and br.grad.shape == br.shape
+    # edge_grad_estimator returns img values unchanged and calls the hook with [N,3,H,W]
+    seen = {}
+    img = out.detach() * (index != -1)[:, None]
+    vr2 = v.clone().requires_grad_(True)
+    res = ops.edge_grad_estimator(vr2, vi, b.detach(), img, index, v_pix_img_hook=lambda g: seen.setdefault("g", g.clone()))
+    assert th.equal(res, img) and res.requires_grad
+    (res * res).sum().backward()
+    assert seen["g"].shape == (v.shape[0], 3, H, W) and vr2.grad is not None
+    # vi may be [N,F,3] or [F,3]
+    idx2 = ops.rasterize(v, vi[None].repeat(v.shape[0], 1, 1), H, W)
+    assert th.equal(idx2, index)
+
+
+def test_errors_are_loud():
+    import drtk_amd as ops
+
+    v = th.zeros(1, 3, 3, device=DEV)
+    vi = th.zeros(1, 3, dtype=th.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="int32"):
+        ops.rasterize(v, vi.long(), 8, 8)
+    with pytest.raises(RuntimeError, match="height and width"):
+        ops.rasterize(v, vi, 0, 8)
+    with pytest.raises(RuntimeError, match="not implemented for 'Half'"):
+        ops.rasterize(v.half(), vi, 8, 8)
+    with pytest.raises(RuntimeError, match="HIP"):
+        ops.rasterize(v.cpu(), vi.cpu(), 8, 8)
+    with pytest.raises(RuntimeError, match="wireframe"):
+        ops.rasterize(v, vi, 8, 8, wireframe=True)
+    with th.autocast("cuda", dtype=th.float16):  # autocast casts to fp32 like the reference
+        idx = ops.rasterize(v.half(), vi, 8, 8)
+    assert idx.dtype == th.int32
+
+
+def test_empty_inputs():
+    from drtk_amd import capi
+
+    v = th.zeros(2, 0, 3, device=DEV)
+    vi = th.zeros(0, 3, dtype=th.int32, device=DEV)
+    depth, index = capi.rasterize(v, vi, 16, 20)
+    assert (index == -1).all() and (depth == 0).all()
+    d, b = capi.render(v, vi, index)
+    assert (d == 0).all() and (b == 0).all()
+
+
+@pytest.mark.parametrize("cfg", [("10k", 4, 512, 3), ("100k", 2, 2048, 16)])
+def test_full_size_properties(cfg):
+    """BASELINE.json configs at full resolution: size-independent properties instead of the
+    (too slow) oracle: determinism, bary sums to one, interpolation of constant attributes is
+    constant, sum of attribute gradients equals sum of masked upstream gradients (partition of
+    unity), linearity of the backward passes."""
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    mesh, n, res, C = cfg
+    nl, no = S.MESH_SIZES[mesh]
+    v, vi = S.sphere_views(n, nl, no, res, res, lobes=0.05, device=DEV)
+    d1, i1 = capi.rasterize(v, vi, res, res)
+    d2, i2 = capi.rasterize(v, vi, res, res)
+    assert th.equal(i1, i2) and th.equal(d1, d2)
+    cov = i1 >= 0
+    frac = cov.float().mean().item()
+    assert 0.4 < frac < 0.75
+    assert int(i1.max()) < vi.shape[0]
+    depth, bary = capi.render(v, vi, i1)
+    close(bary.sum(1)[cov], th.ones(int(cov.sum())), "bary sums to 1")
+    close(depth[cov], d1[cov], "render depth == rasterize depth", atol=2e-5)
+    ones = th.ones(n, v.shape[1], C, device=DEV)
+    out = capi.interpolate(ones, vi, i1, bary)
+    close(out.permute(0, 2, 3, 1)[cov], th.ones(int(cov.sum()), C), "interp of ones")
+    g = th.Generator(device=DEV).manual_seed(3)
+    go = th.rand(n, C, res, res, device=DEV, generator=g) * 2 - 1
+    attr = th.rand(n, v.shape[1], C, device=DEV, generator=g)
+    ag, bg = capi.interpolate_backward(go, attr, vi, i1, bary)
+    # partition of unity: sum_v attr_grad[n,v,c] == sum_px covered go[n,c,px] * sum_k bary_k
+    lhs = ag.double().sum(1)
+    rhs = (go.double() * cov[:, None] * bary.double().sum(1, keepdim=True)).sum((2, 3))
+    close(lhs, rhs, "attr grad partition of unity", atol=1e-3, rtol=1e-6)
+    ag2, _ = capi.interpolate_backward(2 * go, attr, vi, i1, bary)
+    close(ag2, 2 * ag, "attr grad linearity", atol=1e-4)
+    img = out * cov[:, None]
+    eg = capi.edge_grad_backward(v, img, i1, vi, go)
+    assert th.isfinite(eg).all()
+    eg2 = capi.edge_grad_backward(v, img, i1, vi, 2 * go)
+    close(eg2, 2 * eg, "edge grad linearity in grad_output", atol=1e-4)
+    gv = capi.render_backward(v, vi, i1, th.ones_like(depth), th.zeros_like(bary))
+    assert th.isfinite(gv).all()

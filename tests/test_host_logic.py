@@ -1,0 +1,117 @@
+"""CPU: drop-in boundary checks that need no GPU -- the C ABI library loads and exports every
+symbol declared in include/drtk_amd.h, the torch operators are registered under the reference's
+names with the reference's schemas, the Python API mirrors drtk.*, and the product never imports
+the oracle."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch as th
+from conftest import ROOT
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "drtk_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(drtk_amd_\w+)\s*\(", hdr)))
+    assert len(declared) >= 10
+    from drtk_amd import capi
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "drtk_amd", "libdrtk_amd.so"))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/drtk_amd.h but not exported"
+    assert sorted(capi.EXPORTS) == declared
+    assert b"gfx950" in capi.lib().drtk_amd_version()
+    assert capi.lib().drtk_amd_status_string(0) == b"ok"
+
+
+def test_c_abi_argument_validation_without_gpu():
+    from drtk_amd import capi
+
+    L = capi.lib()
+    out = ctypes.c_size_t(0)
+    assert L.drtk_amd_rasterize_workspace_bytes(ctypes.c_int64(8), ctypes.c_int64(100352), ctypes.c_int64(2048),
+                                                ctypes.c_int64(2048), ctypes.byref(out)) == 0
+    assert 0 < out.value < 64 * 2**20
+    assert L.drtk_amd_rasterize_workspace_bytes(ctypes.c_int64(1), ctypes.c_int64(1), ctypes.c_int64(0),
+                                                ctypes.c_int64(4), ctypes.byref(out)) == -1
+    # wireframe is refused before anything touches the device
+    z = ctypes.c_void_p(0)
+    rc = L.drtk_amd_rasterize(ctypes.c_int(0), z, z, ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0),
+                              ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(1), z, z, z,
+                              ctypes.c_size_t(0), z)
+    assert rc == -4
+    rc = L.drtk_amd_rasterize(ctypes.c_int(0), z, z, ctypes.c_int64(1), ctypes.c_int64(1 << 28), ctypes.c_int64(0),
+                              ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(0), z, z, z,
+                              ctypes.c_size_t(0), z)
+    assert rc == -5  # V >= 2^28 (rasterize_kernel.cu:459-462)
+
+
+def test_torch_operator_schemas_match_reference():
+    import drtk_amd  # noqa: F401  (loads the library)
+
+    want = {
+        "rasterize_ext::rasterize": "rasterize_ext::rasterize(Tensor v, Tensor vi, int height, int width, bool wireframe) -> Tensor[]",
+        "render_ext::render": "render_ext::render(Tensor v, Tensor vi, Tensor index_img) -> Tensor[]",
+        "interpolate_ext::interpolate": "interpolate_ext::interpolate(Tensor vert_attributes, Tensor vi, Tensor index_img, Tensor bary_img) -> Tensor",
+        "edge_grad_ext::edge_grad_estimator": "edge_grad_ext::edge_grad_estimator(Tensor v_pix, Tensor v_pix_img, Tensor vi, Tensor img, Tensor index_img, float max_dp_dr=10000.) -> Tensor",
+    }
+    for name, schema in want.items():
+        ns, op = name.split("::")
+        got = str(getattr(getattr(th.ops, ns), op).default._schema)
+        assert got.replace(" ", "") == schema.replace(" ", ""), got
+        for key in ("CUDA", "CPU", "Autograd", "AutocastCUDA"):
+            assert th._C._dispatch_has_kernel_for_dispatch_key(name, key), (name, key)
+
+
+def test_python_api_mirrors_drtk_signatures():
+    import drtk_amd
+
+    def params(f):
+        return [(p.name, p.default) for p in inspect.signature(f).parameters.values()]
+
+    E = inspect.Parameter.empty
+    assert params(drtk_amd.rasterize) == [("v", E), ("vi", E), ("height", E), ("width", E), ("wireframe", False)]
+    assert params(drtk_amd.rasterize_with_depth) == params(drtk_amd.rasterize)
+    assert params(drtk_amd.render) == [("v", E), ("vi", E), ("index_img", E)]
+    assert params(drtk_amd.interpolate) == [("vert_attributes", E), ("vi", E), ("index_img", E), ("bary_img", E)]
+    assert params(drtk_amd.edge_grad_estimator) == [
+        ("v_pix", E), ("vi", E), ("bary_img", E), ("img", E), ("index_img", E), ("v_pix_img_hook", None),
+        ("max_dp_dr", 1e4)]
+    assert drtk_amd.__version__ == "0.1.0"
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    import drtk_amd
+
+    v = th.zeros(1, 3, 3)
+    vi = th.zeros(1, 3, dtype=th.int32)
+    with pytest.raises(RuntimeError, match="HIP"):
+        drtk_amd.rasterize(v, vi, 4, 4)
+    with pytest.raises(RuntimeError, match="HIP"):
+        drtk_amd.render(v, vi, th.zeros(1, 4, 4, dtype=th.int32))
+    with pytest.raises(RuntimeError, match="HIP"):
+        drtk_amd.interpolate(v, vi, th.zeros(1, 4, 4, dtype=th.int32), th.zeros(1, 3, 4, 4))
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "drtk_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"drtk_oracle", r"[\"'/]oracle[\"'/]", r"ref_build", r"_ref/"):
+                    assert not re.search(pat, src), f"{f} reaches into the oracle ({pat})"
+
+
+def test_synthetic_mesh_sizes():
+    from drtk_amd import synthetic as S
+
+    for name, f in (("10k", 10080), ("100k", 100352), ("250k", 250632), ("1M", 1002528)):
+        nl, no = S.MESH_SIZES[name]
+        assert 2 * nl * no == f
+    v, vi = S.uv_sphere(6, 8)
+    assert v.shape == (56, 3) and vi.shape == (96, 3) and vi.dtype == th.int32
+    vp, _ = S.sphere_views(3, 6, 8, 32, 32)
+    assert vp.shape == (3, 56, 3) and (vp[..., 2] > 1.9).all() and (vp[..., 2] < 4.1).all()

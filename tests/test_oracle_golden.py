@@ -1,0 +1,108 @@
+"""CPU: the oracle restatement (oracle/drtk_oracle.c) against the committed golden vectors, which
+were produced by the reference's own CPU kernels (oracle/gen_golden.py).  Everything is bit-exact:
+index/depth images, every forward float tensor, and -- single-threaded, same accumulation order --
+every gradient."""
+import pytest
+import torch as th
+from conftest import GOLDEN_SCENES, load_golden
+
+import oracle as O
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_oracle_matches_reference_fixture(name):
+    i, o = load_golden(name)
+    v, vi, H, W = i["v"], i["vi"], i["H"], i["W"]
+    vi_r = i.get("vi_raster", vi)
+    depth, index = O.rasterize(v, vi_r, H, W)
+    assert th.equal(index, o["index_img"])
+    assert th.equal(depth, o["depth_img"])
+    assert depth.dtype == th.float32  # rasterize depth is float32 even for float64 v
+    r_depth, r_bary = O.render(v, vi, index)
+    assert th.equal(r_depth, o["render_depth"]) and th.equal(r_bary, o["render_bary"])
+    interp = O.interpolate(i["attr"], vi, index, r_bary)
+    assert th.equal(interp, o["interp"])
+    assert th.equal(O.render_backward(v, vi, index, i["gd"], i["gb"]), o["grad_v"])
+    ag, bg = O.interpolate_backward(i["go"], i["attr"], vi, index, r_bary)
+    assert th.equal(ag, o["attr_grad"]) and th.equal(bg, o["bary_grad"])
+    img = interp * (index != -1)[:, None]
+    assert th.equal(img, o["img"])
+    assert th.equal(O.edge_grad_backward(v, img, index, vi, i["go"], 1e4), o["edge_grad"])
+    assert th.equal(O.edge_grad_backward(v, img, index, vi, i["go"], 0.0), o["edge_grad_noclamp"])
+    vg, none = O.interpolate_backward(o["edge_grad"], v, vi, index, r_bary, True, False)
+    assert none is None and th.equal(vg, o["v_pix_grad_from_edges"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_fast_math_reference_build_only_moves_depth_lsbs(name):
+    """The reference's own flags (-O3 --fast-math) change depth LSBs but, on these scenes, no
+    index_img pixel; any future mismatch against a fast-math build must be a depth near-tie."""
+    _, o = load_golden(name)
+    assert th.equal(o["index_img"], o["index_img_fast"])
+    d, df = o["depth_img"].double(), o["depth_img_fast"].double()
+    assert ((d - df).abs() <= 4e-7 * d.abs().clamp(min=1.0)).all()
+
+
+def test_known_answers_edge_cases():
+    """Appendix E of SURVEY.md: answers known independently of any build."""
+    i, o = load_golden("edge_cases_f32")
+    idx = o["index_img"]
+    # 0: coincident triangles of opposite winding and equal depth: lower id wins everywhere
+    assert set(idx[0].unique().tolist()) == {-1, 0}
+    # 1: quad [0,6]^2 split on the diagonal: exactly x,y in 0..5 covered, x >= y -> tri 0, else tri 1
+    cov = idx[1] >= 0
+    exp = th.zeros(16, 16, dtype=th.bool)
+    exp[:6, :6] = True
+    assert th.equal(cov, exp)
+    yy, xx = th.meshgrid(th.arange(16), th.arange(16), indexing="ij")
+    assert th.equal(idx[1][exp], th.where(xx >= yy, 0, 1).to(th.int32)[exp])
+    # 2: z = 0 and z = 1e-9 vertices: whole triangles culled (near plane is 1e-8, no clipping)
+    assert (idx[2] == -1).all()
+    # 3: off-screen, and zero-area (a,a,b)
+    assert (idx[3] == -1).all()
+    # 4: far-away huge triangle covers the canvas except where the nearer small one wins
+    assert (idx[4] >= 0).all() and (idx[4] == 1).sum() > 0
+    # empty pixels: depth exactly 0, bary exactly 0, interpolate = +-1 coordinate sweep
+    assert (o["depth_img"][idx == -1] == 0).all()
+    assert (o["render_bary"].permute(0, 2, 3, 1)[idx == -1] == 0).all()
+    bgx = (th.arange(16, dtype=th.float32) * 2 + 1) / 16 - 1
+    assert th.equal(o["interp"][2, 0], bgx[None, :].expand(16, 16))
+    assert th.equal(o["interp"][2, 1], bgx[:, None].expand(16, 16))
+
+
+def test_bary_sums_to_one_and_depth_in_range():
+    i, o = load_golden("spheres_f32")
+    cov = o["index_img"] >= 0
+    s = o["render_bary"].sum(1)
+    assert ((s[cov] - 1).abs() < 1e-5).all()
+    assert (o["render_depth"][cov] > 1.9).all() and (o["render_depth"][cov] < 4.2).all()
+
+
+def test_two_triangles_trajectory_reproduced_by_oracle(oracle_ops):
+    """Config (1) of BASELINE.json: test/two_triangles.py at 64x64 on the CPU path.  The oracle
+    pipeline must reproduce the reference's iteration-0 tensors exactly and its loss curve."""
+    import numpy as np
+    import torch.nn.functional as thf
+
+    _, r = load_golden("two_triangles_trajectory")
+    ops = oracle_ops
+    vi, vt, tex, img_gt = r["vi"], r["vt"], r["tex"], r["img_gt"]
+    v = th.nn.Parameter(r["v0"].clone())
+    optim = th.optim.Adam([v], lr=0.05, betas=(0.9, 0.999))
+    want = dict(zip(r["loss_iters"].tolist(), r["loss_values"].tolist()))
+    for it in range(201):
+        index_img = ops.rasterize(v, vi, 64, 64)
+        _, bary_img = ops.render(v, vi, index_img)
+        vt_img = ops.interpolate(vt, vi, index_img, bary_img).permute(0, 2, 3, 1)
+        img = thf.grid_sample(tex, vt_img, padding_mode="border", align_corners=False) * (index_img != -1)[:, None]
+        img = ops.edge_grad_estimator(v_pix=v, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
+        loss = ((img - img_gt) ** 2).mean()
+        optim.zero_grad()
+        loss.backward()
+        if it == 0:
+            assert th.equal(index_img, r["index0"]) and th.equal(bary_img.detach(), r["bary0"])
+            assert th.equal(img.detach(), r["img0"]) and th.equal(v.grad, r["grad0"])
+        if it in want:
+            assert abs(float(loss.detach()) - want[it]) <= 1e-3 * want[it] + 1e-9, (it, float(loss.detach()), want[it])
+        optim.step()
+    assert float(loss.detach()) < 0.2 * want[0]
