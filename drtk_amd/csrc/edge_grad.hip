@@ -408,7 +408,8 @@ extern "C" int drtk_amd_edge_grad_backward(
   size_t need = 0;
   if (drtk_amd_edge_grad_backward_workspace_bytes(dtype, N, H, W, &need) != DRTK_OK) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W > 0) {
-    if (!v_pix || !index_img || !vi || !grad_v_pix_img || !workspace) return DRTK_ERR_INVALID_ARGUMENT;
+    if (!index_img || !grad_v_pix_img || !workspace) return DRTK_ERR_INVALID_ARGUMENT;
+    if ((N * V > 0 && !v_pix) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
     if (C > 0 && (!img || !grad_output)) return DRTK_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < need) return DRTK_ERR_WORKSPACE_TOO_SMALL;
   }

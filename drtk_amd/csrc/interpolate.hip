@@ -294,7 +294,8 @@ extern "C" int drtk_amd_interpolate(
     const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H,
     int64_t W, void* out, drtk_stream_t stream) {
   if (bad_common(N, V, C, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
-  if (N * H * W * C > 0 && (!attrs || !vi || !index_img || !bary_img || !out)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W * C > 0 && (!index_img || !bary_img || !out)) return DRTK_ERR_INVALID_ARGUMENT;
+  if ((N * V * C > 0 && !attrs) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:
@@ -312,7 +313,8 @@ extern "C" int drtk_amd_interpolate_backward(
     int64_t vi_sN, int64_t H, int64_t W, void* attr_grad, void* bary_grad, drtk_stream_t stream) {
   if (bad_common(N, V, C, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
   if (!attr_grad && !bary_grad) return DRTK_ERR_INVALID_ARGUMENT;
-  if (N * H * W * C > 0 && (!grad_out || !attrs || !vi || !index_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W * C > 0 && (!grad_out || !index_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  if ((N * V * C > 0 && !attrs) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:

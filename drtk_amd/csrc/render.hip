@@ -274,7 +274,8 @@ extern "C" int drtk_amd_render(
     int64_t V, int64_t F, int64_t vi_sN, int64_t H, int64_t W, void* depth_img, void* bary_img,
     drtk_stream_t stream) {
   if (bad_common(N, V, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
-  if (N * H * W > 0 && (!v || !vi || !index_img || !depth_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W > 0 && (!index_img || !depth_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  if ((N * V > 0 && !v) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:
@@ -292,7 +293,8 @@ extern "C" int drtk_amd_render_backward(
     int64_t vi_sN, int64_t H, int64_t W, void* grad_v, drtk_stream_t stream) {
   if (bad_common(N, V, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * V > 0 && !grad_v) return DRTK_ERR_INVALID_ARGUMENT;
-  if (N * H * W > 0 && (!v || !vi || !index_img || !grad_depth_img || !grad_bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W > 0 && (!index_img || !grad_depth_img || !grad_bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
+  if ((N * V > 0 && !v) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:
