@@ -58,22 +58,24 @@ __device__ __forceinline__ Row<T, VEC> load_row(
     for (int j = 0; j < VEC; ++j) r.v[j] = T(0);
   }
   r.next = __shfl_down(r.v[0], 1);
-  if (lane == kWave - 1 && x + VEC < W) r.next = plane[row_off + x + VEC];
+  if (lane == kWave - 1 && x_ok && x + VEC < W) r.next = plane[row_off + x + VEC];
   return r;
 }
 
-// One wave = strip of 64*VEC pixels x R rows.  gdx[y][x] pairs (x,y)-(x+1,y), gdy[y][x] pairs
-// (x,y)-(x,y+1); accumulation over channels in ascending order (edge_grad_kernel.cu:353-380).
+// One wave = strip of 64*VEC pixels x R rows; the 4 waves of a workgroup are stacked vertically on
+// the same pixel columns (4R rows per workgroup), so the extra "row below" every wave needs is the
+// first row of its sibling wave and is served by this CU's L1 -- HBM sees each row (4R+1)/4R times.
+// gdx[y][x] pairs (x,y)-(x+1,y), gdy[y][x] pairs (x,y)-(x,y+1); accumulation over channels in
+// ascending order (edge_grad_kernel.cu:353-380).
 template <typename T, int VEC, int R>
 __global__ __launch_bounds__(kBlock) void edge_dots_kernel(
     const T* __restrict__ img, const T* __restrict__ grad_output, int C, int H, int W,
     int strips_x, T* __restrict__ gdx, T* __restrict__ gdy) {
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
-  const int wave_global = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  const int by = blockIdx.x / strips_x, sx = blockIdx.x - by * strips_x;
   const int lane = threadIdx.x & (kWave - 1);
-  const int sy = wave_global / strips_x, sx = wave_global - sy * strips_x;
-  const int y0 = sy * R;
+  const int y0 = (by * (kBlock / kWave) + threadIdx.x / kWave) * R;
   if (y0 >= H) return;
   const int x = (sx * kWave + lane) * VEC;
   const bool x_ok = x < W;
@@ -89,27 +91,21 @@ __global__ __launch_bounds__(kBlock) void edge_dots_kernel(
   for (int c = 0; c < C; ++c) {
     const T* ip = img_n + int64_t(c) * HW;
     const T* gp = go_n + int64_t(c) * HW;
-    Row<T, VEC> pi = load_row<T, VEC>(ip, int64_t(y0) * W, x, W, x_ok, lane);
-    Row<T, VEC> pg = load_row<T, VEC>(gp, int64_t(y0) * W, x, W, x_ok, lane);
+    Row<T, VEC> ri[R + 1], rg[R + 1];
+#pragma unroll
+    for (int r = 0; r <= R; ++r) {
+      const bool y_ok = (y0 + r) < H; // wave-uniform
+      ri[r] = load_row<T, VEC>(ip, int64_t(y0 + r) * W, x, W, x_ok && y_ok, lane);
+      rg[r] = load_row<T, VEC>(gp, int64_t(y0 + r) * W, x, W, x_ok && y_ok, lane);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int y = y0 + r;
-      if (y >= H) break;
-      // horizontal pairs of row y
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T ir = (j + 1 < VEC) ? pi.v[(j + 1) % VEC] : pi.next;
-        const T gr = (j + 1 < VEC) ? pg.v[(j + 1) % VEC] : pg.next;
-        ax[r][j] += (ir - pi.v[j]) * (T(0.5) * (gr + pg.v[j]));
-      }
-      if (y + 1 < H) {
-        Row<T, VEC> ci = load_row<T, VEC>(ip, int64_t(y + 1) * W, x, W, x_ok, lane);
-        Row<T, VEC> cg = load_row<T, VEC>(gp, int64_t(y + 1) * W, x, W, x_ok, lane);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          ay[r][j] += (ci.v[j] - pi.v[j]) * (T(0.5) * (cg.v[j] + pg.v[j]));
-        pi = ci;
-        pg = cg;
+        const T inext = (j + 1 < VEC) ? ri[r].v[(j + 1) % VEC] : ri[r].next;
+        const T gnext = (j + 1 < VEC) ? rg[r].v[(j + 1) % VEC] : rg[r].next;
+        ax[r][j] += (inext - ri[r].v[j]) * (T(0.5) * (gnext + rg[r].v[j]));
+        ay[r][j] += (ri[r + 1].v[j] - ri[r].v[j]) * (T(0.5) * (rg[r + 1].v[j] + rg[r].v[j]));
       }
     }
   }
@@ -352,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void edge_gather_kernel(
   o[2 * HW] = ((T(0) + (-dz)) + (-rz)) + (-cz);
 }
 
-constexpr int kStripRows = 8;
+constexpr int kStripRows = 2; // rows per wave; a workgroup covers 4x that
 
 template <typename T>
 int edge_grad_backward_impl(
@@ -368,9 +364,8 @@ int edge_grad_backward_impl(
       (reinterpret_cast<uintptr_t>(workspace) % (4 * sizeof(T)) == 0);
   const int px_per_wave = kWave * (vec ? 4 : 1);
   const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
-  const int strips_y = static_cast<int>(ceil_div(H, kStripRows));
-  const int64_t waves = int64_t(strips_x) * strips_y;
-  const dim3 gridA(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
+  const int bands_y = static_cast<int>(ceil_div(H, kStripRows * (kBlock / kWave)));
+  const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
   if (vec) {
     hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows>), gridA, dim3(kBlock), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
   } else {

@@ -12,9 +12,12 @@
 //   2. bin_scan    exclusive scan of the N*tiles counters (one workgroup).
 //   3. bin_fill    second pass over the triangles writes their id into each touched tile's list.
 //   4. tile_raster one workgroup per (view, tile): the tile's packed (depth_bits<<32 | id) z-buffer
-//                  lives in LDS (64x64x8 B = 32 KiB), small triangles are rasterized one per lane,
-//                  big triangles pixel-parallel across the whole workgroup, both with LDS 64-bit
-//                  atomicMin (ds_min_u64); the finished tile is unpacked and stored once.
+//                  lives in LDS (64x64x8 B = 32 KiB).  Each wave takes 64 binned triangles, sets
+//                  them up one per lane, then walks them one at a time: the triangle's plane
+//                  equations are broadcast into SGPRs (v_readlane) and its bbox is covered with
+//                  64-pixel stamps, one pixel per lane, resolved with LDS 64-bit atomicMin
+//                  (ds_min_u64); the finished tile is unpacked and stored once.
+//                  Counters in passes 1/3 are bumped with wave-aggregated atomics.
 //
 // HBM traffic is therefore the 8 B/px of real output plus the bins (~28 B per triangle): no
 // memset, no global atomics, no unpack pass (the reference moves >= 24 B/px).
@@ -181,35 +184,73 @@ inline BinLayout make_layout(int64_t N, int64_t F, int64_t H, int64_t W) {
   return L;
 }
 
+// Wave-aggregated "+1" on counters[key] for the lanes with `on` set: lanes of a wave that hit the same
+// counter (consecutive triangles of a mesh mostly land in the same few tiles) are merged into ONE
+// atomic by their first lane.  With FETCH each lane gets its own slot (old value + rank).
+template <bool FETCH>
+__device__ __forceinline__ int wave_agg_inc(int32_t* __restrict__ counters, int key, bool on) {
+  const int lane = lane_id();
+  unsigned long long todo = __ballot(on);
+  int pos = 0;
+  while (todo) {
+    const int leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+    const int k = __builtin_amdgcn_readlane(key, leader);
+    const bool mine = on && key == k;
+    const unsigned long long same = __ballot(mine);
+    int base = 0;
+    if (lane == leader) {
+      const int cnt = __popcll(same);
+      if (FETCH) {
+        base = atomicAdd(counters + k, cnt);
+      } else {
+        atomicAdd(counters + k, cnt);
+      }
+    }
+    if (FETCH) {
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (mine) pos = base + __popcll(same & ((1ull << lane) - 1ull));
+    }
+    todo &= ~same;
+  }
+  return pos;
+}
+
 // ---- pass 1: cull, bbox -> tile range, count -------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(
-    const T* __restrict__ v, const int32_t* __restrict__ vi, int64_t total, int F, int64_t V,
-    int64_t vi_sN, int H, int W, int tile_shift, int tiles_x, int tiles_per_view,
-    int32_t* __restrict__ tile_count, int32_t* __restrict__ big_count,
-    int32_t* __restrict__ big_list, uint2* __restrict__ tri_range) {
-  const int64_t idx = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-  if (idx >= total) return;
-  const int n = static_cast<int>(idx / F);
-  const int f = static_cast<int>(idx - int64_t(n) * F);
+    const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN, int H,
+    int W, int tile_shift, int tiles_x, int tiles_per_view, int32_t* __restrict__ tile_count,
+    int32_t* __restrict__ big_count, int32_t* __restrict__ big_list, uint2* __restrict__ tri_range) {
+  const int n = blockIdx.y;
+  const int f = blockIdx.x * kBlock + threadIdx.x;
+  const bool in_range = f < F;
   int bx0, by0, bx1, by1;
   uint2 r = make_uint2(kCulled, kCulled);
-  if (tri_bbox<T>(v + int64_t(n) * V * 3, vi + int64_t(n) * vi_sN + int64_t(f) * 3, H, W, bx0, by0, bx1, by1)) {
-    const int tx0 = bx0 >> tile_shift, tx1 = bx1 >> tile_shift;
-    const int ty0 = by0 >> tile_shift, ty1 = by1 >> tile_shift;
+  int tx0 = 0, ty0 = 0, tw = 0, ntiles = 0;
+  if (in_range &&
+      tri_bbox<T>(v + int64_t(n) * V * 3, vi + int64_t(n) * vi_sN + int64_t(f) * 3, H, W, bx0, by0, bx1, by1)) {
+    tx0 = bx0 >> tile_shift;
+    ty0 = by0 >> tile_shift;
+    const int tx1 = bx1 >> tile_shift, ty1 = by1 >> tile_shift;
     r.x = static_cast<uint32_t>(tx0) | (static_cast<uint32_t>(tx1) << 16);
     r.y = static_cast<uint32_t>(ty0) | (static_cast<uint32_t>(ty1) << 16);
-    const int ntiles = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-    if (ntiles <= kMaxSmallTiles) {
-      int32_t* cnt = tile_count + int64_t(n) * tiles_per_view;
-      for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(cnt + ty * tiles_x + tx, 1);
-    } else {
-      const int pos = atomicAdd(big_count + n, 1);
-      big_list[int64_t(n) * F + pos] = f;
-    }
+    tw = tx1 - tx0 + 1;
+    ntiles = tw * (ty1 - ty0 + 1);
   }
-  tri_range[idx] = r;
+  if (in_range) tri_range[int64_t(n) * F + f] = r;
+  const bool small = ntiles >= 1 && ntiles <= kMaxSmallTiles;
+  const int base = n * tiles_per_view;
+  for (int s = 0; s < kMaxSmallTiles; ++s) {
+    const bool on = small && s < ntiles;
+    const int dy = on ? s / tw : 0;
+    const int dx = on ? s - dy * tw : 0;
+    wave_agg_inc<false>(tile_count, base + (ty0 + dy) * tiles_x + tx0 + dx, on);
+  }
+  const bool big = ntiles > kMaxSmallTiles;
+  if (__ballot(big)) {
+    const int pos = wave_agg_inc<true>(big_count, n, big);
+    if (big) big_list[int64_t(n) * F + pos] = f;
+  }
 }
 
 // ---- pass 2: exclusive scan over all tile counters (single workgroup) -------------------------
@@ -241,27 +282,134 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
 
 // ---- pass 3: write triangle ids into the tile lists -----------------------------------------
 __global__ __launch_bounds__(kBlock) void bin_fill_kernel(
-    const uint2* __restrict__ tri_range, int64_t total, int F, int tiles_x, int tiles_per_view,
+    const uint2* __restrict__ tri_range, int F, int tiles_x, int tiles_per_view,
     const int32_t* __restrict__ tile_offset, int32_t* __restrict__ tile_cursor,
     int32_t* __restrict__ pairs) {
-  const int64_t idx = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-  if (idx >= total) return;
-  const uint2 r = tri_range[idx];
-  if (r.x == kCulled) return;
-  const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-  if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kMaxSmallTiles) return;
-  const int n = static_cast<int>(idx / F);
-  const int f = static_cast<int>(idx - int64_t(n) * F);
-  const int64_t base = int64_t(n) * tiles_per_view;
-  for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      const int64_t t = base + ty * tiles_x + tx;
-      const int pos = atomicAdd(tile_cursor + t, 1);
-      pairs[tile_offset[t] + pos] = f;
+  const int n = blockIdx.y;
+  const int f = blockIdx.x * kBlock + threadIdx.x;
+  int tx0 = 0, ty0 = 0, tw = 0, ntiles = 0;
+  if (f < F) {
+    const uint2 r = tri_range[int64_t(n) * F + f];
+    if (r.x != kCulled) {
+      tx0 = r.x & 0xFFFF;
+      ty0 = r.y & 0xFFFF;
+      tw = static_cast<int>(r.x >> 16) - tx0 + 1;
+      ntiles = tw * (static_cast<int>(r.y >> 16) - ty0 + 1);
     }
+  }
+  const bool small = ntiles >= 1 && ntiles <= kMaxSmallTiles;
+  const int base = n * tiles_per_view;
+  for (int s = 0; s < kMaxSmallTiles; ++s) {
+    const bool on = small && s < ntiles;
+    const int dy = on ? s / tw : 0;
+    const int dx = on ? s - dy * tw : 0;
+    const int t = base + (ty0 + dy) * tiles_x + tx0 + dx;
+    const int pos = wave_agg_inc<true>(tile_cursor, t, on);
+    if (on) pairs[tile_offset[t] + pos] = f;
+  }
 }
 
 // ---- pass 4: per-tile rasterization with the z-buffer in LDS -----------------------------------
+// Wave-uniform plane equations of one triangle (broadcast out of the lane that set it up).
+template <typename T>
+struct TriUniform {
+  T ax[3], ay[3], dx[3], dy[3], s[3]; // edge k: ((py - ay) * dx - (px - ax) * dy) * s
+  T abs_denom, dinv0, dinv1, dinv2;
+  int tl; // bit k: edge k is top-left
+};
+
+__device__ __forceinline__ int bcast(int x, int lane) {
+  return __builtin_amdgcn_readlane(x, lane);
+}
+__device__ __forceinline__ float bcast(float x, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+__device__ __forceinline__ double bcast(double x, int lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(u & 0xFFFFFFFFull), lane);
+  const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(u >> 32), lane);
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// Rasterize the triangles held one-per-lane (`valid` lanes; setup `s`, id `f`) into the LDS tile:
+// the wave walks the valid lanes, broadcasts one triangle at a time into SGPRs and covers its
+// bbox ∩ tile with 64-pixel stamps whose shape (sw x 64/sw, sw = pow2 >= bbox width) follows the
+// bbox, so slivers and blobs both keep most lanes inside the box.  Coverage, depth and the packed
+// atomicMin are the reference's (rasterize_kernel.cu:117-161), evaluated per lane = per pixel.
+template <typename T, int TILE_SHIFT>
+__device__ __forceinline__ void raster_lanes(
+    bool valid, const TriSetup<T>& s, int f, int x0, int y0, int x1, int y1,
+    unsigned long long* __restrict__ zbuf) {
+  const int lane = lane_id();
+  // per-lane: oriented edges + clipped bbox
+  T eax[3], eay[3], edx[3], edy[3], es[3];
+  {
+    const T px[3] = {s.p1x, s.p2x, s.p0x}, py[3] = {s.p1y, s.p2y, s.p0y}; // edge k starts at p_{k+1}
+    const T qx[3] = {s.p2x, s.p0x, s.p1x}, qy[3] = {s.p2y, s.p0y, s.p1y}; // ... and ends at p_{k+2}
+    const bool c[3] = {s.c0, s.c1, s.c2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      eax[k] = c[k] ? px[k] : qx[k];
+      eay[k] = c[k] ? py[k] : qy[k];
+      const T bx = c[k] ? qx[k] : px[k], by = c[k] ? qy[k] : py[k];
+      edx[k] = bx - eax[k];
+      edy[k] = by - eay[k];
+      es[k] = c[k] ? s.sign_denom : -s.sign_denom;
+    }
+  }
+  const int bx0 = max(s.bb_min_x, x0), bx1 = min(s.bb_max_x, x1);
+  const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
+  const int tl = (s.tl0 ? 1 : 0) | (s.tl1 ? 2 : 0) | (s.tl2 ? 4 : 0);
+  unsigned long long todo = __ballot(valid && bx0 <= bx1 && by0 <= by1);
+  while (todo) {
+    const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+    todo &= todo - 1;
+    TriUniform<T> u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      u.ax[k] = bcast(eax[k], j);
+      u.ay[k] = bcast(eay[k], j);
+      u.dx[k] = bcast(edx[k], j);
+      u.dy[k] = bcast(edy[k], j);
+      u.s[k] = bcast(es[k], j);
+    }
+    u.abs_denom = bcast(s.abs_denom, j);
+    u.dinv0 = bcast(s.dinv0, j);
+    u.dinv1 = bcast(s.dinv1, j);
+    u.dinv2 = bcast(s.dinv2, j);
+    u.tl = bcast(tl, j);
+    const int ubx0 = bcast(bx0, j), uby0 = bcast(by0, j), uby1 = bcast(by1, j);
+    const int bw = bcast(bx1, j) - ubx0 + 1;
+    const unsigned long long id = static_cast<uint32_t>(bcast(f, j));
+    // stamp shape
+    const int sw_log = bw <= 1 ? 0 : (32 - __builtin_clz(bw - 1)); // ceil(log2(bw)), <= TILE_SHIFT <= 6
+    const int lx = lane & ((1 << sw_log) - 1), ly = lane >> sw_log;
+    const int sh = kWave >> sw_log;
+    const int x = ubx0 + lx;
+    const T px = static_cast<T>(x);
+    T ex[3]; // -(px - ax) * dy part, constant over rows
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ex[k] = (px - u.ax[k]) * u.dy[k];
+    if (lx < bw) {
+      for (int y = uby0 + ly; y <= uby1; y += sh) {
+        const T py = static_cast<T>(y);
+        T b0 = ((py - u.ay[0]) * u.dx[0] - ex[0]) * u.s[0];
+        T b1 = ((py - u.ay[1]) * u.dx[1] - ex[1]) * u.s[1];
+        T b2 = ((py - u.ay[2]) * u.dx[2] - ex[2]) * u.s[2];
+        if (!((b0 >= T(0)) && (b1 >= T(0)) && (b2 >= T(0)))) continue;
+        if ((!(u.tl & 1) && b0 == T(0)) || (!(u.tl & 2) && b1 == T(0)) || (!(u.tl & 4) && b2 == T(0))) continue;
+        b0 /= u.abs_denom;
+        b1 /= u.abs_denom;
+        b2 /= u.abs_denom;
+        const T depth_inverse = u.dinv0 * b0 + u.dinv1 * b1 + u.dinv2 * b2;
+        const float depth = static_cast<float>(T(1) / epsclamp(depth_inverse));
+        const unsigned long long packed = (static_cast<unsigned long long>(__float_as_uint(depth)) << 32) | id;
+        atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], packed);
+      }
+    }
+  }
+}
+
 template <typename T, int TILE_SHIFT>
 __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN,
@@ -287,52 +435,37 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
   const T* v_n = v + int64_t(n) * V * 3;
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
 
-  // small triangles: one per lane
+  // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively
   const int begin = tile_offset[tile], end = tile_offset[tile + 1];
-  for (int i = begin + tid; i < end; i += kBlock) {
-    const int f = pairs[i];
-    TriSetup<T> s;
-    if (!tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s)) continue;
-    const int bx0 = max(s.bb_min_x, x0), bx1 = min(s.bb_max_x, x1);
-    const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
-    for (int y = by0; y <= by1; ++y) {
-      for (int x = bx0; x <= bx1; ++x) {
-        uint32_t dbits;
-        if (fragment(s, x, y, dbits)) {
-          const unsigned long long packed =
-              (static_cast<unsigned long long>(dbits) << 32) | static_cast<uint32_t>(f);
-          atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], packed);
-        }
-      }
+  for (int i0 = begin + (tid & ~(kWave - 1)); i0 < end; i0 += kBlock) {
+    const int i = i0 + (tid & (kWave - 1));
+    int f = 0;
+    bool valid = false;
+    TriSetup<T> s = {};
+    if (i < end) {
+      f = pairs[i];
+      valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
     }
+    raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf);
   }
 
-  // big triangles: the whole workgroup sweeps bbox ∩ tile pixel-parallel
+  // big triangles (more than kMaxSmallTiles tiles): per-view list, filtered by tile range
   const int nbig = big_count[n];
   const int32_t* big_n = big_list + int64_t(n) * F;
   const uint2* range_n = tri_range + int64_t(n) * F;
-  for (int b = 0; b < nbig; ++b) {
-    const int f = __builtin_amdgcn_readfirstlane(big_n[b]);
-    const uint2 r = range_n[f];
-    const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = r.y >> 16;
-    if (tx < rtx0 || tx > rtx1 || ty < rty0 || ty > rty1) continue;
-    TriSetup<T> s;
-    if (!tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s)) continue;
-    const int bx0 = max(s.bb_min_x, x0), bx1 = min(s.bb_max_x, x1);
-    const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
-    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-    if (bw <= 0 || bh <= 0) continue;
-    const int npx = bw * bh;
-    for (int k = tid; k < npx; k += kBlock) {
-      const int yy = k / bw;
-      const int x = bx0 + (k - yy * bw), y = by0 + yy;
-      uint32_t dbits;
-      if (fragment(s, x, y, dbits)) {
-        const unsigned long long packed =
-            (static_cast<unsigned long long>(dbits) << 32) | static_cast<uint32_t>(f);
-        atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], packed);
-      }
+  for (int i0 = (tid & ~(kWave - 1)); i0 < nbig; i0 += kBlock) {
+    const int i = i0 + (tid & (kWave - 1));
+    int f = 0;
+    bool valid = false;
+    TriSetup<T> s = {};
+    if (i < nbig) {
+      f = big_n[i];
+      const uint2 r = range_n[f];
+      const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = r.y >> 16;
+      if (tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1)
+        valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
     }
+    if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf);
   }
   __syncthreads();
 
@@ -388,22 +521,21 @@ int rasterize_impl(
 
   if (hipMemsetAsync(ws, 0, L.zero_bytes, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
   const int64_t total = N * F;
+  const dim3 tri_grid(static_cast<unsigned>(ceil_div(F > 0 ? F : 1, kBlock)), static_cast<unsigned>(N));
   if (total > 0) {
-    const unsigned blocks = static_cast<unsigned>(ceil_div(total, kBlock));
     hipLaunchKernelGGL(
-        bin_count_kernel<T>, dim3(blocks), dim3(kBlock), 0, stream, v, vi, total, (int)F, V, vi_sN,
-        (int)H, (int)W, L.tile_shift, L.tiles_x, (int)L.tiles_per_view, tile_count, big_count,
-        big_list, tri_range);
+        bin_count_kernel<T>, tri_grid, dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN, (int)H,
+        (int)W, L.tile_shift, L.tiles_x, (int)L.tiles_per_view, tile_count, big_count, big_list,
+        tri_range);
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   hipLaunchKernelGGL(
       bin_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_count, tile_offset, (int)L.num_tiles);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   if (total > 0) {
-    const unsigned blocks = static_cast<unsigned>(ceil_div(total, kBlock));
     hipLaunchKernelGGL(
-        bin_fill_kernel, dim3(blocks), dim3(kBlock), 0, stream, tri_range, total, (int)F,
-        L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_cursor, pairs);
+        bin_fill_kernel, tri_grid, dim3(kBlock), 0, stream, tri_range, (int)F, L.tiles_x,
+        (int)L.tiles_per_view, tile_offset, tile_cursor, pairs);
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   const unsigned tiles = static_cast<unsigned>(L.num_tiles);
@@ -441,7 +573,7 @@ extern "C" int drtk_amd_rasterize(
   if (N < 0 || V < 0 || F < 0 || H <= 0 || W <= 0) return DRTK_ERR_INVALID_ARGUMENT; // :464-468
   if (V >= 0x10000000LL) return DRTK_ERR_TOO_MANY_VERTICES;                           // :459-462
   if (wireframe) return DRTK_ERR_UNSUPPORTED;
-  if (H > 65535LL * 32 || W > 65535LL * 32 || N * F >= (int64_t(1) << 31) / kMaxSmallTiles ||
+  if (N > 65535 || H > 65535LL * 32 || W > 65535LL * 32 || N * F >= (int64_t(1) << 31) / kMaxSmallTiles ||
       N * H * W >= (int64_t(1) << 40))
     return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W > 0 && (!depth_img || !index_img || !workspace)) return DRTK_ERR_INVALID_ARGUMENT;

@@ -10,7 +10,10 @@ def project_pinhole(v_cam: th.Tensor, focal: th.Tensor, princpt: th.Tensor) -> t
     z = v_cam[:, :, 2:3]
     z = th.where(z < 0, z.clamp(max=-1e-8), z.clamp(min=1e-8))
     v_proj = v_cam[:, :, 0:2] / z
-    return (focal[:, None] @ v_proj[..., None])[..., 0] + princpt[:, None]
+    # focal @ v_proj per vertex, written as ONE [N,V,2]x[N,2,2] batched product: the reference's
+    # per-vertex `focal[:, None] @ v_proj[..., None]` launches a degenerate N*V-batch GEMM that
+    # takes milliseconds on ROCm.
+    return th.bmm(v_proj, focal.transpose(1, 2)) + princpt[:, None]
 
 
 def transform_with_v_cam(
@@ -32,7 +35,8 @@ def transform_with_v_cam(
     if focal is None:
         focal = K[:, :2, :2]
         princpt = K[:, :2, 2]
-    v_cam = (camrot[:, None] @ (v - campos[:, None])[..., None])[..., 0]
+    # camrot @ (v - campos) per vertex as one [N,V,3]x[N,3,3] batched product (see project_pinhole)
+    v_cam = th.bmm(v - campos[:, None], camrot.transpose(1, 2))
     v_pix = project_pinhole(v_cam, focal, princpt)
     return th.cat((v_pix, v_cam[:, :, 2:3]), dim=-1), v_cam
 
