@@ -114,105 +114,147 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
   }
 }
 
-// Backward.  lane = pixel; 64 consecutive pixels of one view per wave.
+// Backward.  A workgroup owns a 64 x 16 pixel tile: 4 passes of 4 rows, wave = 64 pixels of a row,
+// lane = pixel in phase 1.  Channels are processed in chunks of 16 (outer loop).
 template <typename T, bool HAS_VERT, bool HAS_BARY, int CV>
 __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
-    int64_t vi_sN, int H, int W, T* __restrict__ attr_grad, T* __restrict__ bary_grad) {
+    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad) {
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
+  constexpr int kPasses = kTileRows / kWaves;
   __shared__ T s_g[HAS_VERT ? kWaves : 1][HAS_VERT ? kChunk * kRunPad : 1];
   __shared__ T s_b[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
-  __shared__ int32_t s_vidx[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
+  __shared__ int32_t s_vid[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
+  __shared__ int32_t s_slot[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
+  __shared__ int32_t t_keys[HAS_VERT ? kTableSlots : 1];
+  __shared__ T t_vals[HAS_VERT ? kTableSlots * kChunk : 1];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
   const int wave = threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t pix = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-  const bool in_range = pix < HW;
+  const int x = txi * kWave + lane;
   const T* attrs_n = attrs + int64_t(n) * V * C;
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
-  const T* go_p = grad_out + int64_t(n) * C * HW + pix;
+  T* attr_grad_n = HAS_VERT ? attr_grad + int64_t(n) * V * C : nullptr;
 
-  const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
-  const bool covered = tr != -1;
-  int32_t vid0 = 0, vid1 = 0, vid2 = 0;
-  if (covered) {
-    const int32_t* face = vi_n + int64_t(tr) * 3;
-    vid0 = face[0], vid1 = face[1], vid2 = face[2];
-  }
-  unsigned long long heads = 0, cov = 0;
-  if constexpr (HAS_VERT) {
-    T B0 = T(0), B1 = T(0), B2 = T(0);
-    if (covered) {
-      const T* bp = bary_img + int64_t(n) * 3 * HW + pix;
-      B0 = bp[0], B1 = bp[HW], B2 = bp[2 * HW];
+  if constexpr (HAS_VERT) table_init(t_keys);
+
+  // per-pass pixel state kept in registers across channel chunks
+  int32_t tr[kPasses];
+  int32_t vid[kPasses][3];
+  int32_t slot[kPasses][3];
+  T bg[kPasses][3];
+#pragma unroll
+  for (int ps = 0; ps < kPasses; ++ps) {
+    const int y = tyi * kTileRows + ps * kWaves + wave;
+    const bool in_range = x < W && y < H;
+    tr[ps] = in_range ? index_img[int64_t(n) * HW + int64_t(y) * W + x] : -1;
+    vid[ps][0] = vid[ps][1] = vid[ps][2] = 0;
+    if (tr[ps] != -1) {
+      const int32_t* face = vi_n + int64_t(tr[ps]) * 3;
+      vid[ps][0] = face[0], vid[ps][1] = face[1], vid[ps][2] = face[2];
     }
-    s_b[wave][0 * kRunPad + lane] = B0;
-    s_b[wave][1 * kRunPad + lane] = B1;
-    s_b[wave][2 * kRunPad + lane] = B2;
-    s_vidx[wave][0 * kRunPad + lane] = vid0;
-    s_vidx[wave][1 * kRunPad + lane] = vid1;
-    s_vidx[wave][2 * kRunPad + lane] = vid2;
-    run_masks(tr, heads, cov);
+    bg[ps][0] = bg[ps][1] = bg[ps][2] = T(0);
   }
-  const T* a0 = attrs_n + int64_t(vid0) * C;
-  const T* a1 = attrs_n + int64_t(vid1) * C;
-  const T* a2 = attrs_n + int64_t(vid2) * C;
+  if constexpr (HAS_VERT) {
+    __syncthreads(); // keys initialised
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) slot[ps][k] = (tr[ps] != -1) ? table_slot(t_keys, vid[ps][k]) : -1;
+  }
 
-  T bg0 = T(0), bg1 = T(0), bg2 = T(0);
   for (int c0 = 0; c0 < C; c0 += kChunk) {
     const int CC = min(kChunk, C - c0);
-    if (covered) {
-      for (int cb = 0; cb < CC; cb += CV) {
-        T g[CV];
-#pragma unroll
-        for (int cc = 0; cc < CV; ++cc) g[cc] = go_p[int64_t(c0 + cb + cc) * HW];
-        if constexpr (HAS_VERT) {
-#pragma unroll
-          for (int cc = 0; cc < CV; ++cc) s_g[wave][(cb + cc) * kRunPad + lane] = g[cc];
-        }
-        if constexpr (HAS_BARY) {
-          T u0[CV], u1[CV], u2[CV];
-          if constexpr (CV == 4) {
-            const V4 q0 = *reinterpret_cast<const V4*>(a0 + c0 + cb);
-            const V4 q1 = *reinterpret_cast<const V4*>(a1 + c0 + cb);
-            const V4 q2 = *reinterpret_cast<const V4*>(a2 + c0 + cb);
-            u0[0] = q0.x, u0[1] = q0.y, u0[2] = q0.z, u0[3] = q0.w;
-            u1[0] = q1.x, u1[1] = q1.y, u1[2] = q1.z, u1[3] = q1.w;
-            u2[0] = q2.x, u2[1] = q2.y, u2[2] = q2.z, u2[3] = q2.w;
-          } else {
-            u0[0] = a0[c0 + cb], u1[0] = a1[c0 + cb], u2[0] = a2[c0 + cb];
-          }
-#pragma unroll
-          for (int cc = 0; cc < CV; ++cc) { // interpolate_kernel.cu:238-246 accumulation order
-            bg0 += g[cc] * u0[cc];
-            bg1 += g[cc] * u1[cc];
-            bg2 += g[cc] * u2[cc];
-          }
-        }
-      }
-    }
     if constexpr (HAS_VERT) {
-      __syncthreads();
-      if (cov != 0) {
-        const T* sg = s_g[wave];
-        const T* sb = s_b[wave];
-        scatter_runs<T>(
-            heads, cov, s_vidx[wave], 3 * CC, CC, attr_grad + int64_t(n) * V * C, C, c0,
-            [sg, sb](int k, int c, int p) { return sg[c * kRunPad + p] * sb[k * kRunPad + p]; });
-      }
+      __syncthreads(); // previous chunk flushed
+      for (int i = threadIdx.x; i < kTableSlots * kChunk; i += kBlock) t_vals[i] = T(0);
       __syncthreads();
     }
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+      const int y = tyi * kTileRows + ps * kWaves + wave;
+      const int64_t pix = int64_t(y) * W + x;
+      const bool covered = tr[ps] != -1;
+      unsigned long long heads = 0, cov = 0;
+      if constexpr (HAS_VERT) {
+        T B0 = T(0), B1 = T(0), B2 = T(0);
+        if (covered) {
+          const T* bp = bary_img + int64_t(n) * 3 * HW + pix;
+          B0 = bp[0], B1 = bp[HW], B2 = bp[2 * HW];
+        }
+        s_b[wave][0 * kRunPad + lane] = B0;
+        s_b[wave][1 * kRunPad + lane] = B1;
+        s_b[wave][2 * kRunPad + lane] = B2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          s_vid[wave][k * kRunPad + lane] = vid[ps][k];
+          s_slot[wave][k * kRunPad + lane] = slot[ps][k];
+        }
+        run_masks(tr[ps], heads, cov);
+      }
+      if (covered) {
+        const T* go_p = grad_out + int64_t(n) * C * HW + pix;
+        const T* a0 = attrs_n + int64_t(vid[ps][0]) * C;
+        const T* a1 = attrs_n + int64_t(vid[ps][1]) * C;
+        const T* a2 = attrs_n + int64_t(vid[ps][2]) * C;
+        for (int cb = 0; cb < CC; cb += CV) {
+          T g[CV];
+#pragma unroll
+          for (int cc = 0; cc < CV; ++cc) g[cc] = go_p[int64_t(c0 + cb + cc) * HW];
+          if constexpr (HAS_VERT) {
+#pragma unroll
+            for (int cc = 0; cc < CV; ++cc) s_g[wave][(cb + cc) * kRunPad + lane] = g[cc];
+          }
+          if constexpr (HAS_BARY) {
+            T u0[CV], u1[CV], u2[CV];
+            if constexpr (CV == 4) {
+              const V4 q0 = *reinterpret_cast<const V4*>(a0 + c0 + cb);
+              const V4 q1 = *reinterpret_cast<const V4*>(a1 + c0 + cb);
+              const V4 q2 = *reinterpret_cast<const V4*>(a2 + c0 + cb);
+              u0[0] = q0.x, u0[1] = q0.y, u0[2] = q0.z, u0[3] = q0.w;
+              u1[0] = q1.x, u1[1] = q1.y, u1[2] = q1.z, u1[3] = q1.w;
+              u2[0] = q2.x, u2[1] = q2.y, u2[2] = q2.z, u2[3] = q2.w;
+            } else {
+              u0[0] = a0[c0 + cb], u1[0] = a1[c0 + cb], u2[0] = a2[c0 + cb];
+            }
+#pragma unroll
+            for (int cc = 0; cc < CV; ++cc) { // interpolate_kernel.cu:238-246 accumulation order
+              bg[ps][0] += g[cc] * u0[cc];
+              bg[ps][1] += g[cc] * u1[cc];
+              bg[ps][2] += g[cc] * u2[cc];
+            }
+          }
+        }
+      }
+      if constexpr (HAS_VERT) {
+        __syncthreads();
+        if (cov != 0) {
+          const T* sg = s_g[wave];
+          const T* sb = s_b[wave];
+          scatter_runs<T>(
+              heads, cov, s_slot[wave], s_vid[wave], 3 * CC, CC, t_vals, kChunk, attr_grad_n, C, c0,
+              [sg, sb](int k, int c, int p) { return sg[c * kRunPad + p] * sb[k * kRunPad + p]; });
+        }
+        __syncthreads();
+      }
+    }
+    if constexpr (HAS_VERT) table_flush<T>(t_keys, t_vals, kChunk, CC, attr_grad_n, C, c0);
   }
   if constexpr (HAS_BARY) {
-    if (in_range) {
-      T* bgp = bary_grad + int64_t(n) * 3 * HW + pix;
-      bgp[0] = bg0;
-      bgp[HW] = bg1;
-      bgp[2 * HW] = bg2;
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+      const int y = tyi * kTileRows + ps * kWaves + wave;
+      if (x < W && y < H) {
+        T* bgp = bary_grad + int64_t(n) * 3 * HW + int64_t(y) * W + x;
+        bgp[0] = bg[ps][0];
+        bgp[HW] = bg[ps][1];
+        bgp[2 * HW] = bg[ps][2];
+      }
     }
   }
 }
@@ -261,12 +303,13 @@ int interpolate_backward_impl(
     return DRTK_OK;
   }
   const bool cvec = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(attrs) % (4 * sizeof(T)) == 0);
-  const dim3 grid(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
+  const int tiles_x = static_cast<int>(ceil_div(W, kWave)), tiles_y = static_cast<int>(ceil_div(H, kTileRows));
+  const dim3 grid(static_cast<unsigned>(int64_t(tiles_x) * tiles_y), static_cast<unsigned>(N));
   const dim3 block(kBlock);
 #define LAUNCH(HV, HB, CV)                                                                      \
   hipLaunchKernelGGL(                                                                           \
       (interpolate_backward_kernel<T, HV, HB, CV>), grid, block, 0, stream, grad_out, attrs, vi, \
-      index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, attr_grad, bary_grad)
+      index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad)
   if (attr_grad && bary_grad) {
     if (cvec) LAUNCH(true, true, 4); else LAUNCH(true, true, 1);
   } else if (attr_grad) {

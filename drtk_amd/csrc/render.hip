@@ -132,95 +132,110 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
   }
 }
 
-// Backward: lane = pixel (64 consecutive pixels of one view per wave).
+// Backward: a workgroup owns a 64 x 16 pixel tile (4 passes of 4 rows, wave = 64 pixels of a row).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ grad_depth_img, const T* __restrict__ grad_bary_img, int64_t V,
-    int64_t vi_sN, int H, int W, T* __restrict__ grad_v) {
+    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ grad_v) {
   constexpr int kWaves = kBlock / kWave;
   __shared__ T s_val[kWaves][9 * kRunPad];
-  __shared__ int32_t s_vidx[kWaves][3 * kRunPad];
+  __shared__ int32_t s_vid[kWaves][3 * kRunPad];
+  __shared__ int32_t s_slot[kWaves][3 * kRunPad];
+  __shared__ int32_t t_keys[kTableSlots];
+  __shared__ T t_vals[kTableSlots * 4];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
   const int wave = threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t pix = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-  const bool in_range = pix < HW;
+  const int x = txi * kWave + lane;
   const T* v_n = v + int64_t(n) * V * 3;
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  T* grad_v_n = grad_v + int64_t(n) * V * 3;
 
-  const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
-  T g[9];
-#pragma unroll
-  for (int j = 0; j < 9; ++j) g[j] = T(0);
-  int32_t vid[3] = {0, 0, 0};
-
-  if (tr != -1) {
-    const int y = static_cast<int>(pix / W);
-    const int x = static_cast<int>(pix - int64_t(y) * W);
-    RenderPix<T> r;
-    render_pix<T>(v_n, vi_n + int64_t(tr) * 3, x, y, r);
-    vid[0] = r.vi0;
-    vid[1] = r.vi1;
-    vid[2] = r.vi2;
-    const bool den_clamped = r.den != r.den_raw;
-    const bool dinv_clamped = r.depth_inverse_eps != r.depth_inverse;
-
-    const T* gb = grad_bary_img + int64_t(n) * 3 * HW + pix;
-    const T dL_B0 = gb[0], dL_B1 = gb[HW], dL_B2 = gb[2 * HW];
-    // render_kernel.cu:225 : *grad_depth + dot(dL_bary_3D * d_inv, bary)
-    const T dL_depth = grad_depth_img[int64_t(n) * HW + pix] + dL_B0 * r.dinv0 * r.b0 +
-        dL_B1 * r.dinv1 * r.b1 + dL_B2 * r.dinv2 * r.b2;
-    const T dL_dinv_s =
-        dinv_clamped ? T(0) : (-dL_depth / (r.depth_inverse * r.depth_inverse));
-
-    const T dL_dinv0 = dL_B0 * r.b0 * r.depth + dL_dinv_s * r.b0;
-    const T dL_dinv1 = dL_B1 * r.b1 * r.depth + dL_dinv_s * r.b1;
-    const T dL_dinv2 = dL_B2 * r.b2 * r.depth + dL_dinv_s * r.b2;
-    g[2] = r.z0c ? T(0) : (-dL_dinv0 / (r.z0e * r.z0e));
-    g[5] = r.z1c ? T(0) : (-dL_dinv1 / (r.z1e * r.z1e));
-    g[8] = r.z2c ? T(0) : (-dL_dinv2 / (r.z2e * r.z2e));
-
-    const T dL_b0 = dL_B0 * r.dinv0 * r.depth + dL_dinv_s * r.dinv0;
-    const T dL_b1 = dL_B1 * r.dinv1 * r.depth + dL_dinv_s * r.dinv1;
-    const T dL_b2 = dL_B2 * r.dinv2 * r.depth + dL_dinv_s * r.dinv2;
-    const T dL_b12x = -dL_b0 + dL_b1;
-    const T dL_b12y = -dL_b0 + dL_b2;
-    const T prex = dL_b12x / r.den;
-    const T prey = dL_b12y / r.den;
-    const T dL_den = den_clamped ? T(0) : -(prex * r.b1 + prey * r.b2);
-
-    const T dL_vp0x = prex * r.v02y - prey * r.v01y;
-    const T dL_vp0y = -prex * r.v02x + prey * r.v01x;
-    const T dL_v02x = -prex * r.vp0y - dL_den * r.v01y;
-    const T dL_v02y = prex * r.vp0x + dL_den * r.v01x;
-    const T dL_v01x = prey * r.vp0y + dL_den * r.v02y;
-    const T dL_v01y = -prey * r.vp0x - dL_den * r.v02x;
-
-    g[0] = -dL_v02x - dL_v01x - dL_vp0x;
-    g[1] = -dL_v02y - dL_v01y - dL_vp0y;
-    g[3] = dL_v01x;
-    g[4] = dL_v01y;
-    g[6] = dL_v02x;
-    g[7] = dL_v02y;
-  }
-
-#pragma unroll
-  for (int j = 0; j < 9; ++j) s_val[wave][j * kRunPad + lane] = g[j];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) s_vidx[wave][k * kRunPad + lane] = vid[k];
-
-  unsigned long long heads, cov;
-  run_masks(tr, heads, cov);
+  table_init(t_keys);
+  for (int i = threadIdx.x; i < kTableSlots * 4; i += kBlock) t_vals[i] = T(0);
   __syncthreads();
-  if (cov == 0) return;
 
-  const T* sv = s_val[wave];
-  scatter_runs<T>(
-      heads, cov, s_vidx[wave], 9, 3, grad_v + int64_t(n) * V * 3, 3, 0,
-      [sv](int k, int c, int p) { return sv[(k * 3 + c) * kRunPad + p]; });
+  for (int pass = 0; pass < kTileRows / kWaves; ++pass) {
+    const int y = tyi * kTileRows + pass * kWaves + wave;
+    const bool in_range = x < W && y < H;
+    const int64_t pix = int64_t(y) * W + x;
+    const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
+    T g[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) g[j] = T(0);
+    int32_t vid[3] = {0, 0, 0};
+
+    if (tr != -1) {
+      RenderPix<T> r;
+      render_pix<T>(v_n, vi_n + int64_t(tr) * 3, x, y, r);
+      vid[0] = r.vi0;
+      vid[1] = r.vi1;
+      vid[2] = r.vi2;
+      const bool den_clamped = r.den != r.den_raw;
+      const bool dinv_clamped = r.depth_inverse_eps != r.depth_inverse;
+
+      const T* gb = grad_bary_img + int64_t(n) * 3 * HW + pix;
+      const T dL_B0 = gb[0], dL_B1 = gb[HW], dL_B2 = gb[2 * HW];
+      // render_kernel.cu:225 : *grad_depth + dot(dL_bary_3D * d_inv, bary)
+      const T dL_depth = grad_depth_img[int64_t(n) * HW + pix] + dL_B0 * r.dinv0 * r.b0 +
+          dL_B1 * r.dinv1 * r.b1 + dL_B2 * r.dinv2 * r.b2;
+      const T dL_dinv_s =
+          dinv_clamped ? T(0) : (-dL_depth / (r.depth_inverse * r.depth_inverse));
+
+      const T dL_dinv0 = dL_B0 * r.b0 * r.depth + dL_dinv_s * r.b0;
+      const T dL_dinv1 = dL_B1 * r.b1 * r.depth + dL_dinv_s * r.b1;
+      const T dL_dinv2 = dL_B2 * r.b2 * r.depth + dL_dinv_s * r.b2;
+      g[2] = r.z0c ? T(0) : (-dL_dinv0 / (r.z0e * r.z0e));
+      g[5] = r.z1c ? T(0) : (-dL_dinv1 / (r.z1e * r.z1e));
+      g[8] = r.z2c ? T(0) : (-dL_dinv2 / (r.z2e * r.z2e));
+
+      const T dL_b0 = dL_B0 * r.dinv0 * r.depth + dL_dinv_s * r.dinv0;
+      const T dL_b1 = dL_B1 * r.dinv1 * r.depth + dL_dinv_s * r.dinv1;
+      const T dL_b2 = dL_B2 * r.dinv2 * r.depth + dL_dinv_s * r.dinv2;
+      const T dL_b12x = -dL_b0 + dL_b1;
+      const T dL_b12y = -dL_b0 + dL_b2;
+      const T prex = dL_b12x / r.den;
+      const T prey = dL_b12y / r.den;
+      const T dL_den = den_clamped ? T(0) : -(prex * r.b1 + prey * r.b2);
+
+      const T dL_vp0x = prex * r.v02y - prey * r.v01y;
+      const T dL_vp0y = -prex * r.v02x + prey * r.v01x;
+      const T dL_v02x = -prex * r.vp0y - dL_den * r.v01y;
+      const T dL_v02y = prex * r.vp0x + dL_den * r.v01x;
+      const T dL_v01x = prey * r.vp0y + dL_den * r.v02y;
+      const T dL_v01y = -prey * r.vp0x - dL_den * r.v02x;
+
+      g[0] = -dL_v02x - dL_v01x - dL_vp0x;
+      g[1] = -dL_v02y - dL_v01y - dL_vp0y;
+      g[3] = dL_v01x;
+      g[4] = dL_v01y;
+      g[6] = dL_v02x;
+      g[7] = dL_v02y;
+    }
+
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s_val[wave][j * kRunPad + lane] = g[j];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s_vid[wave][k * kRunPad + lane] = vid[k];
+      s_slot[wave][k * kRunPad + lane] = (tr != -1) ? table_slot(t_keys, vid[k]) : -1;
+    }
+    unsigned long long heads, cov;
+    run_masks(tr, heads, cov);
+    __syncthreads();
+    if (cov != 0) {
+      const T* sv = s_val[wave];
+      scatter_runs<T>(
+          heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals, 4, grad_v_n, 3, 0,
+          [sv](int k, int c, int p) { return sv[(k * 3 + c) * kRunPad + p]; });
+    }
+    __syncthreads();
+  }
+  table_flush<T>(t_keys, t_vals, 4, 3, grad_v_n, 3, 0);
 }
 
 template <typename T>
@@ -253,8 +268,9 @@ int render_backward_impl(
   }
   const int64_t HW = H * W;
   if (N * HW == 0) return DRTK_OK;
-  dim3 grid(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
-  hipLaunchKernelGGL((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, grad_v);
+  const int tiles_x = static_cast<int>(ceil_div(W, kWave)), tiles_y = static_cast<int>(ceil_div(H, kTileRows));
+  dim3 grid(static_cast<unsigned>(int64_t(tiles_x) * tiles_y), static_cast<unsigned>(N));
+  hipLaunchKernelGGL((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, tiles_x, grad_v);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }

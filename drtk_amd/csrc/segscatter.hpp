@@ -1,20 +1,23 @@
-// Wave-level segmented scatter-add used by the two vertex-gradient backward kernels
+// Two-level segmented scatter-add used by the vertex-gradient backward kernels
 // (render_backward: 9 values per pixel, interpolate_backward: 3*C values per pixel).
 //
 // Reference behaviour: one fastAtomicAdd per (pixel, corner, channel) (render_kernel.cu:233-278)
 // or, for interpolate, a per-channel cub::WarpReduce::TailSegmentedSum over runs of equal vertex
 // id in adjacent lanes followed by head-lane atomics, with a __syncthreads per channel
-// (interpolate_kernel.cu:249-281).
+// (interpolate_kernel.cu:249-281).  Measured on MI355X the global float atomics are what bounds
+// such a kernel (~10 G atomic requests/s, device scope), so the number of REQUESTS is what is
+// minimised here:
 //
-// CDNA4 mapping: a wave owns 64 consecutive pixels of one view.  Phase 1 (pixel-major, done by
-// the caller) leaves the per-pixel operands in LDS; the run structure -- where the triangle id
-// changes along the 64 pixels -- is a 64-bit ballot, i.e. wave-uniform SGPR state.  Phase 2
-// (this file) flips the wave to (corner, channel)-major: a lane owns one (k, c) pair and one
-// contiguous slice of the 64 pixels, sums each run of equal triangle id inside its slice in a
-// register and issues ONE atomic per run -- the CC lanes of a corner hit CC consecutive floats of
-// dst[n, vi_k, c_base:c_base+CC], i.e. one contiguous segment per corner per run.
-//   J = 3*CC pairs.  J <= 16: 4 pixel slices of 16 (lanes = 4 x 16);  J <= 32: 2 slices of 32;
-//   otherwise 1 slice of 64 pixels and ceil(J/64) rounds.
+//   level 1 (wave):  a wave owns 64 consecutive pixels of one image row.  Phase 1 (pixel-major,
+//     done by the caller) leaves the per-pixel operands in LDS; the run structure -- where the
+//     triangle id changes along the 64 pixels -- is a 64-bit ballot, i.e. wave-uniform SGPR state.
+//     Phase 2 flips the wave to (corner, channel)-major: a lane owns one (k, c) pair (and, for
+//     small channel counts, one slice of the pixels), and sums each run in a register.
+//   level 2 (workgroup): run sums go into a small LDS hash table keyed by VERTEX id that lives for
+//     the whole 64 x 16 pixel tile of the workgroup (ds_add_f32), so every vertex touched by the
+//     tile costs one global atomic per channel at the end -- one contiguous segment per vertex --
+//     instead of one per run.  Vertices that do not fit (table full) fall back to a direct
+//     global atomic, so any input is handled.
 #pragma once
 
 #include "common.hpp"
@@ -22,16 +25,48 @@
 namespace drtk_amd {
 
 constexpr int kRunPad = kWave + 1; // LDS row stride: +1 breaks the 32-bank alignment of rows
+constexpr int kTableSlots = 128;   // vertices per tile table (power of two)
+constexpr int kTileRows = 16;      // a workgroup (4 waves) covers 64 x 16 pixels in 4 passes of 4 rows
+constexpr int kTableProbes = 8;
+
+__device__ __forceinline__ void table_init(int32_t* keys) {
+  for (int i = threadIdx.x; i < kTableSlots; i += blockDim.x) keys[i] = -1;
+}
+
+// Slot of vertex `vid` in the tile table (inserting it if needed); -1 if the table is full along
+// its probe sequence.  Safe under concurrent calls from any lanes of the workgroup.
+__device__ __forceinline__ int table_slot(int32_t* keys, int32_t vid) {
+  uint32_t h = (static_cast<uint32_t>(vid) * 2654435761u) >> 25; // 7 bits
+  for (int probe = 0; probe < kTableProbes; ++probe) {
+    const int32_t cur = keys[h];
+    if (cur == vid) return static_cast<int>(h);
+    if (cur == -1) {
+      const int32_t old = atomicCAS(&keys[h], -1, vid);
+      if (old == -1 || old == vid) return static_cast<int>(h);
+    }
+    h = (h + 1) & (kTableSlots - 1);
+  }
+  return -1;
+}
 
 // heads  bit p set  <=>  pixel p starts a new run (p == 0 or triangle differs from pixel p-1)
 // cov    bit p set  <=>  pixel p is covered (index != -1); constant within a run
-// vidx   LDS [3][kRunPad] vertex ids of every pixel's triangle corners
-// pair j = k * CC + c  ->  dst_n[vidx[k] * C_total + c_base + c]
+// slot   LDS [3][kRunPad] table slot of every pixel's triangle corners (-1: use `vid` + global atomic)
+// vid    LDS [3][kRunPad] vertex ids of every pixel's triangle corners
+// pair j = k * CC + c  ->  table vals[slot * stride + c]   (or dst_n[vid * C_total + c_base + c])
 template <typename T, typename ValFn>
 __device__ __forceinline__ void scatter_runs(
-    unsigned long long heads, unsigned long long cov, const int32_t* vidx, int J, int CC,
-    T* __restrict__ dst_n, int C_total, int c_base, ValFn val) {
+    unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
+    int CC, T* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, ValFn val) {
   const int lane = lane_id();
+  auto flush = [&](int k, int c, int start, T acc) {
+    const int s = slot[k * kRunPad + start];
+    if (s >= 0) {
+      atomicAdd(&vals[s * stride + c], acc); // LDS
+    } else {
+      atomic_add_global(dst_n + int64_t(vid[k * kRunPad + start]) * C_total + c_base + c, acc);
+    }
+  };
   if (J > 32) {
     // one slice: run bounds are wave-uniform -> scalar loops, no exec-mask divergence
     for (int j0 = 0; j0 < J; j0 += kWave) {
@@ -48,7 +83,7 @@ __device__ __forceinline__ void scatter_runs(
         if (active) {
           T acc = T(0);
           for (int p = start; p < end; ++p) acc += val(k, c, p);
-          atomic_add_global(dst_n + int64_t(vidx[k * kRunPad + start]) * C_total + c_base + c, acc);
+          flush(k, c, start, acc);
         }
       }
     }
@@ -61,21 +96,33 @@ __device__ __forceinline__ void scatter_runs(
   const bool active = j < J;
   const int k = active ? j / CC : 0;
   const int c = active ? j - k * CC : 0;
-  T* const out = dst_n + c_base + c;
   T acc = T(0);
   int run_start = p0;
   for (int i = 0; i < span; ++i) { // uniform trip count; p differs per slice
     const int p = p0 + i;
     if (i > 0 && ((heads >> p) & 1ull)) {
-      if (active && ((cov >> run_start) & 1ull))
-        atomic_add_global(out + int64_t(vidx[k * kRunPad + run_start]) * C_total, acc);
+      if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
       acc = T(0);
       run_start = p;
     }
     if (active && ((cov >> p) & 1ull)) acc += val(k, c, p);
   }
-  if (active && ((cov >> run_start) & 1ull))
-    atomic_add_global(out + int64_t(vidx[k * kRunPad + run_start]) * C_total, acc);
+  if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+}
+
+// Workgroup-wide: add every occupied table entry to dst_n[key * C_total + c_base + c], c < CC.
+template <typename T>
+__device__ __forceinline__ void table_flush(
+    const int32_t* keys, const T* vals, int stride, int CC, T* __restrict__ dst_n, int C_total,
+    int c_base) {
+  for (int e = threadIdx.x; e < kTableSlots * CC; e += blockDim.x) {
+    const int s = e / CC, c = e - s * CC;
+    const int32_t key = keys[s];
+    if (key >= 0) {
+      const T x = vals[s * stride + c];
+      if (x != T(0)) atomic_add_global(dst_n + int64_t(key) * C_total + c_base + c, x);
+    }
+  }
 }
 
 // Run-head / coverage ballots of a wave whose lane l holds triangle id `tr` (-1 = background or
