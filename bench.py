@@ -178,9 +178,11 @@ def main():
         index_img = drtk_amd.rasterize(v_pix, vi, H, W)
         depth_img, bary_img = drtk_amd.render(v_pix, vi, index_img)
         img = drtk_amd.interpolate(a, vi, index_img, bary_img)
-        img = img * (index_img != -1)[:, None]
+        # user-side shading and loss (plain PyTorch, timed inside the step): mask the background,
+        # loss = mean(img^2) + mean(depth), written with the cheapest equivalent torch ops
+        img = th.where((index_img != -1)[:, None], img, 0.0)
         img = drtk_amd.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
-        loss = (img * img).mean() + depth_img.mean()
+        loss = th.linalg.vector_norm(img).square() / img.numel() + depth_img.mean()
         loss.backward()
         reducer.all_reduce()
         v_world.grad = None

@@ -141,31 +141,9 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
   T* attr_grad_n = HAS_VERT ? attr_grad + int64_t(n) * V * C : nullptr;
 
-  if constexpr (HAS_VERT) table_init(t_keys);
-
-  // per-pass pixel state kept in registers across channel chunks
-  int32_t tr[kPasses];
-  int32_t vid[kPasses][3];
-  int32_t slot[kPasses][3];
-  T bg[kPasses][3];
-#pragma unroll
-  for (int ps = 0; ps < kPasses; ++ps) {
-    const int y = tyi * kTileRows + ps * kWaves + wave;
-    const bool in_range = x < W && y < H;
-    tr[ps] = in_range ? index_img[int64_t(n) * HW + int64_t(y) * W + x] : -1;
-    vid[ps][0] = vid[ps][1] = vid[ps][2] = 0;
-    if (tr[ps] != -1) {
-      const int32_t* face = vi_n + int64_t(tr[ps]) * 3;
-      vid[ps][0] = face[0], vid[ps][1] = face[1], vid[ps][2] = face[2];
-    }
-    bg[ps][0] = bg[ps][1] = bg[ps][2] = T(0);
-  }
   if constexpr (HAS_VERT) {
-    __syncthreads(); // keys initialised
-#pragma unroll
-    for (int ps = 0; ps < kPasses; ++ps)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) slot[ps][k] = (tr[ps] != -1) ? table_slot(t_keys, vid[ps][k]) : -1;
+    table_init(t_keys);
+    __syncthreads();
   }
 
   for (int c0 = 0; c0 < C; c0 += kChunk) {
@@ -175,11 +153,18 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
       for (int i = threadIdx.x; i < kTableSlots * kChunk; i += kBlock) t_vals[i] = T(0);
       __syncthreads();
     }
-#pragma unroll
+#pragma unroll 1
     for (int ps = 0; ps < kPasses; ++ps) {
       const int y = tyi * kTileRows + ps * kWaves + wave;
+      const bool in_range = x < W && y < H;
       const int64_t pix = int64_t(y) * W + x;
-      const bool covered = tr[ps] != -1;
+      const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
+      const bool covered = tr != -1;
+      int32_t vid0 = 0, vid1 = 0, vid2 = 0;
+      if (covered) {
+        const int32_t* face = vi_n + int64_t(tr) * 3;
+        vid0 = face[0], vid1 = face[1], vid2 = face[2];
+      }
       unsigned long long heads = 0, cov = 0;
       if constexpr (HAS_VERT) {
         T B0 = T(0), B1 = T(0), B2 = T(0);
@@ -190,18 +175,20 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         s_b[wave][0 * kRunPad + lane] = B0;
         s_b[wave][1 * kRunPad + lane] = B1;
         s_b[wave][2 * kRunPad + lane] = B2;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          s_vid[wave][k * kRunPad + lane] = vid[ps][k];
-          s_slot[wave][k * kRunPad + lane] = slot[ps][k];
-        }
-        run_masks(tr[ps], heads, cov);
+        s_vid[wave][0 * kRunPad + lane] = vid0;
+        s_vid[wave][1 * kRunPad + lane] = vid1;
+        s_vid[wave][2 * kRunPad + lane] = vid2;
+        s_slot[wave][0 * kRunPad + lane] = covered ? table_slot(t_keys, vid0) : -1;
+        s_slot[wave][1 * kRunPad + lane] = covered ? table_slot(t_keys, vid1) : -1;
+        s_slot[wave][2 * kRunPad + lane] = covered ? table_slot(t_keys, vid2) : -1;
+        run_masks(tr, heads, cov);
       }
+      T bg0 = T(0), bg1 = T(0), bg2 = T(0);
       if (covered) {
         const T* go_p = grad_out + int64_t(n) * C * HW + pix;
-        const T* a0 = attrs_n + int64_t(vid[ps][0]) * C;
-        const T* a1 = attrs_n + int64_t(vid[ps][1]) * C;
-        const T* a2 = attrs_n + int64_t(vid[ps][2]) * C;
+        const T* a0 = attrs_n + int64_t(vid0) * C;
+        const T* a1 = attrs_n + int64_t(vid1) * C;
+        const T* a2 = attrs_n + int64_t(vid2) * C;
         for (int cb = 0; cb < CC; cb += CV) {
           T g[CV];
 #pragma unroll
@@ -224,15 +211,25 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
             }
 #pragma unroll
             for (int cc = 0; cc < CV; ++cc) { // interpolate_kernel.cu:238-246 accumulation order
-              bg[ps][0] += g[cc] * u0[cc];
-              bg[ps][1] += g[cc] * u1[cc];
-              bg[ps][2] += g[cc] * u2[cc];
+              bg0 += g[cc] * u0[cc];
+              bg1 += g[cc] * u1[cc];
+              bg2 += g[cc] * u2[cc];
             }
           }
         }
       }
+      if constexpr (HAS_BARY) {
+        if (in_range) { // channel chunks accumulate in ascending order, like the reference's loop
+          T* bgp = bary_grad + int64_t(n) * 3 * HW + pix;
+          if (c0 == 0) {
+            bgp[0] = bg0, bgp[HW] = bg1, bgp[2 * HW] = bg2;
+          } else if (covered) {
+            bgp[0] += bg0, bgp[HW] += bg1, bgp[2 * HW] += bg2;
+          }
+        }
+      }
       if constexpr (HAS_VERT) {
-        __syncthreads();
+        wave_lds_sync();
         if (cov != 0) {
           const T* sg = s_g[wave];
           const T* sb = s_b[wave];
@@ -240,21 +237,12 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
               heads, cov, s_slot[wave], s_vid[wave], 3 * CC, CC, t_vals, kChunk, attr_grad_n, C, c0,
               [sg, sb](int k, int c, int p) { return sg[c * kRunPad + p] * sb[k * kRunPad + p]; });
         }
-        __syncthreads();
+        wave_lds_sync();
       }
     }
-    if constexpr (HAS_VERT) table_flush<T>(t_keys, t_vals, kChunk, CC, attr_grad_n, C, c0);
-  }
-  if constexpr (HAS_BARY) {
-#pragma unroll
-    for (int ps = 0; ps < kPasses; ++ps) {
-      const int y = tyi * kTileRows + ps * kWaves + wave;
-      if (x < W && y < H) {
-        T* bgp = bary_grad + int64_t(n) * 3 * HW + int64_t(y) * W + x;
-        bgp[0] = bg[ps][0];
-        bgp[HW] = bg[ps][1];
-        bgp[2 * HW] = bg[ps][2];
-      }
+    if constexpr (HAS_VERT) {
+      __syncthreads();
+      table_flush<T>(t_keys, t_vals, kChunk, CC, attr_grad_n, C, c0);
     }
   }
 }

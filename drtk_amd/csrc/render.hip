@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   for (int i = threadIdx.x; i < kTableSlots * 4; i += kBlock) t_vals[i] = T(0);
   __syncthreads();
 
+#pragma unroll 1
   for (int pass = 0; pass < kTileRows / kWaves; ++pass) {
     const int y = tyi * kTileRows + pass * kWaves + wave;
     const bool in_range = x < W && y < H;
@@ -226,15 +227,16 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     }
     unsigned long long heads, cov;
     run_masks(tr, heads, cov);
-    __syncthreads();
+    wave_lds_sync();
     if (cov != 0) {
       const T* sv = s_val[wave];
       scatter_runs<T>(
           heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals, 4, grad_v_n, 3, 0,
           [sv](int k, int c, int p) { return sv[(k * 3 + c) * kRunPad + p]; });
     }
-    __syncthreads();
+    wave_lds_sync();
   }
+  __syncthreads();
   table_flush<T>(t_keys, t_vals, 4, 3, grad_v_n, 3, 0);
 }
 

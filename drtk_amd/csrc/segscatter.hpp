@@ -29,6 +29,13 @@ constexpr int kTableSlots = 128;   // vertices per tile table (power of two)
 constexpr int kTileRows = 16;      // a workgroup (4 waves) covers 64 x 16 pixels in 4 passes of 4 rows
 constexpr int kTableProbes = 8;
 
+// Orders this wave's LDS writes before its later LDS reads by other lanes (wave-private staging
+// areas need no workgroup barrier: a wave's DS operations execute in order).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void table_init(int32_t* keys) {
   for (int i = threadIdx.x; i < kTableSlots; i += blockDim.x) keys[i] = -1;
 }
