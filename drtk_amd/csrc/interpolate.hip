@@ -124,8 +124,8 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPasses = kTileRows / kWaves;
-  __shared__ T s_g[HAS_VERT ? kWaves : 1][HAS_VERT ? kChunk * kRunPad : 1];
-  __shared__ T s_b[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
+  __shared__ __attribute__((aligned(16))) T s_g[HAS_VERT ? kWaves : 1][HAS_VERT ? kChunk * kRunPad : 4];
+  __shared__ __attribute__((aligned(16))) T s_b[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 4];
   __shared__ int32_t s_vid[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
   __shared__ int32_t s_slot[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
   __shared__ int32_t t_keys[HAS_VERT ? kTableSlots : 1];
@@ -153,18 +153,28 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
       for (int i = threadIdx.x; i < kTableSlots * kChunk; i += kBlock) t_vals[i] = T(0);
       __syncthreads();
     }
+    // software pipeline over the 4 row passes: the index of pass p+1 is requested at the top of
+    // pass p and its triangle's vertex ids right before phase 2, so both dependent gathers fly
+    // under the current pass instead of in front of the next one.
+    auto load_tr = [&](int ps) -> int32_t {
+      const int yy = tyi * kTileRows + ps * kWaves + wave;
+      return (x < W && yy < H) ? index_img[int64_t(n) * HW + int64_t(yy) * W + x] : -1;
+    };
+    int32_t tr_next = load_tr(0);
+    int32_t vn0 = 0, vn1 = 0, vn2 = 0;
+    if (tr_next != -1) {
+      const int32_t* face = vi_n + int64_t(tr_next) * 3;
+      vn0 = face[0], vn1 = face[1], vn2 = face[2];
+    }
 #pragma unroll 1
     for (int ps = 0; ps < kPasses; ++ps) {
       const int y = tyi * kTileRows + ps * kWaves + wave;
       const bool in_range = x < W && y < H;
       const int64_t pix = int64_t(y) * W + x;
-      const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
+      const int32_t tr = tr_next;
       const bool covered = tr != -1;
-      int32_t vid0 = 0, vid1 = 0, vid2 = 0;
-      if (covered) {
-        const int32_t* face = vi_n + int64_t(tr) * 3;
-        vid0 = face[0], vid1 = face[1], vid2 = face[2];
-      }
+      const int32_t vid0 = vn0, vid1 = vn1, vid2 = vn2;
+      if (ps + 1 < kPasses) tr_next = load_tr(ps + 1);
       unsigned long long heads = 0, cov = 0;
       if constexpr (HAS_VERT) {
         T B0 = T(0), B1 = T(0), B2 = T(0);
@@ -184,6 +194,11 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         run_masks(tr, heads, cov);
       }
       T bg0 = T(0), bg1 = T(0), bg2 = T(0);
+      if constexpr (HAS_VERT) {
+        if (!covered) { // phase 2 sums whole runs of the staging rows: uncovered pixels must read as 0
+          for (int cb = 0; cb < CC; ++cb) s_g[wave][cb * kRunPad + lane] = T(0);
+        }
+      }
       if (covered) {
         const T* go_p = grad_out + int64_t(n) * C * HW + pix;
         const T* a0 = attrs_n + int64_t(vid0) * C;
@@ -228,6 +243,13 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
           }
         }
       }
+      if (ps + 1 < kPasses) {
+        vn0 = vn1 = vn2 = 0;
+        if (tr_next != -1) {
+          const int32_t* face = vi_n + int64_t(tr_next) * 3;
+          vn0 = face[0], vn1 = face[1], vn2 = face[2];
+        }
+      }
       if constexpr (HAS_VERT) {
         wave_lds_sync();
         if (cov != 0) {
@@ -235,7 +257,11 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
           const T* sb = s_b[wave];
           scatter_runs<T>(
               heads, cov, s_slot[wave], s_vid[wave], 3 * CC, CC, t_vals, kChunk, attr_grad_n, C, c0,
-              [sg, sb](int k, int c, int p) { return sg[c * kRunPad + p] * sb[k * kRunPad + p]; });
+              [sg, sb](int k, int c, int g4, T* x) {
+                const V4 a = *reinterpret_cast<const V4*>(sg + c * kRunPad + 4 * g4);
+                const V4 b = *reinterpret_cast<const V4*>(sb + k * kRunPad + 4 * g4);
+                x[0] = a.x * b.x, x[1] = a.y * b.y, x[2] = a.z * b.z, x[3] = a.w * b.w;
+              });
         }
         wave_lds_sync();
       }

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const T* __restrict__ grad_depth_img, const T* __restrict__ grad_bary_img, int64_t V,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ grad_v) {
   constexpr int kWaves = kBlock / kWave;
-  __shared__ T s_val[kWaves][9 * kRunPad];
+  __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
   __shared__ int32_t s_vid[kWaves][3 * kRunPad];
   __shared__ int32_t s_slot[kWaves][3 * kRunPad];
   __shared__ int32_t t_keys[kTableSlots];
@@ -232,7 +232,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
       const T* sv = s_val[wave];
       scatter_runs<T>(
           heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals, 4, grad_v_n, 3, 0,
-          [sv](int k, int c, int p) { return sv[(k * 3 + c) * kRunPad + p]; });
+          [sv](int k, int c, int g4, T* x) {
+            using V4 = typename Vec4<T>::type;
+            const V4 q = *reinterpret_cast<const V4*>(sv + (k * 3 + c) * kRunPad + 4 * g4);
+            x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
+          });
     }
     wave_lds_sync();
   }

@@ -24,7 +24,7 @@
 
 namespace drtk_amd {
 
-constexpr int kRunPad = kWave + 1; // LDS row stride: +1 breaks the 32-bank alignment of rows
+constexpr int kRunPad = kWave + 4; // LDS row stride: rows stay 16-byte aligned (ds_read_b128), +4 staggers banks
 constexpr int kTableSlots = 128;   // vertices per tile table (power of two)
 constexpr int kTileRows = 16;      // a workgroup (4 waves) covers 64 x 16 pixels in 4 passes of 4 rows
 constexpr int kTableProbes = 8;
@@ -32,7 +32,8 @@ constexpr int kTableProbes = 8;
 // Orders this wave's LDS writes before its later LDS reads by other lanes (wave-private staging
 // areas need no workgroup barrier: a wave's DS operations execute in order).
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0) only: do NOT drain outstanding global stores
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -60,11 +61,13 @@ __device__ __forceinline__ int table_slot(int32_t* keys, int32_t vid) {
 // cov    bit p set  <=>  pixel p is covered (index != -1); constant within a run
 // slot   LDS [3][kRunPad] table slot of every pixel's triangle corners (-1: use `vid` + global atomic)
 // vid    LDS [3][kRunPad] vertex ids of every pixel's triangle corners
+// val4(k, c, g, out[4]) yields the contributions of pixels 4g..4g+3 to pair (k, c); it must be 0
+// for uncovered pixels (phase 1 stores zeros there).
 // pair j = k * CC + c  ->  table vals[slot * stride + c]   (or dst_n[vid * C_total + c_base + c])
-template <typename T, typename ValFn>
+template <typename T, typename Val4Fn>
 __device__ __forceinline__ void scatter_runs(
     unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
-    int CC, T* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, ValFn val) {
+    int CC, T* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4) {
   const int lane = lane_id();
   auto flush = [&](int k, int c, int start, T acc) {
     const int s = slot[k * kRunPad + start];
@@ -75,24 +78,30 @@ __device__ __forceinline__ void scatter_runs(
     }
   };
   if (J > 32) {
-    // one slice: run bounds are wave-uniform -> scalar loops, no exec-mask divergence
+    // one slice of 64 pixels: run boundaries are wave-uniform -> scalar tests, no divergence
     for (int j0 = 0; j0 < J; j0 += kWave) {
       const int j = j0 + lane;
       const bool active = j < J;
       const int k = active ? j / CC : 0;
       const int c = active ? j - k * CC : 0;
-      unsigned long long h = heads;
-      while (h) {
-        const int start = __builtin_ctzll(h);
-        h &= h - 1;
-        const int end = h ? __builtin_ctzll(h) : kWave;
-        if (!((cov >> start) & 1ull)) continue; // background run
-        if (active) {
-          T acc = T(0);
-          for (int p = start; p < end; ++p) acc += val(k, c, p);
-          flush(k, c, start, acc);
+      T acc = T(0);
+      int run_start = 0;
+#pragma unroll 2
+      for (int g = 0; g < kWave / 4; ++g) {
+        T x[4];
+        val4(k, c, g, x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = 4 * g + q;
+          if (p > 0 && ((heads >> p) & 1ull)) {
+            if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+            acc = T(0);
+            run_start = p;
+          }
+          acc += x[q];
         }
       }
+      if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
     }
     return;
   }
@@ -105,14 +114,19 @@ __device__ __forceinline__ void scatter_runs(
   const int c = active ? j - k * CC : 0;
   T acc = T(0);
   int run_start = p0;
-  for (int i = 0; i < span; ++i) { // uniform trip count; p differs per slice
-    const int p = p0 + i;
-    if (i > 0 && ((heads >> p) & 1ull)) {
-      if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
-      acc = T(0);
-      run_start = p;
+  for (int g = 0; g < span / 4; ++g) { // uniform trip count; pixels differ per slice
+    T x[4];
+    val4(k, c, p0 / 4 + g, x);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = p0 + 4 * g + q;
+      if ((g > 0 || q > 0) && ((heads >> p) & 1ull)) {
+        if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+        acc = T(0);
+        run_start = p;
+      }
+      acc += x[q];
     }
-    if (active && ((cov >> p) & 1ull)) acc += val(k, c, p);
   }
   if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
 }
