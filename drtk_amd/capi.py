@@ -29,7 +29,7 @@ def lib() -> ctypes.CDLL:
         L.drtk_amd_status_string.argtypes = [ctypes.c_int]
         L.drtk_amd_version.restype = ctypes.c_char_p
         for name in EXPORTS:
-            if name not in ("drtk_amd_status_string", "drtk_amd_version"):
+            if name not in ("drtk_amd_status_string", "drtk_amd_version", "drtk_amd_debug_set_flags"):
                 getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib
@@ -46,6 +46,7 @@ EXPORTS = [
     "drtk_amd_interpolate_backward",
     "drtk_amd_edge_grad_backward_workspace_bytes",
     "drtk_amd_edge_grad_backward",
+    "drtk_amd_debug_set_flags",
 ]
 
 

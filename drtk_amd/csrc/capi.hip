@@ -25,3 +25,14 @@ extern "C" const char* drtk_amd_status_string(int status) {
 extern "C" const char* drtk_amd_version(void) {
   return DRTK_STR(DRTK_AMD_VERSION_MAJOR) "." DRTK_STR(DRTK_AMD_VERSION_MINOR) " (gfx950)";
 }
+
+namespace drtk_amd {
+static int g_debug_flags = 0;
+int debug_flags() {
+  return g_debug_flags;
+}
+} // namespace drtk_amd
+
+extern "C" void drtk_amd_debug_set_flags(int flags) {
+  drtk_amd::g_debug_flags = flags;
+}

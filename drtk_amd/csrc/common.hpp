@@ -71,6 +71,10 @@ __device__ __forceinline__ void atomic_add_global(T* p, T v) {
   unsafeAtomicAdd(p, v);
 }
 
+// Diagnostics only (profiles/*.py): bit mask that lets single phases of a kernel be switched off to
+// attribute time.  0 in normal operation.
+int debug_flags();
+
 inline int64_t ceil_div(int64_t a, int64_t b) {
   return (a + b - 1) / b;
 }

@@ -120,7 +120,8 @@ template <typename T, bool HAS_VERT, bool HAS_BARY, int CV>
 __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
-    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad) {
+    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
+    int dbg) {
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPasses = kTileRows / kWaves;
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         s_vid[wave][0 * kRunPad + lane] = vid0;
         s_vid[wave][1 * kRunPad + lane] = vid1;
         s_vid[wave][2 * kRunPad + lane] = vid2;
-        s_slot[wave][0 * kRunPad + lane] = covered ? table_slot(t_keys, vid0) : -1;
-        s_slot[wave][1 * kRunPad + lane] = covered ? table_slot(t_keys, vid1) : -1;
-        s_slot[wave][2 * kRunPad + lane] = covered ? table_slot(t_keys, vid2) : -1;
+        s_slot[wave][0 * kRunPad + lane] = (covered && !(dbg & 2)) ? table_slot(t_keys, vid0) : -1;
+        s_slot[wave][1 * kRunPad + lane] = (covered && !(dbg & 2)) ? table_slot(t_keys, vid1) : -1;
+        s_slot[wave][2 * kRunPad + lane] = (covered && !(dbg & 2)) ? table_slot(t_keys, vid2) : -1;
         run_masks(tr, heads, cov);
       }
       T bg0 = T(0), bg1 = T(0), bg2 = T(0);
@@ -207,12 +208,12 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         for (int cb = 0; cb < CC; cb += CV) {
           T g[CV];
 #pragma unroll
-          for (int cc = 0; cc < CV; ++cc) g[cc] = go_p[int64_t(c0 + cb + cc) * HW];
+          for (int cc = 0; cc < CV; ++cc) g[cc] = (dbg & 4) ? T(1) : go_p[int64_t(c0 + cb + cc) * HW];
           if constexpr (HAS_VERT) {
 #pragma unroll
             for (int cc = 0; cc < CV; ++cc) s_g[wave][(cb + cc) * kRunPad + lane] = g[cc];
           }
-          if constexpr (HAS_BARY) {
+          if (HAS_BARY && !(dbg & 8)) {
             T u0[CV], u1[CV], u2[CV];
             if constexpr (CV == 4) {
               const V4 q0 = *reinterpret_cast<const V4*>(a0 + c0 + cb);
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
       }
       if constexpr (HAS_VERT) {
         wave_lds_sync();
-        if (cov != 0) {
+        if (cov != 0 && !(dbg & 1)) {
           const T* sg = s_g[wave];
           const T* sb = s_b[wave];
           scatter_runs<T>(
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
     }
     if constexpr (HAS_VERT) {
       __syncthreads();
-      table_flush<T>(t_keys, t_vals, kChunk, CC, attr_grad_n, C, c0);
+      if (!(dbg & 16)) table_flush<T>(t_keys, t_vals, kChunk, CC, attr_grad_n, C, c0);
     }
   }
 }
@@ -323,7 +324,7 @@ int interpolate_backward_impl(
 #define LAUNCH(HV, HB, CV)                                                                      \
   hipLaunchKernelGGL(                                                                           \
       (interpolate_backward_kernel<T, HV, HB, CV>), grid, block, 0, stream, grad_out, attrs, vi, \
-      index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad)
+      index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags())
   if (attr_grad && bary_grad) {
     if (cvec) LAUNCH(true, true, 4); else LAUNCH(true, true, 1);
   } else if (attr_grad) {

@@ -64,6 +64,14 @@ __device__ __forceinline__ int table_slot(int32_t* keys, int32_t vid) {
 // val4(k, c, g, out[4]) yields the contributions of pixels 4g..4g+3 to pair (k, c); it must be 0
 // for uncovered pixels (phase 1 stores zeros there).
 // pair j = k * CC + c  ->  table vals[slot * stride + c]   (or dst_n[vid * C_total + c_base + c])
+// LDS float/double atomic add on an explicitly LDS-typed pointer: guarantees ds_add_f32/f64 (a
+// generic pointer that may alias global memory is lowered to a much slower flat_atomic).
+template <typename T>
+__device__ __forceinline__ void lds_atomic_add(T* p, T v) {
+  using LdsPtr = __attribute__((address_space(3))) T*;
+  __hip_atomic_fetch_add((LdsPtr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <typename T, typename Val4Fn>
 __device__ __forceinline__ void scatter_runs(
     unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
@@ -72,8 +80,9 @@ __device__ __forceinline__ void scatter_runs(
   auto flush = [&](int k, int c, int start, T acc) {
     const int s = slot[k * kRunPad + start];
     if (s >= 0) {
-      atomicAdd(&vals[s * stride + c], acc); // LDS
-    } else {
+      lds_atomic_add(vals + s * stride + c, acc);
+    }
+    if (s < 0) { // table full for this vertex: direct global atomic (rare)
       atomic_add_global(dst_n + int64_t(vid[k * kRunPad + start]) * C_total + c_base + c, acc);
     }
   };
@@ -85,20 +94,29 @@ __device__ __forceinline__ void scatter_runs(
       const int k = active ? j / CC : 0;
       const int c = active ? j - k * CC : 0;
       T acc = T(0);
-      int run_start = 0;
-#pragma unroll 2
+      int run_start = 0; // wave-uniform
+#pragma unroll 4
       for (int g = 0; g < kWave / 4; ++g) {
         T x[4];
         val4(k, c, g, x);
+        // run heads among pixels 4g..4g+3 (pixel 0 never flushes)
+        const uint32_t hb = __builtin_amdgcn_readfirstlane(
+            static_cast<uint32_t>(heads >> (4 * g)) & (g == 0 ? 0xEu : 0xFu));
+        if (hb == 0) {
+          acc += x[0];
+          acc += x[1];
+          acc += x[2];
+          acc += x[3];
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int p = 4 * g + q;
-          if (p > 0 && ((heads >> p) & 1ull)) {
-            if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
-            acc = T(0);
-            run_start = p;
+          for (int q = 0; q < 4; ++q) {
+            if (hb & (1u << q)) {
+              if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+              acc = T(0);
+              run_start = __builtin_amdgcn_readfirstlane(4 * g + q);
+            }
+            acc += x[q];
           }
-          acc += x[q];
         }
       }
       if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
@@ -117,15 +135,22 @@ __device__ __forceinline__ void scatter_runs(
   for (int g = 0; g < span / 4; ++g) { // uniform trip count; pixels differ per slice
     T x[4];
     val4(k, c, p0 / 4 + g, x);
+    const uint32_t hb = static_cast<uint32_t>(heads >> (p0 + 4 * g)) & (g == 0 ? 0xEu : 0xFu);
+    if (__ballot(hb != 0) == 0) { // no slice has a run head in this group
+      acc += x[0];
+      acc += x[1];
+      acc += x[2];
+      acc += x[3];
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int p = p0 + 4 * g + q;
-      if ((g > 0 || q > 0) && ((heads >> p) & 1ull)) {
-        if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
-        acc = T(0);
-        run_start = p;
+      for (int q = 0; q < 4; ++q) {
+        if (hb & (1u << q)) {
+          if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+          acc = T(0);
+          run_start = p0 + 4 * g + q;
+        }
+        acc += x[q];
       }
-      acc += x[q];
     }
   }
   if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);

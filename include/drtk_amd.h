@@ -118,6 +118,10 @@ int drtk_amd_edge_grad_backward(
     int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix_img, void* workspace,
     size_t workspace_bytes, drtk_stream_t stream);
 
+/* Diagnostics for profiling scripts: a bit mask that switches single kernel phases off so that
+ * their time can be attributed.  Results are WRONG while it is non-zero; default 0. */
+void drtk_amd_debug_set_flags(int flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,3 +54,19 @@ for name, fn in kernels.items():
     ev1.record()
     th.cuda.synchronize()
     print(f"{name}: {ev0.elapsed_time(ev1) / a.reps:.3f} ms")
+
+if os.environ.get("DRTK_ABLATE"):
+    L = capi.lib()
+    fn = kernels[os.environ["DRTK_ABLATE"]]
+    for flags in (0, 1, 2 | 1, 4, 8, 16, 1 | 16, 1 | 2 | 16, 1 | 2 | 4 | 8 | 16, 4 | 8):
+        L.drtk_amd_debug_set_flags(flags)
+        fn()
+        th.cuda.synchronize()
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        th.cuda.synchronize()
+        print(f"ablate {os.environ['DRTK_ABLATE']} flags={flags:2d}: {e0.elapsed_time(e1) / 5:.3f} ms")
+    L.drtk_amd_debug_set_flags(0)
