@@ -114,8 +114,9 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
   }
 }
 
-// Backward.  A workgroup owns a 64 x 16 pixel tile: 4 passes of 4 rows, wave = 64 pixels of a row,
-// lane = pixel in phase 1.  Channels are processed in chunks of 16 (outer loop).
+// Backward.  A workgroup owns a 64 x 16 pixel tile; each of its 4 waves walks 4 adjacent rows of 64
+// pixels (lane = pixel in phase 1) with a wave-private vertex table.  Channels are processed in
+// chunks of 16 (outer loop).  No workgroup barrier is needed anywhere.
 template <typename T, bool HAS_VERT, bool HAS_BARY, int CV>
 __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   __shared__ __attribute__((aligned(16))) T s_b[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 4];
   __shared__ int32_t s_vid[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
   __shared__ int32_t s_slot[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
-  __shared__ int32_t t_keys[HAS_VERT ? kTableSlots : 1];
-  __shared__ T t_vals[HAS_VERT ? kTableSlots * kChunk : 1];
+  __shared__ int32_t t_keys[HAS_VERT ? kWaves : 1][HAS_VERT ? kTableSlots : 1];
+  __shared__ T t_vals[HAS_VERT ? kWaves : 1][HAS_VERT ? kTableSlots * kChunk : 1];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -142,23 +143,20 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
   T* attr_grad_n = HAS_VERT ? attr_grad + int64_t(n) * V * C : nullptr;
 
-  if constexpr (HAS_VERT) {
-    table_init(t_keys);
-    __syncthreads();
-  }
+  if constexpr (HAS_VERT) table_init(t_keys[wave]);
 
   for (int c0 = 0; c0 < C; c0 += kChunk) {
     const int CC = min(kChunk, C - c0);
     if constexpr (HAS_VERT) {
-      __syncthreads(); // previous chunk flushed
-      for (int i = threadIdx.x; i < kTableSlots * kChunk; i += kBlock) t_vals[i] = T(0);
-      __syncthreads();
+      wave_lds_sync(); // previous chunk flushed, keys initialised
+      for (int i = lane; i < kTableSlots * kChunk; i += kWave) t_vals[wave][i] = T(0);
+      wave_lds_sync();
     }
     // software pipeline over the 4 row passes: the index of pass p+1 is requested at the top of
     // pass p and its triangle's vertex ids right before phase 2, so both dependent gathers fly
     // under the current pass instead of in front of the next one.
     auto load_tr = [&](int ps) -> int32_t {
-      const int yy = tyi * kTileRows + ps * kWaves + wave;
+      const int yy = tyi * kTileRows + wave * kPasses + ps;
       return (x < W && yy < H) ? index_img[int64_t(n) * HW + int64_t(yy) * W + x] : -1;
     };
     int32_t tr_next = load_tr(0);
@@ -169,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
     }
 #pragma unroll 1
     for (int ps = 0; ps < kPasses; ++ps) {
-      const int y = tyi * kTileRows + ps * kWaves + wave;
+      const int y = tyi * kTileRows + wave * kPasses + ps;
       const bool in_range = x < W && y < H;
       const int64_t pix = int64_t(y) * W + x;
       const int32_t tr = tr_next;
@@ -189,9 +187,10 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         s_vid[wave][0 * kRunPad + lane] = vid0;
         s_vid[wave][1 * kRunPad + lane] = vid1;
         s_vid[wave][2 * kRunPad + lane] = vid2;
-        s_slot[wave][0 * kRunPad + lane] = (covered && !(dbg & 2)) ? table_slot(t_keys, vid0) : -1;
-        s_slot[wave][1 * kRunPad + lane] = (covered && !(dbg & 2)) ? table_slot(t_keys, vid1) : -1;
-        s_slot[wave][2 * kRunPad + lane] = (covered && !(dbg & 2)) ? table_slot(t_keys, vid2) : -1;
+        const bool use_table = covered && !(dbg & 2) && vid0 != vid1 && vid0 != vid2 && vid1 != vid2;
+        s_slot[wave][0 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid0) : -1;
+        s_slot[wave][1 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid1) : -1;
+        s_slot[wave][2 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid2) : -1;
         run_masks(tr, heads, cov);
       }
       T bg0 = T(0), bg1 = T(0), bg2 = T(0);
@@ -257,19 +256,22 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
           const T* sg = s_g[wave];
           const T* sb = s_b[wave];
           scatter_runs<T>(
-              heads, cov, s_slot[wave], s_vid[wave], 3 * CC, CC, t_vals, kChunk, attr_grad_n, C, c0,
-              [sg, sb](int k, int c, int g4, T* x) {
+              heads, cov, s_slot[wave], s_vid[wave], 3 * CC, CC, t_vals[wave], kChunk, attr_grad_n, C, c0,
+              [sg, sb, dbg](int k, int c, int g4, T* x) {
+                if (dbg & 64) {
+                  x[0] = x[1] = x[2] = x[3] = T(1);
+                  return;
+                }
                 const V4 a = *reinterpret_cast<const V4*>(sg + c * kRunPad + 4 * g4);
                 const V4 b = *reinterpret_cast<const V4*>(sb + k * kRunPad + 4 * g4);
                 x[0] = a.x * b.x, x[1] = a.y * b.y, x[2] = a.z * b.z, x[3] = a.w * b.w;
-              });
+              }, dbg);
         }
         wave_lds_sync();
       }
     }
     if constexpr (HAS_VERT) {
-      __syncthreads();
-      if (!(dbg & 16)) table_flush<T>(t_keys, t_vals, kChunk, CC, attr_grad_n, C, c0);
+      if (!(dbg & 16)) table_flush<T>(t_keys[wave], t_vals[wave], kChunk, CC, attr_grad_n, C, c0);
     }
   }
 }

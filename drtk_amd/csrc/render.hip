@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
   }
 }
 
-// Backward: a workgroup owns a 64 x 16 pixel tile (4 passes of 4 rows, wave = 64 pixels of a row).
+// Backward: a workgroup owns a 64 x 16 pixel tile; each of its 4 waves walks 4 adjacent rows of 64 pixels.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
   __shared__ int32_t s_vid[kWaves][3 * kRunPad];
   __shared__ int32_t s_slot[kWaves][3 * kRunPad];
-  __shared__ int32_t t_keys[kTableSlots];
-  __shared__ T t_vals[kTableSlots * 4];
+  __shared__ int32_t t_keys[kWaves][kTableSlots];
+  __shared__ T t_vals[kWaves][kTableSlots * 4];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -155,13 +155,13 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
   T* grad_v_n = grad_v + int64_t(n) * V * 3;
 
-  table_init(t_keys);
-  for (int i = threadIdx.x; i < kTableSlots * 4; i += kBlock) t_vals[i] = T(0);
-  __syncthreads();
+  table_init(t_keys[wave]);
+  for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = T(0);
+  wave_lds_sync();
 
 #pragma unroll 1
   for (int pass = 0; pass < kTileRows / kWaves; ++pass) {
-    const int y = tyi * kTileRows + pass * kWaves + wave;
+    const int y = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
     const bool in_range = x < W && y < H;
     const int64_t pix = int64_t(y) * W + x;
     const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
@@ -220,10 +220,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
 
 #pragma unroll
     for (int j = 0; j < 9; ++j) s_val[wave][j * kRunPad + lane] = g[j];
+    const bool dup = vid[0] == vid[1] || vid[0] == vid[2] || vid[1] == vid[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       s_vid[wave][k * kRunPad + lane] = vid[k];
-      s_slot[wave][k * kRunPad + lane] = (tr != -1) ? table_slot(t_keys, vid[k]) : -1;
+      s_slot[wave][k * kRunPad + lane] = (tr != -1 && !dup) ? table_slot(t_keys[wave], vid[k]) : -1;
     }
     unsigned long long heads, cov;
     run_masks(tr, heads, cov);
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     if (cov != 0) {
       const T* sv = s_val[wave];
       scatter_runs<T>(
-          heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals, 4, grad_v_n, 3, 0,
+          heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals[wave], 4, grad_v_n, 3, 0,
           [sv](int k, int c, int g4, T* x) {
             using V4 = typename Vec4<T>::type;
             const V4 q = *reinterpret_cast<const V4*>(sv + (k * 3 + c) * kRunPad + 4 * g4);
@@ -240,8 +241,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     }
     wave_lds_sync();
   }
-  __syncthreads();
-  table_flush<T>(t_keys, t_vals, 4, 3, grad_v_n, 3, 0);
+  table_flush<T>(t_keys[wave], t_vals[wave], 4, 3, grad_v_n, 3, 0);
 }
 
 template <typename T>

@@ -13,11 +13,13 @@
 //     triangle id changes along the 64 pixels -- is a 64-bit ballot, i.e. wave-uniform SGPR state.
 //     Phase 2 flips the wave to (corner, channel)-major: a lane owns one (k, c) pair (and, for
 //     small channel counts, one slice of the pixels), and sums each run in a register.
-//   level 2 (workgroup): run sums go into a small LDS hash table keyed by VERTEX id that lives for
-//     the whole 64 x 16 pixel tile of the workgroup (ds_add_f32), so every vertex touched by the
-//     tile costs one global atomic per channel at the end -- one contiguous segment per vertex --
-//     instead of one per run.  Vertices that do not fit (table full) fall back to a direct
-//     global atomic, so any input is handled.
+//   level 2 (wave tile): run sums go into a small wave-private LDS hash table keyed by VERTEX id
+//     that lives for the wave's whole 64 x 4 pixel tile, so every vertex touched by the tile costs
+//     one global atomic per channel at the end -- one contiguous segment per vertex -- instead of
+//     one per run.  The table is private to the wave, so the wide (C = 16) path updates it with
+//     plain read-modify-write (measured: LDS float atomics retire ~1 lane per clock and were the
+//     bottleneck of a workgroup-shared table).  Vertices that do not fit (table full) fall back to
+//     a direct global atomic, so any input is handled.
 #pragma once
 
 #include "common.hpp"
@@ -25,9 +27,9 @@
 namespace drtk_amd {
 
 constexpr int kRunPad = kWave + 4; // LDS row stride: rows stay 16-byte aligned (ds_read_b128), +4 staggers banks
-constexpr int kTableSlots = 128;   // vertices per tile table (power of two)
-constexpr int kTileRows = 16;      // a workgroup (4 waves) covers 64 x 16 pixels in 4 passes of 4 rows
-constexpr int kTableProbes = 8;
+constexpr int kTableSlots = 64;    // vertices per wave-tile table (power of two)
+constexpr int kTileRows = 16;      // a workgroup (4 waves) covers 64 x 16 pixels: 4 adjacent rows per wave
+constexpr int kTableProbes = 6;
 
 // Orders this wave's LDS writes before its later LDS reads by other lanes (wave-private staging
 // areas need no workgroup barrier: a wave's DS operations execute in order).
@@ -37,14 +39,14 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void table_init(int32_t* keys) {
-  for (int i = threadIdx.x; i < kTableSlots; i += blockDim.x) keys[i] = -1;
+__device__ __forceinline__ void table_init(int32_t* keys) { // wave-private table
+  for (int i = lane_id(); i < kTableSlots; i += kWave) keys[i] = -1;
 }
 
 // Slot of vertex `vid` in the tile table (inserting it if needed); -1 if the table is full along
-// its probe sequence.  Safe under concurrent calls from any lanes of the workgroup.
+// its probe sequence.  Safe under concurrent calls from the lanes of the owning wave.
 __device__ __forceinline__ int table_slot(int32_t* keys, int32_t vid) {
-  uint32_t h = (static_cast<uint32_t>(vid) * 2654435761u) >> 25; // 7 bits
+  uint32_t h = (static_cast<uint32_t>(vid) * 2654435761u) >> 26; // 6 bits
   for (int probe = 0; probe < kTableProbes; ++probe) {
     const int32_t cur = keys[h];
     if (cur == vid) return static_cast<int>(h);
@@ -75,12 +77,22 @@ __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
 template <typename T, typename Val4Fn>
 __device__ __forceinline__ void scatter_runs(
     unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
-    int CC, T* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4) {
+    int CC, T* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0) {
   const int lane = lane_id();
-  auto flush = [&](int k, int c, int start, T acc) {
+  using LdsPtr = __attribute__((address_space(3))) T*;
+  // `exclusive`: no two lanes of one call target the same table entry (one run at a time, and the
+  // three corners of a triangle are distinct vertices -- phase 1 sends triangles with repeated
+  // vertex ids to the global fallback), so a plain read-modify-write is race free.
+  auto flush = [&](int k, int c, int start, T acc, bool exclusive) {
+    if (dbg & 32) return;
     const int s = slot[k * kRunPad + start];
     if (s >= 0) {
-      lds_atomic_add(vals + s * stride + c, acc);
+      if (exclusive) {
+        LdsPtr q = (LdsPtr)(vals + s * stride + c);
+        *q = *q + acc;
+      } else {
+        lds_atomic_add(vals + s * stride + c, acc);
+      }
     }
     if (s < 0) { // table full for this vertex: direct global atomic (rare)
       atomic_add_global(dst_n + int64_t(vid[k * kRunPad + start]) * C_total + c_base + c, acc);
@@ -111,7 +123,7 @@ __device__ __forceinline__ void scatter_runs(
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             if (hb & (1u << q)) {
-              if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+              if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc, true);
               acc = T(0);
               run_start = __builtin_amdgcn_readfirstlane(4 * g + q);
             }
@@ -119,7 +131,7 @@ __device__ __forceinline__ void scatter_runs(
           }
         }
       }
-      if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+      if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc, true);
     }
     return;
   }
@@ -145,7 +157,7 @@ __device__ __forceinline__ void scatter_runs(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (hb & (1u << q)) {
-          if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+          if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc, false);
           acc = T(0);
           run_start = p0 + 4 * g + q;
         }
@@ -153,15 +165,15 @@ __device__ __forceinline__ void scatter_runs(
       }
     }
   }
-  if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc);
+  if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc, false);
 }
 
-// Workgroup-wide: add every occupied table entry to dst_n[key * C_total + c_base + c], c < CC.
+// Wave-wide: add every occupied entry of the wave's table to dst_n[key * C_total + c_base + c], c < CC.
 template <typename T>
 __device__ __forceinline__ void table_flush(
     const int32_t* keys, const T* vals, int stride, int CC, T* __restrict__ dst_n, int C_total,
     int c_base) {
-  for (int e = threadIdx.x; e < kTableSlots * CC; e += blockDim.x) {
+  for (int e = lane_id(); e < kTableSlots * CC; e += kWave) {
     const int s = e / CC, c = e - s * CC;
     const int32_t key = keys[s];
     if (key >= 0) {

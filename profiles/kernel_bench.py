@@ -58,7 +58,7 @@ for name, fn in kernels.items():
 if os.environ.get("DRTK_ABLATE"):
     L = capi.lib()
     fn = kernels[os.environ["DRTK_ABLATE"]]
-    for flags in (0, 1, 2 | 1, 4, 8, 16, 1 | 16, 1 | 2 | 16, 1 | 2 | 4 | 8 | 16, 4 | 8):
+    for flags in [int(x) for x in os.environ.get('DRTK_ABLATE_FLAGS', '0,1,32,64,96,16').split(',')]:
         L.drtk_amd_debug_set_flags(flags)
         fn()
         th.cuda.synchronize()
