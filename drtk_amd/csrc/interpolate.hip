@@ -13,7 +13,6 @@
 namespace drtk_amd {
 namespace {
 
-constexpr int kChunk = 16; // channels per scatter chunk
 
 template <typename T>
 struct Vec4;
@@ -117,7 +116,11 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
 // Backward.  A workgroup owns a 64 x 16 pixel tile; each of its 4 waves walks 4 adjacent rows of 64
 // pixels (lane = pixel in phase 1) with a wave-private vertex table.  Channels are processed in
 // chunks of 16 (outer loop).  No workgroup barrier is needed anywhere.
-template <typename T, bool HAS_VERT, bool HAS_BARY, int CV>
+// CHUNK = channels staged per round.  CHUNK = 4 (C <= 4, e.g. the v_pix route of edge_grad) keeps
+// a wave-private vertex table; CHUNK = 16 sends each run's sums straight to global memory -- its 16
+// lanes per corner form one 64-byte request, and the smaller LDS footprint buys the occupancy
+// that hides phase 1's gather latency (measured faster than the table at C = 16).
+template <typename T, bool HAS_VERT, bool HAS_BARY, int CV, int CHUNK>
 __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
@@ -126,12 +129,13 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPasses = kTileRows / kWaves;
-  __shared__ __attribute__((aligned(16))) T s_g[HAS_VERT ? kWaves : 1][HAS_VERT ? kChunk * kRunPad : 4];
+  constexpr bool TABLE = HAS_VERT && CHUNK <= 4;
+  __shared__ __attribute__((aligned(16))) T s_g[HAS_VERT ? kWaves : 1][HAS_VERT ? CHUNK * kRunPad : 4];
   __shared__ __attribute__((aligned(16))) T s_b[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 4];
   __shared__ int32_t s_vid[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
   __shared__ int32_t s_slot[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
-  __shared__ int32_t t_keys[HAS_VERT ? kWaves : 1][HAS_VERT ? kTableSlots : 1];
-  __shared__ T t_vals[HAS_VERT ? kWaves : 1][HAS_VERT ? kTableSlots * kChunk : 1];
+  __shared__ int32_t t_keys[TABLE ? kWaves : 1][TABLE ? kTableSlots : 1];
+  __shared__ T t_vals[TABLE ? kWaves : 1][TABLE ? kTableSlots * CHUNK : 1];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -143,13 +147,13 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
   T* attr_grad_n = HAS_VERT ? attr_grad + int64_t(n) * V * C : nullptr;
 
-  if constexpr (HAS_VERT) table_init(t_keys[wave]);
+  if constexpr (TABLE) table_init(t_keys[wave]);
 
-  for (int c0 = 0; c0 < C; c0 += kChunk) {
-    const int CC = min(kChunk, C - c0);
-    if constexpr (HAS_VERT) {
+  for (int c0 = 0; c0 < C; c0 += CHUNK) {
+    const int CC = min(CHUNK, C - c0);
+    if constexpr (TABLE) {
       wave_lds_sync(); // previous chunk flushed, keys initialised
-      for (int i = lane; i < kTableSlots * kChunk; i += kWave) t_vals[wave][i] = T(0);
+      for (int i = lane; i < kTableSlots * CHUNK; i += kWave) t_vals[wave][i] = T(0);
       wave_lds_sync();
     }
     // software pipeline over the 4 row passes: the index of pass p+1 is requested at the top of
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         s_vid[wave][0 * kRunPad + lane] = vid0;
         s_vid[wave][1 * kRunPad + lane] = vid1;
         s_vid[wave][2 * kRunPad + lane] = vid2;
-        const bool use_table = covered && !(dbg & 2) && vid0 != vid1 && vid0 != vid2 && vid1 != vid2;
+        const bool use_table = TABLE && covered && !(dbg & 2) && vid0 != vid1 && vid0 != vid2 && vid1 != vid2;
         s_slot[wave][0 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid0) : -1;
         s_slot[wave][1 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid1) : -1;
         s_slot[wave][2 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid2) : -1;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
           const T* sg = s_g[wave];
           const T* sb = s_b[wave];
           scatter_runs<T>(
-              heads, cov, s_slot[wave], s_vid[wave], 3 * CC, CC, t_vals[wave], kChunk, attr_grad_n, C, c0,
+              heads, cov, s_slot[wave], s_vid[wave], 3 * CC, CC, t_vals[wave], CHUNK, attr_grad_n, C, c0,
               [sg, sb, dbg](int k, int c, int g4, T* x) {
                 if (dbg & 64) {
                   x[0] = x[1] = x[2] = x[3] = T(1);
@@ -270,8 +274,8 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         wave_lds_sync();
       }
     }
-    if constexpr (HAS_VERT) {
-      if (!(dbg & 16)) table_flush<T>(t_keys[wave], t_vals[wave], kChunk, CC, attr_grad_n, C, c0);
+    if constexpr (TABLE) {
+      if (!(dbg & 16)) table_flush<T>(t_keys[wave], t_vals[wave], CHUNK, CC, attr_grad_n, C, c0);
     }
   }
 }
@@ -323,16 +327,22 @@ int interpolate_backward_impl(
   const int tiles_x = static_cast<int>(ceil_div(W, kWave)), tiles_y = static_cast<int>(ceil_div(H, kTileRows));
   const dim3 grid(static_cast<unsigned>(int64_t(tiles_x) * tiles_y), static_cast<unsigned>(N));
   const dim3 block(kBlock);
-#define LAUNCH(HV, HB, CV)                                                                      \
+#define LAUNCH(HV, HB, CV, CH)                                                                  \
   hipLaunchKernelGGL(                                                                           \
-      (interpolate_backward_kernel<T, HV, HB, CV>), grid, block, 0, stream, grad_out, attrs, vi, \
-      index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags())
+      (interpolate_backward_kernel<T, HV, HB, CV, CH>), grid, block, 0, stream, grad_out, attrs, \
+      vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad,  \
+      debug_flags())
+  const bool small_c = C <= 4;
   if (attr_grad && bary_grad) {
-    if (cvec) LAUNCH(true, true, 4); else LAUNCH(true, true, 1);
+    if (small_c) {
+      if (cvec) LAUNCH(true, true, 4, 4); else LAUNCH(true, true, 1, 4);
+    } else {
+      if (cvec) LAUNCH(true, true, 4, 16); else LAUNCH(true, true, 1, 16);
+    }
   } else if (attr_grad) {
-    LAUNCH(true, false, 1);
+    if (small_c) LAUNCH(true, false, 1, 4); else LAUNCH(true, false, 1, 16);
   } else {
-    if (cvec) LAUNCH(false, true, 4); else LAUNCH(false, true, 1);
+    if (cvec) LAUNCH(false, true, 4, 16); else LAUNCH(false, true, 1, 16);
   }
 #undef LAUNCH
   DRTK_RETURN_IF_LAUNCH_FAILED();
