@@ -61,6 +61,37 @@ def algorithmic_bytes_per_px(C):
     }
 
 
+# op -> substrings of the HIP kernels it launches (names as rocprofv3 prints them)
+OP_KERNELS = {
+    "rasterize": ["bin_count_kernel", "bin_scan_kernel", "bin_fill_kernel", "tile_raster_kernel"],
+    "render": ["render_kernel<"],
+    "interpolate": ["interpolate_kernel<float, 4, 4>"],
+    "edge_grad_backward": ["edge_dots_kernel", "edge_gather_kernel"],
+    "interpolate_backward_vpix": ["interpolate_backward_kernel<float, true, false"],
+    "interpolate_backward": ["interpolate_backward_kernel<float, true, true"],
+    "render_backward": ["render_backward_kernel"],
+}
+
+
+def measured_traffic(op):
+    """HBM bytes per launch of `op` from the newest committed PMC summary (profiles/rNN/traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on the same kernels and workload,
+    corrected as MI355X_MICROARCH.md prescribes).  None if no profile covers the op."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files or op not in OP_KERNELS:
+        return None
+    kernels = json.load(open(files[-1]))["kernels"]
+    total, hit = 0, 0
+    for pat in OP_KERNELS[op]:
+        for name, rec in kernels.items():
+            if pat in name:
+                total += rec["hbm_bytes"]
+                hit += 1
+    return int(total) if hit else None
+
+
 def time_kernels(v_pix, vi, attr, H, W, reps):
     """Per-kernel HIP-event timing through the C ABI on torch's current stream (the stream the
     kernels are launched on).  Returns {name: ms}."""
@@ -218,7 +249,9 @@ def main():
         total_bpp = sum(bpp.values())  # = 164 + 16 C
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": measured_traffic(dom) if (args.mesh, H, n_local, C) == ("100k", 2048, 8, 16) else None,
+            "algorithmic_bytes": bpp[dom] * P,
             "bytes_per_px": bpp[dom], "ms_per_launch": round(kt[dom], 4),
         }
         path = {
