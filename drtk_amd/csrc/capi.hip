@@ -27,6 +27,18 @@ extern "C" const char* drtk_amd_version(void) {
 }
 
 namespace drtk_amd {
+int num_compute_units() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 static int g_debug_flags = 0;
 int debug_flags() {
   return g_debug_flags;

@@ -75,6 +75,9 @@ __device__ __forceinline__ void atomic_add_global(T* p, T v) {
 // attribute time.  0 in normal operation.
 int debug_flags();
 
+// Compute units of the current device (cached per device id).
+int num_compute_units();
+
 inline int64_t ceil_div(int64_t a, int64_t b) {
   return (a + b - 1) / b;
 }

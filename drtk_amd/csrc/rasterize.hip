@@ -23,6 +23,8 @@
 // memset, no global atomics, no unpack pass (the reference moves >= 24 B/px).
 // The min-reduction over (depth bits, id) is order independent, so the result is deterministic
 // and bit-identical to the reference regardless of bin order.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace drtk_amd {
@@ -147,9 +149,17 @@ struct BinLayout {
   int tile_shift; // log2(tile size in pixels)
   int tiles_x, tiles_y;
   int64_t tiles_per_view, num_tiles; // per view / total
-  size_t off_count, off_cursor, off_big_count, zero_bytes; // zero-filled prefix
-  size_t off_offset, off_range, off_big_list, off_pairs, total_bytes;
+  size_t off_count, off_cursor, off_big_count, off_queue, zero_bytes; // zero-filled prefix
+  size_t off_offset, off_range, off_big_list, off_pairs, off_items, total_bytes;
+  int64_t max_items;
 };
+
+// Work items of the raster pass: a tile, or one of 4 / 16 sub-rectangles of a heavy tile.
+constexpr int kSplit4Threshold = 384;   // triangles in a tile's list above which it is split 2x2
+constexpr int kSplit16Threshold = 1536; // ... 4x4
+__host__ __device__ inline uint32_t make_item(uint32_t tile, uint32_t sub, uint32_t split_log) {
+  return tile | (sub << 24) | (split_log << 28);
+}
 
 inline size_t align_up(size_t x, size_t a) {
   return (x + a - 1) / a * a;
@@ -171,6 +181,8 @@ inline BinLayout make_layout(int64_t N, int64_t F, int64_t H, int64_t W) {
   o += align_up(sizeof(int32_t) * L.num_tiles, 256);
   L.off_big_count = o;
   o += align_up(sizeof(int32_t) * (N > 0 ? N : 1), 256);
+  L.off_queue = o; // [0] next work item, [1] number of work items
+  o += 256;
   L.zero_bytes = o;
   L.off_offset = o;
   o += align_up(sizeof(int32_t) * (L.num_tiles + 1), 256);
@@ -180,6 +192,10 @@ inline BinLayout make_layout(int64_t N, int64_t F, int64_t H, int64_t W) {
   o += align_up(sizeof(int32_t) * N * F, 256);
   L.off_pairs = o;
   o += align_up(sizeof(int32_t) * kMaxSmallTiles * N * F, 256);
+  // every split tile holds > kSplit4Threshold of the <= 4*N*F list entries and yields <= 16 items
+  L.max_items = L.num_tiles + 16 * ((kMaxSmallTiles * N * F) / kSplit4Threshold);
+  L.off_items = o;
+  o += align_up(sizeof(uint32_t) * L.max_items, 256);
   L.total_bytes = o > 0 ? o : 256;
   return L;
 }
@@ -253,14 +269,27 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(
   }
 }
 
-// ---- pass 2: exclusive scan over all tile counters (single workgroup) -------------------------
+// ---- pass 2: exclusive scan over all tile counters + raster work list (single workgroup) -------
+// The work list orders the raster pass heavy-first: tiles whose lists are long are split into 4x4 or
+// 2x2 sub-rectangles (each sub-rectangle re-scans the tile's list but rasterizes only its part), then
+// ordinary tiles, then tiles with empty lists.  The raster kernel pulls items from this list through
+// an atomic counter, so the pole / limb tiles of a mesh (10x the mean triangle count) no longer form
+// a serial tail.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(
-    const int32_t* __restrict__ tile_count, int32_t* __restrict__ tile_offset, int num_tiles) {
+    const int32_t* __restrict__ tile_count, int32_t* __restrict__ tile_offset, int num_tiles,
+    int tile_shift, uint32_t* __restrict__ items, int32_t* __restrict__ queue) {
   __shared__ int32_t part[1024];
+  __shared__ int32_t cls_count[4], cls_base[4];
   const int tid = threadIdx.x;
   const int chunk = (num_tiles + 1023) / 1024;
   const int begin = tid * chunk;
   const int end = min(begin + chunk, num_tiles);
+  const int max_split_log = max(0, min(2, tile_shift - 4)); // sub-rectangles are at least 16 px
+  auto split_log_of = [&](int c) {
+    int sl = c > kSplit16Threshold ? 2 : (c > kSplit4Threshold ? 1 : 0);
+    return min(sl, max_split_log);
+  };
+  if (tid < 4) cls_count[tid] = 0;
   int32_t sum = 0;
   for (int i = begin; i < end; ++i) sum += tile_count[i];
   part[tid] = sum;
@@ -274,10 +303,32 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
   }
   int32_t run = part[tid] - sum; // exclusive prefix of this thread's chunk
   for (int i = begin; i < end; ++i) {
+    const int c = tile_count[i];
     tile_offset[i] = run;
-    run += tile_count[i];
+    run += c;
+    const int sl = split_log_of(c);
+    const int cls = c == 0 ? 3 : 2 - sl; // 0: 4x4 split, 1: 2x2 split, 2: whole tile, 3: empty list
+    atomicAdd(&cls_count[cls], 1 << (2 * sl));
   }
   if (tid == 1023) tile_offset[num_tiles] = part[1023];
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < 4; ++k) {
+      cls_base[k] = acc;
+      acc += cls_count[k];
+    }
+    queue[1] = acc; // number of work items
+  }
+  __syncthreads();
+  for (int i = begin; i < end; ++i) {
+    const int c = tile_count[i];
+    const int sl = split_log_of(c);
+    const int cls = c == 0 ? 3 : 2 - sl;
+    const int n_sub = 1 << (2 * sl);
+    const int base = atomicAdd(&cls_base[cls], n_sub);
+    for (int j = 0; j < n_sub; ++j) items[base + j] = make_item(static_cast<uint32_t>(i), j, sl);
+  }
 }
 
 // ---- pass 3: write triangle ids into the tile lists -----------------------------------------
@@ -416,89 +467,111 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
     int H, int W, int tiles_x, int tiles_per_view, const int32_t* __restrict__ tile_offset,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ big_count,
     const int32_t* __restrict__ big_list, const uint2* __restrict__ tri_range,
-    float* __restrict__ depth_img, int32_t* __restrict__ index_img) {
+    const uint32_t* __restrict__ items, int32_t* __restrict__ queue, float* __restrict__ depth_img,
+    int32_t* __restrict__ index_img) {
   constexpr int TILE = 1 << TILE_SHIFT;
   constexpr int NPIX = TILE * TILE;
   __shared__ unsigned long long zbuf[NPIX];
+  __shared__ int s_item;
 
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int n = tile / tiles_per_view;
-  const int t_in_view = tile - n * tiles_per_view;
-  const int ty = t_in_view / tiles_x, tx = t_in_view - ty * tiles_x;
-  const int x0 = tx << TILE_SHIFT, y0 = ty << TILE_SHIFT;
-  const int x1 = min(x0 + TILE - 1, W - 1), y1 = min(y0 + TILE - 1, H - 1);
+  const int n_items = queue[1];
+  for (;;) {
+    if (tid == 0) s_item = atomicAdd(&queue[0], 1);
+    __syncthreads();
+    const int item_index = s_item;
+    if (item_index >= n_items) break;
+    const uint32_t item = items[item_index];
+    const int tile = item & 0xFFFFFF;
+    const int sub = (item >> 24) & 0xF, split_log = (item >> 28) & 3;
+    const int n = tile / tiles_per_view;
+    const int t_in_view = tile - n * tiles_per_view;
+    const int ty = t_in_view / tiles_x, tx = t_in_view - ty * tiles_x;
+    const int ss = TILE >> split_log; // side of this item's rectangle
+    const int x0 = (tx << TILE_SHIFT) + (sub & ((1 << split_log) - 1)) * ss;
+    const int y0 = (ty << TILE_SHIFT) + (sub >> split_log) * ss;
+    const int x1 = min(x0 + ss - 1, W - 1), y1 = min(y0 + ss - 1, H - 1);
+    if (x0 < W && y0 < H) {
+      const int rows = y1 - y0 + 1;
+      for (int i = tid; i < (rows << TILE_SHIFT); i += kBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
+      __syncthreads();
 
-  for (int i = tid; i < NPIX; i += kBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
-  __syncthreads();
+      const T* v_n = v + int64_t(n) * V * 3;
+      const int32_t* vi_n = vi + int64_t(n) * vi_sN;
 
-  const T* v_n = v + int64_t(n) * V * 3;
-  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+      // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively
+      const int begin = tile_offset[tile], end = tile_offset[tile + 1];
+      for (int i0 = begin + (tid & ~(kWave - 1)); i0 < end; i0 += kBlock) {
+        const int i = i0 + (tid & (kWave - 1));
+        int f = 0;
+        bool valid = false;
+        TriSetup<T> s = {};
+        if (i < end) {
+          f = pairs[i];
+          const uint2 r = tri_range[int64_t(n) * F + f]; // cheap pre-filter for sub-rectangles
+          (void)r;
+          valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
+          valid = valid && s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0;
+        }
+        if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf);
+      }
 
-  // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively
-  const int begin = tile_offset[tile], end = tile_offset[tile + 1];
-  for (int i0 = begin + (tid & ~(kWave - 1)); i0 < end; i0 += kBlock) {
-    const int i = i0 + (tid & (kWave - 1));
-    int f = 0;
-    bool valid = false;
-    TriSetup<T> s = {};
-    if (i < end) {
-      f = pairs[i];
-      valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
-    }
-    raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf);
-  }
+      // big triangles (more than kMaxSmallTiles tiles): per-view list, filtered by tile range
+      const int nbig = big_count[n];
+      const int32_t* big_n = big_list + int64_t(n) * F;
+      const uint2* range_n = tri_range + int64_t(n) * F;
+      for (int i0 = (tid & ~(kWave - 1)); i0 < nbig; i0 += kBlock) {
+        const int i = i0 + (tid & (kWave - 1));
+        int f = 0;
+        bool valid = false;
+        TriSetup<T> s = {};
+        if (i < nbig) {
+          f = big_n[i];
+          const uint2 r = range_n[f];
+          const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = r.y >> 16;
+          if (tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1) {
+            valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
+            valid = valid && s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0;
+          }
+        }
+        if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf);
+      }
+      __syncthreads();
 
-  // big triangles (more than kMaxSmallTiles tiles): per-view list, filtered by tile range
-  const int nbig = big_count[n];
-  const int32_t* big_n = big_list + int64_t(n) * F;
-  const uint2* range_n = tri_range + int64_t(n) * F;
-  for (int i0 = (tid & ~(kWave - 1)); i0 < nbig; i0 += kBlock) {
-    const int i = i0 + (tid & (kWave - 1));
-    int f = 0;
-    bool valid = false;
-    TriSetup<T> s = {};
-    if (i < nbig) {
-      f = big_n[i];
-      const uint2 r = range_n[f];
-      const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = r.y >> 16;
-      if (tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1)
-        valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
-    }
-    if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf);
-  }
-  __syncthreads();
-
-  // unpack + store (rasterize_kernel.cu:402-415)
-  const int64_t img_base = int64_t(n) * H * W;
-  const bool vec_ok = (W & 3) == 0;
-  for (int q = tid; q < NPIX / 4; q += kBlock) {
-    const int row = q >> (TILE_SHIFT - 2);
-    const int col = (q & ((TILE >> 2) - 1)) << 2;
-    const int y = y0 + row, x = x0 + col;
-    if (y > y1 || x > x1) continue;
-    int32_t idx4[4];
-    float dep4[4];
+      // unpack + store (rasterize_kernel.cu:402-415)
+      const int64_t img_base = int64_t(n) * H * W;
+      const bool vec_ok = (W & 3) == 0;
+      const int quads_per_row = ss >> 2;
+      for (int q = tid; q < rows * quads_per_row; q += kBlock) {
+        const int row = q / quads_per_row;
+        const int col = (q - row * quads_per_row) << 2;
+        const int y = y0 + row, x = x0 + col;
+        if (x > x1) continue;
+        int32_t idx4[4];
+        float dep4[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned long long pv = zbuf[(row << TILE_SHIFT) + col + j];
-      const uint32_t hi = static_cast<uint32_t>(pv >> 32);
-      dep4[j] = (hi == 0xFFFFFFFFu) ? 0.0f : __uint_as_float(hi);
-      idx4[j] = static_cast<int32_t>(static_cast<uint32_t>(pv & 0xFFFFFFFFu));
-    }
-    const int64_t o = img_base + int64_t(y) * W + x;
-    if (vec_ok) { // x % 4 == 0 and W % 4 == 0 -> x+3 < W and 16-byte aligned
-      *reinterpret_cast<int4*>(index_img + o) = make_int4(idx4[0], idx4[1], idx4[2], idx4[3]);
-      *reinterpret_cast<float4*>(depth_img + o) = make_float4(dep4[0], dep4[1], dep4[2], dep4[3]);
-    } else {
+        for (int j = 0; j < 4; ++j) {
+          const unsigned long long pv = zbuf[(row << TILE_SHIFT) + col + j];
+          const uint32_t hi = static_cast<uint32_t>(pv >> 32);
+          dep4[j] = (hi == 0xFFFFFFFFu) ? 0.0f : __uint_as_float(hi);
+          idx4[j] = static_cast<int32_t>(static_cast<uint32_t>(pv & 0xFFFFFFFFu));
+        }
+        const int64_t o = img_base + int64_t(y) * W + x;
+        if (vec_ok) { // x % 4 == 0 and W % 4 == 0 -> x+3 < W and 16-byte aligned
+          *reinterpret_cast<int4*>(index_img + o) = make_int4(idx4[0], idx4[1], idx4[2], idx4[3]);
+          *reinterpret_cast<float4*>(depth_img + o) = make_float4(dep4[0], dep4[1], dep4[2], dep4[3]);
+        } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (x + j <= x1) {
-          index_img[o + j] = idx4[j];
-          depth_img[o + j] = dep4[j];
+          for (int j = 0; j < 4; ++j) {
+            if (x + j <= x1) {
+              index_img[o + j] = idx4[j];
+              depth_img[o + j] = dep4[j];
+            }
+          }
         }
       }
     }
+    __syncthreads(); // zbuf and s_item are reused by the next item
   }
 }
 
@@ -518,6 +591,8 @@ int rasterize_impl(
   auto* tri_range = reinterpret_cast<uint2*>(ws + L.off_range);
   auto* big_list = reinterpret_cast<int32_t*>(ws + L.off_big_list);
   auto* pairs = reinterpret_cast<int32_t*>(ws + L.off_pairs);
+  auto* items = reinterpret_cast<uint32_t*>(ws + L.off_items);
+  auto* queue = reinterpret_cast<int32_t*>(ws + L.off_queue);
 
   if (hipMemsetAsync(ws, 0, L.zero_bytes, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
   const int64_t total = N * F;
@@ -530,7 +605,8 @@ int rasterize_impl(
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   hipLaunchKernelGGL(
-      bin_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_count, tile_offset, (int)L.num_tiles);
+      bin_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_count, tile_offset, (int)L.num_tiles,
+      L.tile_shift, items, queue);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   if (total > 0) {
     hipLaunchKernelGGL(
@@ -538,17 +614,19 @@ int rasterize_impl(
         (int)L.tiles_per_view, tile_offset, tile_cursor, pairs);
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
-  const unsigned tiles = static_cast<unsigned>(L.num_tiles);
+  // persistent workgroups pulling work items: as many as can be resident, never more than items
+  const int64_t resident = int64_t(num_compute_units()) * (L.tile_shift == 6 ? 5 : 8);
+  const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(L.max_items, resident));
   if (L.tile_shift == 6) {
     hipLaunchKernelGGL(
-        (tile_raster_kernel<T, 6>), dim3(tiles), dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN,
+        (tile_raster_kernel<T, 6>), dim3(blocks), dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN,
         (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, pairs, big_count, big_list,
-        tri_range, depth_img, index_img);
+        tri_range, items, queue, depth_img, index_img);
   } else {
     hipLaunchKernelGGL(
-        (tile_raster_kernel<T, 5>), dim3(tiles), dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN,
+        (tile_raster_kernel<T, 5>), dim3(blocks), dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN,
         (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, pairs, big_count, big_list,
-        tri_range, depth_img, index_img);
+        tri_range, items, queue, depth_img, index_img);
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
