@@ -500,16 +500,18 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
       const int32_t* vi_n = vi + int64_t(n) * vi_sN;
 
       // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively
-      const int begin = tile_offset[tile], end = tile_offset[tile + 1];
-      for (int i0 = begin + (tid & ~(kWave - 1)); i0 < end; i0 += kBlock) {
+      // the list is cut into 4 equal parts, one per wave, so that the waves reach the barrier together
+      const int begin = tile_offset[tile], end_all = tile_offset[tile + 1];
+      const int per_wave = (end_all - begin + kBlock / kWave - 1) / (kBlock / kWave);
+      const int wave_begin = begin + (tid / kWave) * per_wave;
+      const int end = min(wave_begin + per_wave, end_all);
+      for (int i0 = wave_begin; i0 < end; i0 += kWave) {
         const int i = i0 + (tid & (kWave - 1));
         int f = 0;
         bool valid = false;
         TriSetup<T> s = {};
         if (i < end) {
           f = pairs[i];
-          const uint2 r = tri_range[int64_t(n) * F + f]; // cheap pre-filter for sub-rectangles
-          (void)r;
           valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
           valid = valid && s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0;
         }
@@ -520,12 +522,14 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
       const int nbig = big_count[n];
       const int32_t* big_n = big_list + int64_t(n) * F;
       const uint2* range_n = tri_range + int64_t(n) * F;
-      for (int i0 = (tid & ~(kWave - 1)); i0 < nbig; i0 += kBlock) {
+      const int big_per_wave = (nbig + kBlock / kWave - 1) / (kBlock / kWave);
+      const int big_begin = (tid / kWave) * big_per_wave, big_end = min(big_begin + big_per_wave, nbig);
+      for (int i0 = big_begin; i0 < big_end; i0 += kWave) {
         const int i = i0 + (tid & (kWave - 1));
         int f = 0;
         bool valid = false;
         TriSetup<T> s = {};
-        if (i < nbig) {
+        if (i < big_end) {
           f = big_n[i];
           const uint2 r = range_n[f];
           const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = r.y >> 16;
