@@ -275,6 +275,56 @@ __device__ __forceinline__ void eval_pair(
   }
 }
 
+// Output of one pixel that takes part in at least one pair with differing indices ("edge pixel").
+// ic/ir/id/il/iu: indices of the pixel and its right/down/left/up neighbours, already forced equal
+// to ic where the pair is outside the reference's stencil domain.
+template <typename T>
+__device__ __forceinline__ void edge_pixel(
+    const T* __restrict__ v_n, const int32_t* __restrict__ vi_n, const T* __restrict__ gdx_n,
+    const T* __restrict__ gdy_n, int64_t pix, int x, int y, int W, int32_t ic, int32_t ir, int32_t id,
+    int32_t il, int32_t iu, T M, T& ox, T& oy, T& oz) {
+  T cx = T(0), cy = T(0), cz = T(0); // own centre contributions (gc)
+  T rx = T(0), rz = T(0);            // as right pixel of the left neighbour's stencil (gr)
+  T dy = T(0), dz = T(0);            // as down pixel of the upper neighbour's stencil (gd)
+  TriInfo<T> tc;
+  load_tri<T>(v_n, vi_n, ic, tc);
+  T gA, zA, gB, zB;
+  if (ic != ir) {
+    TriInfo<T> tn;
+    load_tri<T>(v_n, vi_n, ir, tn);
+    eval_pair<T, 0>(v_n, tc, tn, ic, ir, x, y, gdx_n[pix], M, gA, zA, gB, zB);
+    cx += gA;
+    cz += zA;
+  }
+  if (ic != id) {
+    TriInfo<T> tn;
+    load_tri<T>(v_n, vi_n, id, tn);
+    eval_pair<T, 1>(v_n, tc, tn, ic, id, x, y, gdy_n[pix], M, gA, zA, gB, zB);
+    cy += gA;
+    cz += zA;
+  }
+  if (il != ic) {
+    TriInfo<T> tn;
+    load_tri<T>(v_n, vi_n, il, tn);
+    eval_pair<T, 0>(v_n, tn, tc, il, ic, x - 1, y, gdx_n[pix - 1], M, gA, zA, gB, zB);
+    rx += gB;
+    rz += zB;
+  }
+  if (iu != ic) {
+    TriInfo<T> tn;
+    load_tri<T>(v_n, vi_n, iu, tn);
+    eval_pair<T, 1>(v_n, tn, tc, iu, ic, x, y - 1, gdy_n[pix - W], M, gA, zA, gB, zB);
+    dy += gB;
+    dz += zB;
+  }
+  // edge_grad_kernel.cu:427-445 negates and accumulates; order = the single-threaded reference
+  // order (upper neighbour's stencil, left neighbour's stencil, own stencil).
+  ox = (T(0) + (-rx)) + (-cx);
+  oy = (T(0) + (-dy)) + (-cy);
+  oz = ((T(0) + (-dz)) + (-rz)) + (-cz);
+}
+
+// Generic fallback (any W): one pixel per lane.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void edge_gather_kernel(
     const T* __restrict__ v_pix, const int32_t* __restrict__ vi,
@@ -287,65 +337,141 @@ __global__ __launch_bounds__(kBlock) void edge_gather_kernel(
   const int y = static_cast<int>(pix / W);
   const int x = static_cast<int>(pix - int64_t(y) * W);
   const int32_t* idx_n = index_img + int64_t(n) * HW;
-  const T* v_n = v_pix + int64_t(n) * V * 3;
-  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
-  const T* gdx_n = gdx + int64_t(n) * HW;
-  const T* gdy_n = gdy + int64_t(n) * HW;
 
   // stencil domain of the reference: centres with x < W-1 && y < H-1 (edge_grad_kernel.cu:270)
   const bool own = (x < W - 1) && (y < H - 1);
   const bool left = (x >= 1) && (y < H - 1); // pair (x-1,y)-(x,y), centre (x-1,y)
   const bool up = (y >= 1) && (x < W - 1);   // pair (x,y-1)-(x,y), centre (x,y-1)
-
   const int32_t ic = idx_n[pix];
   const int32_t ir = own ? idx_n[pix + 1] : ic;
   const int32_t id = own ? idx_n[pix + W] : ic;
   const int32_t il = left ? idx_n[pix - 1] : ic;
   const int32_t iu = up ? idx_n[pix - W] : ic;
-
-  T cx = T(0), cy = T(0), cz = T(0); // own centre contributions (gc)
-  T rx = T(0), rz = T(0);            // as right pixel of the left neighbour's stencil (gr)
-  T dy = T(0), dz = T(0);            // as down pixel of the upper neighbour's stencil (gd)
-
+  T ox = T(0), oy = T(0), oz = T(0);
   if (ic != ir || ic != id || ic != il || ic != iu) {
-    TriInfo<T> tc;
-    load_tri<T>(v_n, vi_n, ic, tc);
-    T gA, zA, gB, zB;
-    if (ic != ir) {
-      TriInfo<T> tn;
-      load_tri<T>(v_n, vi_n, ir, tn);
-      eval_pair<T, 0>(v_n, tc, tn, ic, ir, x, y, gdx_n[pix], M, gA, zA, gB, zB);
-      cx += gA;
-      cz += zA;
-    }
-    if (ic != id) {
-      TriInfo<T> tn;
-      load_tri<T>(v_n, vi_n, id, tn);
-      eval_pair<T, 1>(v_n, tc, tn, ic, id, x, y, gdy_n[pix], M, gA, zA, gB, zB);
-      cy += gA;
-      cz += zA;
-    }
-    if (il != ic) {
-      TriInfo<T> tn;
-      load_tri<T>(v_n, vi_n, il, tn);
-      eval_pair<T, 0>(v_n, tn, tc, il, ic, x - 1, y, gdx_n[pix - 1], M, gA, zA, gB, zB);
-      rx += gB;
-      rz += zB;
-    }
-    if (iu != ic) {
-      TriInfo<T> tn;
-      load_tri<T>(v_n, vi_n, iu, tn);
-      eval_pair<T, 1>(v_n, tn, tc, iu, ic, x, y - 1, gdy_n[pix - W], M, gA, zA, gB, zB);
-      dy += gB;
-      dz += zB;
+    edge_pixel<T>(
+        v_pix + int64_t(n) * V * 3, vi + int64_t(n) * vi_sN, gdx + int64_t(n) * HW, gdy + int64_t(n) * HW, pix,
+        x, y, W, ic, ir, id, il, iu, M, ox, oy, oz);
+  }
+  T* o = out + int64_t(n) * 3 * HW + pix;
+  o[0] = ox;
+  o[HW] = oy;
+  o[2 * HW] = oz;
+}
+
+// W % 4 == 0: a wave owns 256 consecutive pixels (4 per lane, 16-byte index loads and output
+// stores).  Only ~1 pixel in 5 is an edge pixel, scattered, so running the heavy classification
+// per lane-pixel would execute it for every wave at ~20 % lane utilisation; instead the edge
+// pixels of the 256 are COMPACTED (ballot + popcount ranks -> LDS list) and classified 64 at a
+// time at near-full utilisation; results go through an LDS tile and leave as dense float4 stores.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
+    const T* __restrict__ v_pix, const int32_t* __restrict__ vi,
+    const int32_t* __restrict__ index_img, const T* __restrict__ gdx, const T* __restrict__ gdy,
+    int64_t V, int64_t vi_sN, int H, int W, T M, T* __restrict__ out) {
+  using V4 = typename Vec4<T>::type;
+  constexpr int kWaves = kBlock / kWave;
+  constexpr int kPix = kWave * 4;
+  __shared__ __attribute__((aligned(16))) T s_out[kWaves][3][kPix];
+  __shared__ uint16_t s_list[kWaves][kPix];
+  __shared__ int32_t s_nb[kWaves][4][kPix]; // right/down/left/up neighbour index per pixel
+
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  const int64_t wave_pix0 = (int64_t(blockIdx.x) * kWaves + wave) * kPix;
+  if (wave_pix0 >= HW) return;
+  const int64_t pix0 = wave_pix0 + lane * 4;
+  const bool in_range = pix0 < HW;
+  const int32_t* idx_n = index_img + int64_t(n) * HW;
+  const int y = in_range ? static_cast<int>(pix0 / W) : 0;
+  const int x0 = in_range ? static_cast<int>(pix0 - int64_t(y) * W) : 0;
+
+  int32_t c[4] = {-1, -1, -1, -1}, u[4], d[4];
+  if (in_range) {
+    const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0);
+    c[0] = q.x, c[1] = q.y, c[2] = q.z, c[3] = q.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u[j] = d[j] = c[j];
+  if (in_range && y >= 1) {
+    const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0 - W);
+    u[0] = q.x, u[1] = q.y, u[2] = q.z, u[3] = q.w;
+  }
+  if (in_range && y < H - 1) {
+    const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0 + W);
+    d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w;
+  }
+  // horizontal neighbours across lanes: previous lane's last / next lane's first pixel
+  int32_t lprev = __shfl_up(c[3], 1), rnext = __shfl_down(c[0], 1);
+  if (in_range && lane == 0 && x0 >= 1) lprev = idx_n[pix0 - 1];
+  if (in_range && lane == kWave - 1 && x0 + 4 < W) rnext = idx_n[pix0 + 4];
+
+  bool e[4];
+  int32_t nr[4], nd[4], nl[4], nu[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int x = x0 + j;
+    // stencil domain of the reference: centres with x < W-1 && y < H-1 (edge_grad_kernel.cu:270)
+    const bool own = in_range && (x < W - 1) && (y < H - 1);
+    const bool left = in_range && (x >= 1) && (y < H - 1);
+    const bool up = in_range && (y >= 1) && (x < W - 1);
+    nr[j] = own ? (j < 3 ? c[(j + 1) & 3] : rnext) : c[j];
+    nd[j] = own ? d[j] : c[j];
+    nl[j] = left ? (j > 0 ? c[(j + 3) & 3] : lprev) : c[j];
+    nu[j] = up ? u[j] : c[j];
+    e[j] = c[j] != nr[j] || c[j] != nd[j] || c[j] != nl[j] || c[j] != nu[j];
+  }
+
+  // zero the output tile, publish neighbour indices, compact the edge pixels
+  const V4 zero4 = V4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) *reinterpret_cast<V4*>(&s_out[wave][k][lane * 4]) = zero4;
+  *reinterpret_cast<int4*>(&s_nb[wave][0][lane * 4]) = make_int4(nr[0], nr[1], nr[2], nr[3]);
+  *reinterpret_cast<int4*>(&s_nb[wave][1][lane * 4]) = make_int4(nd[0], nd[1], nd[2], nd[3]);
+  *reinterpret_cast<int4*>(&s_nb[wave][2][lane * 4]) = make_int4(nl[0], nl[1], nl[2], nl[3]);
+  *reinterpret_cast<int4*>(&s_nb[wave][3][lane * 4]) = make_int4(nu[0], nu[1], nu[2], nu[3]);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int total = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned long long m = __ballot(e[j]);
+    if (e[j]) s_list[wave][total + __popcll(m & lt)] = static_cast<uint16_t>(lane * 4 + j);
+    total += __popcll(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+
+  const T* v_n = v_pix + int64_t(n) * V * 3;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  const T* gdx_n = gdx + int64_t(n) * HW;
+  const T* gdy_n = gdy + int64_t(n) * HW;
+  for (int t0 = 0; t0 < total; t0 += kWave) {
+    const int t = t0 + lane;
+    if (t < total) {
+      const int local = s_list[wave][t];
+      const int64_t pix = wave_pix0 + local;
+      const int py = static_cast<int>(pix / W);
+      const int px = static_cast<int>(pix - int64_t(py) * W);
+      const int32_t ic = idx_n[pix];
+      T ox, oy, oz;
+      edge_pixel<T>(
+          v_n, vi_n, gdx_n, gdy_n, pix, px, py, W, ic, s_nb[wave][0][local], s_nb[wave][1][local],
+          s_nb[wave][2][local], s_nb[wave][3][local], M, ox, oy, oz);
+      s_out[wave][0][local] = ox;
+      s_out[wave][1][local] = oy;
+      s_out[wave][2][local] = oz;
     }
   }
-  // edge_grad_kernel.cu:427-445 negates and accumulates; order = the single-threaded reference
-  // order (upper neighbour's stencil, left neighbour's stencil, own stencil).
-  T* o = out + int64_t(n) * 3 * HW + pix;
-  o[0] = (T(0) + (-rx)) + (-cx);
-  o[HW] = (T(0) + (-dy)) + (-cy);
-  o[2 * HW] = ((T(0) + (-dz)) + (-rz)) + (-cz);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (in_range) {
+    T* o = out + int64_t(n) * 3 * HW + pix0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<V4*>(o + int64_t(k) * HW) = *reinterpret_cast<const V4*>(&s_out[wave][k][lane * 4]);
+  }
 }
 
 constexpr int kStripRows = 2; // rows per wave; a workgroup covers 4x that
@@ -372,8 +498,15 @@ int edge_grad_backward_impl(
     hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows>), gridA, dim3(kBlock), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
-  const dim3 gridB(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
-  hipLaunchKernelGGL((edge_gather_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out);
+  const bool vec_out = vec && (reinterpret_cast<uintptr_t>(index_img) % 16 == 0) &&
+      (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0);
+  if (vec_out) {
+    const dim3 gridB(static_cast<unsigned>(ceil_div(HW, kBlock * 4)), static_cast<unsigned>(N));
+    hipLaunchKernelGGL((edge_gather4_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out);
+  } else {
+    const dim3 gridB(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
+    hipLaunchKernelGGL((edge_gather_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out);
+  }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }
