@@ -175,6 +175,22 @@ def cpu_baseline(v_pix, vi, attr, H, W, n_views, min_seconds=10.0):
     }
 
 
+class _MeanSquare(th.autograd.Function):
+    """User-side loss term mean(x^2), written so that forward is ONE reduction pass and backward ONE
+    scaling pass over x (plain `(x*x).mean()` or `vector_norm(x)**2/n` cost 2-4 extra passes over the
+    2 GB image in eager PyTorch).  Same value, same gradient 2*x/n."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return th.linalg.vector_norm(x).square() / x.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return x * (g * (2.0 / x.numel()))
+
+
 def main():
     args = parse()
     from drtk_amd import dist as ddist
@@ -183,7 +199,8 @@ def main():
 
     rank, world, local_rank = ddist.init_from_env()
     assert th.cuda.is_available(), "bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)"
-    dev = th.device("cuda", local_rank)
+    # DRTK_FORCE_DEVICE: test-only (several ranks on one GPU with DRTK_DIST_BACKEND=gloo)
+    dev = th.device("cuda", int(os.environ.get("DRTK_FORCE_DEVICE", local_rank)))
     th.cuda.set_device(dev)
     import drtk_amd
 
@@ -213,7 +230,7 @@ def main():
         # loss = mean(img^2) + mean(depth), written with the cheapest equivalent torch ops
         img = th.where((index_img != -1)[:, None], img, 0.0)
         img = drtk_amd.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
-        loss = th.linalg.vector_norm(img).square() / img.numel() + depth_img.mean()
+        loss = _MeanSquare.apply(img) + depth_img.mean()
         loss.backward()
         reducer.all_reduce()
         v_world.grad = None

@@ -26,7 +26,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if th.cuda.is_available() else "gloo"
+            # DRTK_DIST_BACKEND=gloo lets the multi-rank code path be exercised on a single-GPU box
+            backend = os.environ.get("DRTK_DIST_BACKEND") or ("nccl" if th.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
