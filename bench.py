@@ -124,6 +124,7 @@ def time_kernels(v_pix, vi, attr, H, W, reps):
     out["interpolate"] = timed(lambda: capi.interpolate(attr, vi, index, bary))
     out["interpolate_vpix"] = timed(lambda: capi.interpolate(v_pix, vi, index, bary))
     out["edge_grad_backward"] = timed(lambda: capi.edge_grad_backward(v_pix, img, index, vi, go, workspace=ws_e))
+    out["edge_grad_backward_fused"] = timed(lambda: capi.edge_grad_backward_fused(v_pix, img, index, vi, bary, go))
     eg = capi.edge_grad_backward(v_pix, img, index, vi, go)
     out["interpolate_backward_vpix"] = timed(lambda: capi.interpolate_backward(eg, v_pix, vi, index, bary, True, False))
     out["interpolate_backward"] = timed(lambda: capi.interpolate_backward(go, attr, vi, index, bary, True, True))

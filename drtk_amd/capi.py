@@ -46,6 +46,8 @@ EXPORTS = [
     "drtk_amd_interpolate_backward",
     "drtk_amd_edge_grad_backward_workspace_bytes",
     "drtk_amd_edge_grad_backward",
+    "drtk_amd_edge_grad_backward_fused_workspace_bytes",
+    "drtk_amd_edge_grad_backward_fused",
     "drtk_amd_debug_set_flags",
 ]
 
@@ -208,4 +210,29 @@ def edge_grad_backward(v_pix, img, index_img, vi, grad_output, max_dp_dr=1e4, st
             _i(C), _i(F), _i(vi_sN), _i(H), _i(W), ctypes.c_double(max_dp_dr), _p(out), _p(ws),
             ctypes.c_size_t(ws.numel()), _stream(v_pix, stream)),
         "edge_grad_backward")
+    return out
+
+
+def edge_grad_backward_fused(v_pix, img, index_img, vi, bary_img, grad_output, max_dp_dr=1e4, stream=None):
+    """grad_v_pix [N,V,3] = interpolate_backward(edge_grad_backward(...), v_pix, ...) in one call."""
+    v_pix = v_pix.contiguous()
+    img = img.contiguous()
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    grad_output = grad_output.contiguous()
+    N, V, _ = v_pix.shape
+    C, H, W = img.shape[1:]
+    vi_c, vi_sN, F = _vi(vi, N)
+    out = th.empty(N, V, 3, dtype=v_pix.dtype, device=v_pix.device)
+    nb = ctypes.c_size_t(0)
+    code = DRTK_F32 if v_pix.dtype == th.float32 else DRTK_F64
+    _check(lib().drtk_amd_edge_grad_backward_fused_workspace_bytes(ctypes.c_int(code), _i(N), _i(H), _i(W), ctypes.byref(nb)),
+           "edge_grad_backward_fused")
+    ws = th.empty(nb.value, dtype=th.uint8, device=v_pix.device)
+    _check(
+        lib().drtk_amd_edge_grad_backward_fused(
+            ctypes.c_int(_dt(v_pix)), _p(v_pix), _p(img), _p(index_img), _p(vi_c), _p(bary_img), _p(grad_output),
+            _i(N), _i(V), _i(C), _i(F), _i(vi_sN), _i(H), _i(W), ctypes.c_double(max_dp_dr), _p(out), _p(ws),
+            ctypes.c_size_t(ws.numel()), _stream(v_pix, stream)),
+        "edge_grad_backward_fused")
     return out

@@ -17,6 +17,7 @@
 //      contributions in the single-threaded reference order.
 // Pairs are classified twice (once by each member), which costs ALU only.
 #include "common.hpp"
+#include "segscatter.hpp"
 
 namespace drtk_amd {
 namespace {
@@ -282,12 +283,15 @@ template <typename T>
 __device__ __forceinline__ void edge_pixel(
     const T* __restrict__ v_n, const int32_t* __restrict__ vi_n, const T* __restrict__ gdx_n,
     const T* __restrict__ gdy_n, int64_t pix, int x, int y, int W, int32_t ic, int32_t ir, int32_t id,
-    int32_t il, int32_t iu, T M, T& ox, T& oy, T& oz) {
+    int32_t il, int32_t iu, T M, T& ox, T& oy, T& oz, int32_t* centre_vids = nullptr) {
   T cx = T(0), cy = T(0), cz = T(0); // own centre contributions (gc)
   T rx = T(0), rz = T(0);            // as right pixel of the left neighbour's stencil (gr)
   T dy = T(0), dz = T(0);            // as down pixel of the upper neighbour's stencil (gd)
   TriInfo<T> tc;
   load_tri<T>(v_n, vi_n, ic, tc);
+  if (centre_vids) {
+    centre_vids[0] = tc.i0, centre_vids[1] = tc.i1, centre_vids[2] = tc.i2;
+  }
   T gA, zA, gB, zB;
   if (ic != ir) {
     TriInfo<T> tn;
@@ -474,6 +478,151 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
   }
 }
 
+// Fused pass B for the default route of drtk.edge_grad_estimator (no v_pix_img hook): instead of
+// materialising grad_v_pix_img [N,3,H,W] (80 % exact zeros) for a separate C=3 interpolate backward to
+// scatter, the edge pixels are compacted as in edge_gather4_kernel and their three gradient components
+// are multiplied by the pixel's barycentrics and scattered to the triangle's vertices right away,
+// through the run reduction + wave-private vertex table of segscatter.hpp.  A wave owns a
+// 256 x 4 pixel tile.  (edge_grad_estimator.py:168-176 + interpolate_kernel.cu:271-279 fused.)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void edge_scatter4_kernel(
+    const T* __restrict__ v_pix, const int32_t* __restrict__ vi,
+    const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, const T* __restrict__ gdx,
+    const T* __restrict__ gdy, int64_t V, int64_t vi_sN, int H, int W, int strips_x, T M,
+    T* __restrict__ grad_v_pix) {
+  using V4 = typename Vec4<T>::type;
+  constexpr int kWaves = kBlock / kWave;
+  constexpr int kRows = 4;
+  __shared__ uint16_t s_list[kWaves][kWave * 4];
+  __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
+  __shared__ int32_t s_vid[kWaves][3 * kRunPad];
+  __shared__ int32_t s_slot[kWaves][3 * kRunPad];
+  __shared__ int32_t t_keys[kWaves][kTableSlots];
+  __shared__ T t_vals[kWaves][kTableSlots * 4];
+
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  const int wg = blockIdx.x * kWaves + wave;
+  const int ry = wg / strips_x, sx = wg - ry * strips_x;
+  const int y_base = ry * kRows;
+  if (y_base >= H) return;
+  const int x0 = (sx * kWave + lane) * 4;
+  const bool in_x = x0 < W;
+  const int32_t* idx_n = index_img + int64_t(n) * HW;
+  const T* v_n = v_pix + int64_t(n) * V * 3;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  const T* gdx_n = gdx + int64_t(n) * HW;
+  const T* gdy_n = gdy + int64_t(n) * HW;
+  const T* bary_n = bary_img + int64_t(n) * 3 * HW;
+  T* grad_n = grad_v_pix + int64_t(n) * V * 3;
+
+  table_init(t_keys[wave]);
+  for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = T(0);
+  wave_lds_sync();
+
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll 1
+  for (int r = 0; r < kRows; ++r) {
+    const int y = y_base + r;
+    if (y >= H) break;
+    const int64_t pix0 = int64_t(y) * W + x0;
+    int32_t c[4] = {-1, -1, -1, -1}, u[4], d[4];
+    if (in_x) {
+      const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0);
+      c[0] = q.x, c[1] = q.y, c[2] = q.z, c[3] = q.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = d[j] = c[j];
+    if (in_x && y >= 1) {
+      const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0 - W);
+      u[0] = q.x, u[1] = q.y, u[2] = q.z, u[3] = q.w;
+    }
+    if (in_x && y < H - 1) {
+      const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0 + W);
+      d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w;
+    }
+    int32_t lprev = __shfl_up(c[3], 1), rnext = __shfl_down(c[0], 1);
+    if (in_x && lane == 0 && x0 >= 1) lprev = idx_n[pix0 - 1];
+    if (in_x && lane == kWave - 1 && x0 + 4 < W) rnext = idx_n[pix0 + 4];
+
+    // edge flags (same stencil domain as edge_gather4_kernel) and pixel-ordered compaction
+    bool e[4];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = x0 + j;
+      const bool own = in_x && (x < W - 1) && (y < H - 1);
+      const bool left = in_x && (x >= 1) && (y < H - 1);
+      const bool up = in_x && (y >= 1) && (x < W - 1);
+      const int32_t nr = own ? (j < 3 ? c[(j + 1) & 3] : rnext) : c[j];
+      const int32_t nd = own ? d[j] : c[j];
+      const int32_t nl = left ? (j > 0 ? c[(j + 3) & 3] : lprev) : c[j];
+      const int32_t nu = up ? u[j] : c[j];
+      e[j] = c[j] != nr || c[j] != nd || c[j] != nl || c[j] != nu;
+      cnt += e[j] ? 1 : 0;
+    }
+    // exclusive prefix of cnt (0..4) over the lanes from three ballots
+    const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+    int pos = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+    const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (e[j]) s_list[wave][pos++] = static_cast<uint16_t>(lane * 4 + j);
+    }
+    wave_lds_sync();
+
+    for (int t0 = 0; t0 < total; t0 += kWave) {
+      const int t = t0 + lane;
+      const bool act = t < total;
+      int32_t ic = -1;
+      T g[3] = {T(0), T(0), T(0)};
+      T B[3] = {T(0), T(0), T(0)};
+      int32_t vid[3] = {0, 0, 0};
+      if (act) {
+        const int local = s_list[wave][t];
+        const int px = sx * (kWave * 4) + local;
+        const int64_t pix = int64_t(y) * W + px;
+        ic = idx_n[pix];
+        if (ic >= 0) { // background pixels never receive a gradient
+          const bool own = (px < W - 1) && (y < H - 1);
+          const bool left = (px >= 1) && (y < H - 1);
+          const bool up = (y >= 1) && (px < W - 1);
+          const int32_t ir = own ? idx_n[pix + 1] : ic;
+          const int32_t id = own ? idx_n[pix + W] : ic;
+          const int32_t il = left ? idx_n[pix - 1] : ic;
+          const int32_t iu = up ? idx_n[pix - W] : ic;
+          edge_pixel<T>(v_n, vi_n, gdx_n, gdy_n, pix, px, y, W, ic, ir, id, il, iu, M, g[0], g[1], g[2], vid);
+          B[0] = bary_n[pix], B[1] = bary_n[HW + pix], B[2] = bary_n[2 * HW + pix];
+        }
+      }
+      const bool covered = ic >= 0;
+      const bool use_table = covered && vid[0] != vid[1] && vid[0] != vid[2] && vid[1] != vid[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) s_val[wave][(k * 3 + cc) * kRunPad + lane] = g[cc] * B[k];
+        s_vid[wave][k * kRunPad + lane] = vid[k];
+        s_slot[wave][k * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid[k]) : -1;
+      }
+      unsigned long long heads, cov;
+      run_masks(covered ? ic : -1, heads, cov);
+      wave_lds_sync();
+      if (cov != 0) {
+        const T* sv = s_val[wave];
+        scatter_runs<T>(
+            heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals[wave], 4, grad_n, 3, 0,
+            [sv](int k, int cc, int g4, T* x) {
+              const V4 q = *reinterpret_cast<const V4*>(sv + (k * 3 + cc) * kRunPad + 4 * g4);
+              x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
+            });
+      }
+      wave_lds_sync();
+    }
+  }
+  table_flush<T>(t_keys[wave], t_vals[wave], 4, 3, grad_n, 3, 0);
+}
+
 constexpr int kStripRows = 2; // rows per wave; a workgroup covers 4x that
 
 template <typename T>
@@ -509,6 +658,59 @@ int edge_grad_backward_impl(
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
+}
+
+// pass A shared by both routes
+template <typename T>
+int launch_edge_dots(const T* img, const T* grad_output, int64_t N, int64_t C, int64_t H, int64_t W, T* gdx, T* gdy, bool vec, hipStream_t stream) {
+  const int px_per_wave = kWave * (vec ? 4 : 1);
+  const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
+  const int bands_y = static_cast<int>(ceil_div(H, kStripRows * (kBlock / kWave)));
+  const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
+  if (vec) {
+    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows>), gridA, dim3(kBlock), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+  } else {
+    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows>), gridA, dim3(kBlock), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+  }
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}
+
+template <typename T>
+bool fused_vec_ok(const T* img, const T* grad_output, const int32_t* index_img, const void* workspace, int64_t W) {
+  return (W % 4 == 0) && (reinterpret_cast<uintptr_t>(img) % (4 * sizeof(T)) == 0) &&
+      (reinterpret_cast<uintptr_t>(grad_output) % (4 * sizeof(T)) == 0) &&
+      (reinterpret_cast<uintptr_t>(workspace) % (4 * sizeof(T)) == 0) &&
+      (reinterpret_cast<uintptr_t>(index_img) % 16 == 0);
+}
+
+template <typename T>
+int edge_grad_backward_fused_impl(
+    drtk_dtype_t dtype, const T* v_pix, const T* img, const int32_t* index_img, const int32_t* vi,
+    const T* bary_img, const T* grad_output, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN,
+    int64_t H, int64_t W, double max_dp_dr, T* grad_v_pix, void* workspace, size_t workspace_bytes,
+    hipStream_t stream) {
+  const int64_t HW = H * W;
+  if (N * V > 0 && hipMemsetAsync(grad_v_pix, 0, sizeof(T) * N * V * 3, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+  if (N * HW == 0) return DRTK_OK;
+  T* gdx = static_cast<T*>(workspace);
+  T* gdy = gdx + N * HW;
+  if (fused_vec_ok<T>(img, grad_output, index_img, workspace, W)) {
+    const int st = launch_edge_dots<T>(img, grad_output, N, C, H, W, gdx, gdy, true, stream);
+    if (st != DRTK_OK) return st;
+    const int strips_x = static_cast<int>(ceil_div(W, kWave * 4));
+    const int64_t waves = int64_t(strips_x) * ceil_div(H, 4);
+    const dim3 grid(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
+    hipLaunchKernelGGL((edge_scatter4_kernel<T>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix);
+    DRTK_RETURN_IF_LAUNCH_FAILED();
+    return DRTK_OK;
+  }
+  // generic sizes: the unfused route through a scratch grad_v_pix_img (needs 5 planes of workspace)
+  if (workspace_bytes < sizeof(T) * 5 * N * HW) return DRTK_ERR_WORKSPACE_TOO_SMALL;
+  T* tmp = gdy + N * HW;
+  int st = edge_grad_backward_impl<T>(v_pix, img, index_img, vi, grad_output, N, V, C, vi_sN, H, W, max_dp_dr, tmp, workspace, stream);
+  if (st != DRTK_OK) return st;
+  return drtk_amd_interpolate_backward(dtype, tmp, v_pix, vi, index_img, bary_img, N, V, 3, F, vi_sN, H, W, grad_v_pix, nullptr, stream);
 }
 
 } // namespace
@@ -547,6 +749,44 @@ extern "C" int drtk_amd_edge_grad_backward(
       return edge_grad_backward_impl<float>(static_cast<const float*>(v_pix), static_cast<const float*>(img), index_img, vi, static_cast<const float*>(grad_output), N, V, C, vi_sN, H, W, max_dp_dr, static_cast<float*>(grad_v_pix_img), workspace, s);
     case DRTK_F64:
       return edge_grad_backward_impl<double>(static_cast<const double*>(v_pix), static_cast<const double*>(img), index_img, vi, static_cast<const double*>(grad_output), N, V, C, vi_sN, H, W, max_dp_dr, static_cast<double*>(grad_v_pix_img), workspace, s);
+    default:
+      return DRTK_ERR_INVALID_ARGUMENT;
+  }
+}
+
+extern "C" int drtk_amd_edge_grad_backward_fused_workspace_bytes(
+    drtk_dtype_t dtype, int64_t N, int64_t H, int64_t W, size_t* bytes) {
+  if (!bytes || N < 0 || H < 0 || W < 0 || (dtype != DRTK_F32 && dtype != DRTK_F64)) return DRTK_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype == DRTK_F32 ? 4 : 8;
+  const size_t planes = (W % 4 == 0) ? 2 : 5;
+  const size_t b = planes * N * H * W * es;
+  *bytes = b > 0 ? b : 16;
+  return DRTK_OK;
+}
+
+extern "C" int drtk_amd_edge_grad_backward_fused(
+    drtk_dtype_t dtype, const void* v_pix, const void* img, const int32_t* index_img,
+    const int32_t* vi, const void* bary_img, const void* grad_output, int64_t N, int64_t V, int64_t C,
+    int64_t F, int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix,
+    void* workspace, size_t workspace_bytes, drtk_stream_t stream) {
+  if (N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || N > 65535 ||
+      (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31))
+    return DRTK_ERR_INVALID_ARGUMENT;
+  size_t need = 0;
+  if (drtk_amd_edge_grad_backward_fused_workspace_bytes(dtype, N, H, W, &need) != DRTK_OK) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * V > 0 && !grad_v_pix) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W > 0) {
+    if (!index_img || !bary_img || !workspace) return DRTK_ERR_INVALID_ARGUMENT;
+    if ((N * V > 0 && !v_pix) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
+    if (C > 0 && (!img || !grad_output)) return DRTK_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < need) return DRTK_ERR_WORKSPACE_TOO_SMALL;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case DRTK_F32:
+      return edge_grad_backward_fused_impl<float>(dtype, static_cast<const float*>(v_pix), static_cast<const float*>(img), index_img, vi, static_cast<const float*>(bary_img), static_cast<const float*>(grad_output), N, V, C, F, vi_sN, H, W, max_dp_dr, static_cast<float*>(grad_v_pix), workspace, workspace_bytes, s);
+    case DRTK_F64:
+      return edge_grad_backward_fused_impl<double>(dtype, static_cast<const double*>(v_pix), static_cast<const double*>(img), index_img, vi, static_cast<const double*>(bary_img), static_cast<const double*>(grad_output), N, V, C, F, vi_sN, H, W, max_dp_dr, static_cast<double*>(grad_v_pix), workspace, workspace_bytes, s);
     default:
       return DRTK_ERR_INVALID_ARGUMENT;
   }

@@ -118,6 +118,20 @@ int drtk_amd_edge_grad_backward(
     int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix_img, void* workspace,
     size_t workspace_bytes, drtk_stream_t stream);
 
+/* edge_grad_backward_fused  =  edge_grad_backward followed by the C=3 interpolate backward that
+ * drtk.edge_grad_estimator hangs behind it (drtk/edge_grad_estimator.py:168-176 + interpolate_kernel.cu
+ * :642-697), without materialising grad_v_pix_img: writes grad_v_pix [N,V,3] (zero-filled here) directly.
+ * Same values as the two calls (within float summation order).  Used by drtk_amd.edge_grad_estimator
+ * when no v_pix_img hook is registered.
+ */
+int drtk_amd_edge_grad_backward_fused_workspace_bytes(
+    drtk_dtype_t dtype, int64_t N, int64_t H, int64_t W, size_t* bytes);
+int drtk_amd_edge_grad_backward_fused(
+    drtk_dtype_t dtype, const void* v_pix, const void* img, const int32_t* index_img,
+    const int32_t* vi, const void* bary_img, const void* grad_output, int64_t N, int64_t V, int64_t C,
+    int64_t F, int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix,
+    void* workspace, size_t workspace_bytes, drtk_stream_t stream);
+
 /* Diagnostics for profiling scripts: a bit mask that switches single kernel phases off so that
  * their time can be attributed.  Results are WRONG while it is non-zero; default 0. */
 void drtk_amd_debug_set_flags(int flags);

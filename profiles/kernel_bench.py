@@ -38,6 +38,7 @@ kernels = {
     "render": lambda: capi.render(v, vi, index),
     "interpolate": lambda: capi.interpolate(attr, vi, index, bary),
     "edge_grad_backward": lambda: capi.edge_grad_backward(v, img, index, vi, go),
+    "edge_grad_backward_fused": lambda: capi.edge_grad_backward_fused(v, img, index, vi, bary, go),
     "interpolate_backward_vpix": lambda: capi.interpolate_backward(eg, v, vi, index, bary, True, False),
     "interpolate_backward": lambda: capi.interpolate_backward(go, attr, vi, index, bary, True, True),
     "render_backward": lambda: capi.render_backward(v, vi, index, gd, gb),

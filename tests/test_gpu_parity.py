@@ -58,6 +58,9 @@ def test_capi_matches_reference_fixture(name):
     close(capi.edge_grad_backward(v, img, gi, vi, dev(i["go"]), 0.0), o["edge_grad_noclamp"], "edge_grad backward M=0")
     vg, _ = capi.interpolate_backward(dev(o["edge_grad"]), v, vi, gi, gb, True, False)
     close(vg, o["v_pix_grad_from_edges"], "edge grads routed to v_pix")
+    # fused route (edge_grad backward + C=3 interpolate backward in one call)
+    close(capi.edge_grad_backward_fused(v, img, gi, vi, gb, dev(i["go"]), 1e4), o["v_pix_grad_from_edges"],
+          "fused edge grads routed to v_pix")
 
 
 @pytest.mark.parametrize("dtype", [th.float32, th.float64])
@@ -91,8 +94,11 @@ def test_capi_matches_oracle_on_seeded_scenes(dtype, shape):
     close(bg_g, bg_o, "bary grad")
     img = O.interpolate(attr, vi, i_o, rb_o, nthreads=0) * (i_o != -1)[:, None]
     for M in (1e4, 0.0):
-        close(capi.edge_grad_backward(dev(v), dev(img), i_g, dev(vi), dev(go), M),
-              O.edge_grad_backward(v, img, i_o, vi, go, M), f"edge grad M={M}")
+        eg_o = O.edge_grad_backward(v, img, i_o, vi, go, M)
+        close(capi.edge_grad_backward(dev(v), dev(img), i_g, dev(vi), dev(go), M), eg_o, f"edge grad M={M}")
+        vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False)
+        close(capi.edge_grad_backward_fused(dev(v), dev(img), i_g, dev(vi), dev(rb_o), dev(go), M), vg_o,
+              f"fused edge grad M={M}")
 
 
 def test_torch_ops_end_to_end_step_matches_reference():
@@ -173,6 +179,12 @@ def test_autograd_contracts():
     assert th.equal(res, img) and res.requires_grad
     (res * res).sum().backward()
     assert seen["g"].shape == (v.shape[0], 3, H, W) and vr2.grad is not None
+    # without a hook the fused route runs; gradients must agree with the hooked (reference-graph) route
+    vr3 = v.clone().requires_grad_(True)
+    res3 = ops.edge_grad_estimator(vr3, vi, b.detach(), img, index)
+    assert th.equal(res3, img)
+    (res3 * res3).sum().backward()
+    close(vr3.grad, vr2.grad, "fused vs unfused edge_grad_estimator", atol=1e-4)
     # vi may be [N,F,3] or [F,3]
     idx2 = ops.rasterize(v, vi[None].repeat(v.shape[0], 1, 1), H, W)
     assert th.equal(idx2, index)
