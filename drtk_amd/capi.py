@@ -48,6 +48,7 @@ EXPORTS = [
     "drtk_amd_edge_grad_backward",
     "drtk_amd_edge_grad_backward_fused_workspace_bytes",
     "drtk_amd_edge_grad_backward_fused",
+    "drtk_amd_selftest_exact_div",
     "drtk_amd_debug_set_flags",
 ]
 
@@ -236,3 +237,12 @@ def edge_grad_backward_fused(v_pix, img, index_img, vi, bary_img, grad_output, m
             ctypes.c_size_t(ws.numel()), _stream(v_pix, stream)),
         "edge_grad_backward_fused")
     return out
+
+
+def selftest_exact_div(dtype=th.float32, seed=1, count=1 << 28, device="cuda:0") -> int:
+    """Number of (n, d) pairs for which the rasterizer's exact division differs from IEEE `/` (must be 0)."""
+    out = th.zeros(1, dtype=th.int64, device=device)
+    code = DRTK_F32 if dtype == th.float32 else DRTK_F64
+    _check(lib().drtk_amd_selftest_exact_div(ctypes.c_int(code), ctypes.c_uint64(seed), _i(count), _p(out),
+                                             _stream(out, None)), "selftest_exact_div")
+    return int(out.item())

@@ -38,11 +38,54 @@ template <typename T>
 struct TriSetup {
   T p0x, p0y, p1x, p1y, p2x, p2y;
   T dinv0, dinv1, dinv2;
-  T sign_denom, abs_denom;
+  T sign_denom, abs_denom, rdenom; // rdenom = RN(1 / abs_denom)
   int bb_min_x, bb_min_y, bb_max_x, bb_max_y;
   bool c0, c1, c2;    // canonical edge orientation flags (vi_a <= vi_b)
   bool tl0, tl1, tl2; // top-left classification
 };
+
+// Correctly rounded n / d for 0 <= n, d > 0 from a precomputed r = RN(1/d) (IEEE division, once per
+// triangle): q0 = RN(n r); two Markstein corrections q <- fma(fma(-d, q, n), r, q).  After the first
+// correction q is a faithful rounding of n/d, and with r the correctly rounded reciprocal the second
+// one yields RN(n/d) exactly (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic,
+// Newton-Raphson division, final-rounding theorem) as long as nothing under/overflows -- which the
+// range guard ensures; outside it the IEEE division is used.  5 full-rate instructions instead of
+// the 11-instruction / 5 quarter-rate IEEE expansion, three times per fragment: the divisions were
+// ~60 % of the raster loop's issue cycles.  drtk_amd_selftest_exact_div() compares it with `/` on
+// the device over arbitrary many random operand pairs.
+template <typename T>
+struct DivRange;
+template <>
+struct DivRange<float> {
+  static __device__ constexpr float lo() { return 0x1p-60f; }
+  static __device__ constexpr float hi() { return 0x1p60f; }
+  static __device__ constexpr float tiny() { return 0x1p-100f; }
+};
+template <>
+struct DivRange<double> {
+  static __device__ constexpr double lo() { return 0x1p-500; }
+  static __device__ constexpr double hi() { return 0x1p500; }
+  static __device__ constexpr double tiny() { return 0x1p-900; }
+};
+__device__ __forceinline__ float fma_t(float a, float b, float c) {
+  return __builtin_fmaf(a, b, c);
+}
+__device__ __forceinline__ double fma_t(double a, double b, double c) {
+  return __builtin_fma(a, b, c);
+}
+template <typename T>
+__device__ __forceinline__ bool exact_div_ok(T d) {
+  return d >= DivRange<T>::lo() && d <= DivRange<T>::hi();
+}
+template <typename T>
+__device__ __forceinline__ T exact_div(T n, T d, T r, bool range_ok) {
+  const T q0 = n * r;
+  if (range_ok && (q0 >= DivRange<T>::tiny() || n == T(0))) {
+    const T q1 = fma_t(fma_t(-d, q0, n), r, q0);
+    return fma_t(fma_t(-d, q1, n), r, q1);
+  }
+  return n / d;
+}
 
 // Culling + bounding box only (used by the binning passes).  Returns false if the triangle is
 // dropped by the reference (:81 degenerate indices, :96 near plane, :97-98 off canvas, :107 zero
@@ -99,6 +142,7 @@ __device__ __forceinline__ bool tri_setup(
   if (den == T(0)) return false;
   s.sign_denom = den > T(0) ? T(1) : T(-1);
   s.abs_denom = den > T(0) ? den : -den;
+  s.rdenom = T(1) / s.abs_denom;
   s.bb_min_x = max(0, trunc_i32(min_x));
   s.bb_min_y = max(0, trunc_i32(min_y));
   s.bb_max_x = min(W - 1, static_cast<int32_t>(static_cast<uint32_t>(trunc_i32(max_x)) + 1u));
@@ -365,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(
 template <typename T>
 struct TriUniform {
   T ax[3], ay[3], dx[3], dy[3], s[3]; // edge k: ((py - ay) * dx - (px - ax) * dy) * s
-  T abs_denom, dinv0, dinv1, dinv2;
+  T abs_denom, rdenom, dinv0, dinv1, dinv2;
   int tl; // bit k: edge k is top-left
 };
 
@@ -425,6 +469,8 @@ __device__ __forceinline__ void raster_lanes(
       u.s[k] = bcast(es[k], j);
     }
     u.abs_denom = bcast(s.abs_denom, j);
+    u.rdenom = bcast(s.rdenom, j);
+    const bool div_ok = exact_div_ok(u.abs_denom);
     u.dinv0 = bcast(s.dinv0, j);
     u.dinv1 = bcast(s.dinv1, j);
     u.dinv2 = bcast(s.dinv2, j);
@@ -449,9 +495,9 @@ __device__ __forceinline__ void raster_lanes(
         T b2 = ((py - u.ay[2]) * u.dx[2] - ex[2]) * u.s[2];
         if (!((b0 >= T(0)) && (b1 >= T(0)) && (b2 >= T(0)))) continue;
         if ((!(u.tl & 1) && b0 == T(0)) || (!(u.tl & 2) && b1 == T(0)) || (!(u.tl & 4) && b2 == T(0))) continue;
-        b0 /= u.abs_denom;
-        b1 /= u.abs_denom;
-        b2 /= u.abs_denom;
+        b0 = exact_div(b0, u.abs_denom, u.rdenom, div_ok); // == b0 / abs_denom, rasterize_kernel.cu:148
+        b1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
+        b2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
         const T depth_inverse = u.dinv0 * b0 + u.dinv1 * b1 + u.dinv2 * b2;
         const float depth = static_cast<float>(T(1) / epsclamp(depth_inverse));
         const unsigned long long packed = (static_cast<unsigned long long>(__float_as_uint(depth)) << 32) | id;
@@ -579,6 +625,44 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
   }
 }
 
+// Diagnostics: exact_div against the IEEE division on pseudo-random operands.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void exact_div_selftest_kernel(
+    unsigned long long seed, long long count, unsigned long long* __restrict__ mismatches) {
+  const long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+  unsigned long long local = 0;
+  for (long long k = i; k < count; k += static_cast<long long>(gridDim.x) * kBlock) {
+    // splitmix64
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * static_cast<unsigned long long>(k + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    unsigned long long w = z * 0xD6E8FEB86659FD93ull;
+    w ^= w >> 32;
+    T n, d;
+    if constexpr (sizeof(T) == 4) {
+      // random mantissas (every 8th: all-ones / single-bit patterns), exponents spread over ~2^+-40
+      uint32_t md = static_cast<uint32_t>(z) & 0x7FFFFFu, mn = static_cast<uint32_t>(z >> 23) & 0x7FFFFFu;
+      if ((k & 7) == 0) md = 0x7FFFFFu >> ((z >> 50) & 7);
+      if ((k & 7) == 1) mn = 0x7FFFFFu << ((z >> 53) & 7) & 0x7FFFFFu;
+      const int ed = 127 + static_cast<int>((w >> 8) % 81) - 40, en = ed - static_cast<int>((w >> 20) % 30);
+      d = __uint_as_float((static_cast<uint32_t>(ed) << 23) | md);
+      n = __uint_as_float((static_cast<uint32_t>(en > 1 ? en : 1) << 23) | mn);
+    } else {
+      unsigned long long md = z & 0xFFFFFFFFFFFFFull, mn = w & 0xFFFFFFFFFFFFFull;
+      if ((k & 7) == 0) md = 0xFFFFFFFFFFFFFull >> ((z >> 55) & 15);
+      const int ed = 1023 + static_cast<int>((w >> 52) % 81) - 40, en = ed - static_cast<int>((z >> 52) % 60);
+      d = __longlong_as_double((static_cast<unsigned long long>(ed) << 52) | md);
+      n = __longlong_as_double((static_cast<unsigned long long>(en) << 52) | mn);
+    }
+    const T r = T(1) / d;
+    const T fast = exact_div(n, d, r, exact_div_ok(d));
+    const T ref = n / d;
+    if (!(fast == ref)) ++local;
+  }
+  if (local) atomicAdd(mismatches, local);
+}
+
 template <typename T>
 int rasterize_impl(
     const T* v, const int32_t* vi, int64_t N, int64_t V, int64_t F, int64_t vi_sN, int64_t H,
@@ -670,4 +754,21 @@ extern "C" int drtk_amd_rasterize(
     default:
       return DRTK_ERR_INVALID_ARGUMENT;
   }
+}
+
+extern "C" int drtk_amd_selftest_exact_div(
+    drtk_dtype_t dtype, uint64_t seed, int64_t count, uint64_t* d_mismatches, drtk_stream_t stream) {
+  if (!d_mismatches || count < 0) return DRTK_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(d_mismatches, 0, sizeof(uint64_t), s) != hipSuccess) return DRTK_ERR_LAUNCH;
+  const unsigned blocks = 4096;
+  if (dtype == DRTK_F32) {
+    hipLaunchKernelGGL((exact_div_selftest_kernel<float>), dim3(blocks), dim3(kBlock), 0, s, seed, (long long)count, (unsigned long long*)d_mismatches);
+  } else if (dtype == DRTK_F64) {
+    hipLaunchKernelGGL((exact_div_selftest_kernel<double>), dim3(blocks), dim3(kBlock), 0, s, seed, (long long)count, (unsigned long long*)d_mismatches);
+  } else {
+    return DRTK_ERR_INVALID_ARGUMENT;
+  }
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
 }

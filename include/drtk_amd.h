@@ -132,6 +132,12 @@ int drtk_amd_edge_grad_backward_fused(
     int64_t F, int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix,
     void* workspace, size_t workspace_bytes, drtk_stream_t stream);
 
+/* Diagnostics: compares the rasterizer's reciprocal-based exact division with the IEEE `/` on `count`
+ * pseudo-random operand pairs on the device; *d_mismatches (device memory) receives the number of
+ * differing results (must be 0). */
+int drtk_amd_selftest_exact_div(
+    drtk_dtype_t dtype, uint64_t seed, int64_t count, uint64_t* d_mismatches, drtk_stream_t stream);
+
 /* Diagnostics for profiling scripts: a bit mask that switches single kernel phases off so that
  * their time can be attributed.  Results are WRONG while it is non-zero; default 0. */
 void drtk_amd_debug_set_flags(int flags);

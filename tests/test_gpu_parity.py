@@ -263,3 +263,14 @@ def test_full_size_properties(cfg):
     close(eg2, 2 * eg, "edge grad linearity in grad_output", atol=1e-4)
     gv = capi.render_backward(v, vi, i1, th.ones_like(depth), th.zeros_like(bary))
     assert th.isfinite(gv).all()
+
+
+@pytest.mark.parametrize("dtype", [th.float32, th.float64])
+def test_exact_division_matches_ieee(dtype):
+    """The rasterizer divides by |denominator| through a precomputed reciprocal + two fused
+    corrections; it must agree with IEEE division bit for bit (2^31 random operand pairs incl.
+    all-ones / sparse mantissas), otherwise depth bits and hence index_img could differ."""
+    from drtk_amd import capi
+
+    for seed in (1, 2):
+        assert capi.selftest_exact_div(dtype, seed=seed, count=1 << 30) == 0
