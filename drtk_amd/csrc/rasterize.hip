@@ -87,6 +87,25 @@ __device__ __forceinline__ T exact_div(T n, T d, T r, bool range_ok) {
   return n / d;
 }
 
+// Correctly rounded 1 / x (float, x normal, result normal): hardware v_rcp_f32 (<= 1 ulp) plus one
+// Markstein correction y' = fma(y, fma(-x, y, 1), y).  The correction is exact-rounding for every
+// faithful y except when x's significand is all ones (classical exception of the reciprocal
+// theorem), which -- like operands outside the safe exponent range -- takes the IEEE division.
+// Reciprocals depend on the significand only, so drtk_amd_selftest_exact_div() checks this routine
+// EXHAUSTIVELY over all 2^23 significands.
+__device__ __forceinline__ float exact_rcp(float x) {
+  const uint32_t bits = __float_as_uint(x);
+  const float ax = __uint_as_float(bits & 0x7FFFFFFFu);
+  if ((bits & 0x7FFFFFu) != 0x7FFFFFu && ax >= 0x1p-100f && ax <= 0x1p100f) {
+    const float y = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(y, __builtin_fmaf(-x, y, 1.0f), y);
+  }
+  return 1.0f / x;
+}
+__device__ __forceinline__ double exact_rcp(double x) {
+  return 1.0 / x;
+}
+
 // Culling + bounding box only (used by the binning passes).  Returns false if the triangle is
 // dropped by the reference (:81 degenerate indices, :96 near plane, :97-98 off canvas, :107 zero
 // area).  On success the pixel bbox (already clamped to the canvas) is returned.
@@ -434,7 +453,7 @@ __device__ __forceinline__ double bcast(double x, int lane) {
 template <typename T, int TILE_SHIFT>
 __device__ __forceinline__ void raster_lanes(
     bool valid, const TriSetup<T>& s, int f, int x0, int y0, int x1, int y1,
-    unsigned long long* __restrict__ zbuf) {
+    unsigned long long* __restrict__ zbuf, int dbg = 0) {
   const int lane = lane_id();
   // per-lane: oriented edges + clipped bbox
   T eax[3], eay[3], edx[3], edy[3], es[3];
@@ -456,6 +475,7 @@ __device__ __forceinline__ void raster_lanes(
   const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
   const int tl = (s.tl0 ? 1 : 0) | (s.tl1 ? 2 : 0) | (s.tl2 ? 4 : 0);
   unsigned long long todo = __ballot(valid && bx0 <= bx1 && by0 <= by1);
+  if (dbg & 1) todo = 0;
   while (todo) {
     const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
     todo &= todo - 1;
@@ -487,7 +507,7 @@ __device__ __forceinline__ void raster_lanes(
     T ex[3]; // -(px - ax) * dy part, constant over rows
 #pragma unroll
     for (int k = 0; k < 3; ++k) ex[k] = (px - u.ax[k]) * u.dy[k];
-    if (lx < bw) {
+    if (lx < bw && !(dbg & 2)) {
       for (int y = uby0 + ly; y <= uby1; y += sh) {
         const T py = static_cast<T>(y);
         T b0 = ((py - u.ay[0]) * u.dx[0] - ex[0]) * u.s[0];
@@ -495,11 +515,15 @@ __device__ __forceinline__ void raster_lanes(
         T b2 = ((py - u.ay[2]) * u.dx[2] - ex[2]) * u.s[2];
         if (!((b0 >= T(0)) && (b1 >= T(0)) && (b2 >= T(0)))) continue;
         if ((!(u.tl & 1) && b0 == T(0)) || (!(u.tl & 2) && b1 == T(0)) || (!(u.tl & 4) && b2 == T(0))) continue;
+        if (dbg & 4) {
+          atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], id);
+          continue;
+        }
         b0 = exact_div(b0, u.abs_denom, u.rdenom, div_ok); // == b0 / abs_denom, rasterize_kernel.cu:148
         b1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
         b2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
         const T depth_inverse = u.dinv0 * b0 + u.dinv1 * b1 + u.dinv2 * b2;
-        const float depth = static_cast<float>(T(1) / epsclamp(depth_inverse));
+        const float depth = static_cast<float>(exact_rcp(epsclamp(depth_inverse))); // == 1 / epsclamp(..), :153
         const unsigned long long packed = (static_cast<unsigned long long>(__float_as_uint(depth)) << 32) | id;
         atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], packed);
       }
@@ -507,14 +531,18 @@ __device__ __forceinline__ void raster_lanes(
   }
 }
 
+// The raster loop is a long dependent chain per wave (IPC ~0.2 with 4 waves per workgroup), so the
+// workgroup is 8 waves: with the 32 KiB tile that is 4 workgroups = 32 waves per CU, the hardware maximum.
+constexpr int kRasterBlock = 512;
+
 template <typename T, int TILE_SHIFT>
-__global__ __launch_bounds__(kBlock) void tile_raster_kernel(
+__global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN,
     int H, int W, int tiles_x, int tiles_per_view, const int32_t* __restrict__ tile_offset,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ big_count,
     const int32_t* __restrict__ big_list, const uint2* __restrict__ tri_range,
     const uint32_t* __restrict__ items, int32_t* __restrict__ queue, float* __restrict__ depth_img,
-    int32_t* __restrict__ index_img) {
+    int32_t* __restrict__ index_img, int dbg) {
   constexpr int TILE = 1 << TILE_SHIFT;
   constexpr int NPIX = TILE * TILE;
   __shared__ unsigned long long zbuf[NPIX];
@@ -539,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
     const int x1 = min(x0 + ss - 1, W - 1), y1 = min(y0 + ss - 1, H - 1);
     if (x0 < W && y0 < H) {
       const int rows = y1 - y0 + 1;
-      for (int i = tid; i < (rows << TILE_SHIFT); i += kBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
+      for (int i = tid; i < (rows << TILE_SHIFT); i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
       __syncthreads();
 
       const T* v_n = v + int64_t(n) * V * 3;
@@ -548,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
       // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively
       // the list is cut into 4 equal parts, one per wave, so that the waves reach the barrier together
       const int begin = tile_offset[tile], end_all = tile_offset[tile + 1];
-      const int per_wave = (end_all - begin + kBlock / kWave - 1) / (kBlock / kWave);
+      const int per_wave = (end_all - begin + kRasterBlock / kWave - 1) / (kRasterBlock / kWave);
       const int wave_begin = begin + (tid / kWave) * per_wave;
       const int end = min(wave_begin + per_wave, end_all);
       for (int i0 = wave_begin; i0 < end; i0 += kWave) {
@@ -556,19 +584,19 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
         int f = 0;
         bool valid = false;
         TriSetup<T> s = {};
-        if (i < end) {
+        if (i < end && !(dbg & 8)) {
           f = pairs[i];
           valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
           valid = valid && s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0;
         }
-        if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf);
+        if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
       }
 
       // big triangles (more than kMaxSmallTiles tiles): per-view list, filtered by tile range
       const int nbig = big_count[n];
       const int32_t* big_n = big_list + int64_t(n) * F;
       const uint2* range_n = tri_range + int64_t(n) * F;
-      const int big_per_wave = (nbig + kBlock / kWave - 1) / (kBlock / kWave);
+      const int big_per_wave = (nbig + kRasterBlock / kWave - 1) / (kRasterBlock / kWave);
       const int big_begin = (tid / kWave) * big_per_wave, big_end = min(big_begin + big_per_wave, nbig);
       for (int i0 = big_begin; i0 < big_end; i0 += kWave) {
         const int i = i0 + (tid & (kWave - 1));
@@ -584,7 +612,7 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
             valid = valid && s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0;
           }
         }
-        if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf);
+        if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
       }
       __syncthreads();
 
@@ -592,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void tile_raster_kernel(
       const int64_t img_base = int64_t(n) * H * W;
       const bool vec_ok = (W & 3) == 0;
       const int quads_per_row = ss >> 2;
-      for (int q = tid; q < rows * quads_per_row; q += kBlock) {
+      for (int q = tid; q < rows * quads_per_row; q += kRasterBlock) {
         const int row = q / quads_per_row;
         const int col = (q - row * quads_per_row) << 2;
         const int y = y0 + row, x = x0 + col;
@@ -659,6 +687,16 @@ __global__ __launch_bounds__(kBlock) void exact_div_selftest_kernel(
     const T fast = exact_div(n, d, r, exact_div_ok(d));
     const T ref = n / d;
     if (!(fast == ref)) ++local;
+    if (!(exact_rcp(d) == T(1) / d)) ++local;
+    if constexpr (sizeof(T) == 4) {
+      // exhaustive over significands: pair k < 2^23 x 8 exponents
+      if (k < (1ll << 26)) {
+        const int ex[8] = {127, 126, 128, 100, 160, 60, 190, 127 - 90};
+        const float x = __uint_as_float((static_cast<uint32_t>(ex[k >> 23]) << 23) | static_cast<uint32_t>(k & 0x7FFFFF));
+        if (!(exact_rcp(x) == 1.0f / x)) ++local;
+        if (!(exact_rcp(-x) == 1.0f / -x)) ++local;
+      }
+    }
   }
   if (local) atomicAdd(mismatches, local);
 }
@@ -703,18 +741,18 @@ int rasterize_impl(
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   // persistent workgroups pulling work items: as many as can be resident, never more than items
-  const int64_t resident = int64_t(num_compute_units()) * (L.tile_shift == 6 ? 5 : 8);
+  const int64_t resident = int64_t(num_compute_units()) * 4;
   const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(L.max_items, resident));
   if (L.tile_shift == 6) {
     hipLaunchKernelGGL(
-        (tile_raster_kernel<T, 6>), dim3(blocks), dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN,
+        (tile_raster_kernel<T, 6>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
         (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, pairs, big_count, big_list,
-        tri_range, items, queue, depth_img, index_img);
+        tri_range, items, queue, depth_img, index_img, debug_flags());
   } else {
     hipLaunchKernelGGL(
-        (tile_raster_kernel<T, 5>), dim3(blocks), dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN,
+        (tile_raster_kernel<T, 5>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
         (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, pairs, big_count, big_list,
-        tri_range, items, queue, depth_img, index_img);
+        tri_range, items, queue, depth_img, index_img, debug_flags());
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
