@@ -135,25 +135,40 @@ def time_kernels(v_pix, vi, attr, H, W, reps):
     return out
 
 
-def cpu_baseline(v_pix, vi, attr, H, W, n_views, min_seconds=10.0):
-    """The CPU oracle (a port of the reference's CPU kernels, validated bit-exact against them)
-    on all host cores, fwd+bwd over `n_views` views of the same workload."""
+def _cpu_backend():
+    """(kind, backend, threads): the reference's own CPU kernels if their prebuilt library travelled
+    with the repo (oracle/_ref/libdrtk_ref_fast.so = /root/reference/src/*/*_kernel_cpu.cpp built with
+    the reference's `-O3 --fast-math` flags by oracle/ref_build.py), else the CPU oracle port."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        from backends import RefBackend
 
+        b = RefBackend("fast")
+        return "reference", b, th.get_num_threads()
+    except Exception:
+        from backends import OracleBackend
+
+        import oracle as O
+
+        return "port", OracleBackend(nthreads=0), O.max_threads()
+
+
+def cpu_baseline(v_pix, vi, attr, H, W, n_views, min_seconds=10.0):
+    """fwd+bwd of the four ops on the host cores over `n_views` views of the same workload, with the
+    reference's own CPU kernels (at::parallel_for over all cores) when available."""
+    kind, B, cores = _cpu_backend()
     v = v_pix[:n_views].detach().cpu().contiguous()
     a = attr[:n_views].detach().cpu().contiguous()
     vi_c = vi.cpu()
-    nt = 0
-    cores = O.max_threads()
     g = th.Generator().manual_seed(0)
     secs, passes = 0.0, 0
     while secs < min_seconds and passes < 64:
         t0 = time.perf_counter()
-        depth0, index = O.rasterize(v, vi_c, H, W, nthreads=nt)
-        depth, bary = O.render(v, vi_c, index, nthreads=nt)
-        img = O.interpolate(a, vi_c, index, bary, nthreads=nt)
-        vpix_img = O.interpolate(v, vi_c, index, bary, nthreads=nt)  # edge_grad_estimator's forward
+        depth0, index = B.rasterize(v, vi_c, H, W)
+        depth, bary = B.render(v, vi_c, index)
+        img = B.interpolate(a, vi_c, index, bary)
+        vpix_img = B.interpolate(v, vi_c, index, bary)  # edge_grad_estimator's forward
         t_fwd = time.perf_counter()
         img = img * (index != -1)[:, None]
         if passes == 0:
@@ -161,21 +176,23 @@ def cpu_baseline(v_pix, vi, attr, H, W, n_views, min_seconds=10.0):
             gd = th.rand(depth.shape, generator=g)
             gb = th.rand(bary.shape, generator=g)
         t1 = time.perf_counter()
-        eg = O.edge_grad_backward(v, img, index, vi_c, go, nthreads=nt)
-        O.interpolate_backward(eg, v, vi_c, index, bary, True, False, nthreads=nt)
-        O.interpolate_backward(go, a, vi_c, index, bary, True, True, nthreads=nt)
-        O.render_backward(v, vi_c, index, gd, gb, nthreads=nt)
+        eg = B.edge_grad_backward(v, img, index, vi_c, go, 1e4)
+        B.interpolate_backward(eg, v, vi_c, index, bary, True, False)
+        B.interpolate_backward(go, a, vi_c, index, bary, True, True)
+        B.render_backward(v, vi_c, index, gd, gb)
         t2 = time.perf_counter()
         secs += (t_fwd - t0) + (t2 - t1)
         passes += 1
     del vpix_img, depth0
+    what = ("the reference's own CPU kernels (oracle/_ref, -O3 --fast-math, at::parallel_for)" if kind == "reference"
+            else "the CPU oracle port (OpenMP)")
     return {
         "value": round(passes * n_views * H * W / secs / 1e6, 4),
         "unit": "Mpix/s",
         "cores": cores,
-        "kind": "port",
+        "kind": kind,
         "sample": f"{n_views} of the {v_pix.shape[0]} views of the same workload, {passes} fwd+bwd passes of the four ops "
-                  f"(OpenMP, {cores} threads), {secs:.2f} s of CPU work",
+                  f"with {what}, {cores} threads, {secs:.2f} s of CPU work",
     }
 
 
