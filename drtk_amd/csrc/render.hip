@@ -28,10 +28,10 @@ struct RenderPix {
 
 template <typename T>
 __device__ __forceinline__ void render_pix(
-    const T* __restrict__ v_n, const int32_t* __restrict__ face, int x, int y, RenderPix<T>& r) {
-  r.vi0 = face[0];
-  r.vi1 = face[1];
-  r.vi2 = face[2];
+    const T* __restrict__ v_n, int32_t vi0, int32_t vi1, int32_t vi2, int x, int y, RenderPix<T>& r) {
+  r.vi0 = vi0;
+  r.vi1 = vi1;
+  r.vi2 = vi2;
   const T* q0 = v_n + 3 * (int64_t)r.vi0;
   const T* q1 = v_n + 3 * (int64_t)r.vi1;
   const T* q2 = v_n + 3 * (int64_t)r.vi2;
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
   for (int j = 0; j < VEC; ++j) {
     if (tr[j] != -1) {
       RenderPix<T> r;
-      render_pix<T>(v_n, vi_n + int64_t(tr[j]) * 3, x0 + j, y, r);
+      const int32_t* face = vi_n + int64_t(tr[j]) * 3;
+      render_pix<T>(v_n, face[0], face[1], face[2], x0 + j, y, r);
       b0[j] = r.dinv0 * r.b0 * r.depth;
       b1[j] = r.dinv1 * r.b1 * r.depth;
       b2[j] = r.dinv2 * r.b2 * r.depth;
@@ -159,12 +160,35 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = T(0);
   wave_lds_sync();
 
+  // software pipeline over the 4 rows: index of row p+1 is requested at the top of row p, its
+  // triangle's vertex ids before phase 2 -- both dependent gathers fly under the current row.
+  auto load_tr = [&](int pass) -> int32_t {
+    const int yy = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
+    return (x < W && yy < H) ? index_img[int64_t(n) * HW + int64_t(yy) * W + x] : -1;
+  };
+  int32_t tr_next = load_tr(0);
+  int32_t vn[3] = {0, 0, 0};
+  if (tr_next != -1) {
+    const int32_t* face = vi_n + int64_t(tr_next) * 3;
+    vn[0] = face[0], vn[1] = face[1], vn[2] = face[2];
+  }
 #pragma unroll 1
   for (int pass = 0; pass < kTileRows / kWaves; ++pass) {
     const int y = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
-    const bool in_range = x < W && y < H;
     const int64_t pix = int64_t(y) * W + x;
-    const int32_t tr = in_range ? index_img[int64_t(n) * HW + pix] : -1;
+    const int32_t tr = tr_next;
+    const int32_t cur[3] = {vn[0], vn[1], vn[2]};
+    if (pass + 1 < kTileRows / kWaves) tr_next = load_tr(pass + 1);
+    if (__ballot(tr != -1) == 0) { // whole row segment is background: nothing to do but keep the pipeline fed
+      if (pass + 1 < kTileRows / kWaves) {
+        vn[0] = vn[1] = vn[2] = 0;
+        if (tr_next != -1) {
+          const int32_t* face = vi_n + int64_t(tr_next) * 3;
+          vn[0] = face[0], vn[1] = face[1], vn[2] = face[2];
+        }
+      }
+      continue;
+    }
     T g[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) g[j] = T(0);
@@ -172,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
 
     if (tr != -1) {
       RenderPix<T> r;
-      render_pix<T>(v_n, vi_n + int64_t(tr) * 3, x, y, r);
+      render_pix<T>(v_n, cur[0], cur[1], cur[2], x, y, r);
       vid[0] = r.vi0;
       vid[1] = r.vi1;
       vid[2] = r.vi2;
@@ -225,6 +249,13 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     for (int k = 0; k < 3; ++k) {
       s_vid[wave][k * kRunPad + lane] = vid[k];
       s_slot[wave][k * kRunPad + lane] = (tr != -1 && !dup) ? table_slot(t_keys[wave], vid[k]) : -1;
+    }
+    if (pass + 1 < kTileRows / kWaves) {
+      vn[0] = vn[1] = vn[2] = 0;
+      if (tr_next != -1) {
+        const int32_t* face = vi_n + int64_t(tr_next) * 3;
+        vn[0] = face[0], vn[1] = face[1], vn[2] = face[2];
+      }
     }
     unsigned long long heads, cov;
     run_masks(tr, heads, cov);
