@@ -7,7 +7,7 @@
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): per GPU 8 camera views of a
 100 352-triangle "head" UV sphere at 2048x2048, 16 attribute channels, float32.  One step =
-transform (PyTorch) -> rasterize -> render -> interpolate(C=16) -> mask -> edge_grad_estimator ->
+transform -> rasterize -> render -> interpolate(C=16) -> mask -> edge_grad_estimator ->
 loss = mean(img^2) + mean(depth) -> backward, producing gradients for the SHARED world-space
 vertices [V,3] and SHARED attributes [1,V,C]; with N > 1 ranks every rank renders its own 8 views
 (weak scaling) and the shared gradients are summed with ONE fused RCCL all-reduce per step.
@@ -242,7 +242,7 @@ def main():
     reducer = ddist.SharedGradReducer([v_world, attr])
 
     def step():
-        v_pix = transform(v_world[None].expand(n_local, -1, -1), campos, camrot, focal, princpt)
+        v_pix = transform(v_world[None], campos, camrot, focal, princpt)  # shared [1,V,3] -> [n_local,V,3]
         a = attr.expand(n_local, -1, -1)
         index_img = drtk_amd.rasterize(v_pix, vi, H, W)
         depth_img, bary_img = drtk_amd.render(v_pix, vi, index_img)

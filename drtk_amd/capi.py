@@ -48,6 +48,8 @@ EXPORTS = [
     "drtk_amd_edge_grad_backward",
     "drtk_amd_edge_grad_backward_fused_workspace_bytes",
     "drtk_amd_edge_grad_backward_fused",
+    "drtk_amd_transform_pinhole",
+    "drtk_amd_transform_pinhole_backward",
     "drtk_amd_selftest_exact_div",
     "drtk_amd_debug_set_flags",
 ]

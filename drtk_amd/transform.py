@@ -1,6 +1,8 @@
 """Pinhole `transform` -- the step before the hot path (drtk/transform.py:13-119,
-drtk/utils/projection.py:33-53,486-540).  Pure PyTorch, runs unchanged on ROCm; only the
-undistorted pinhole model is provided (the distortion models are outside the hot-path scope)."""
+drtk/utils/projection.py:33-53,486-540).  Only the undistorted pinhole model is provided (the
+distortion models are outside the hot-path scope).  On a HIP device, when the camera parameters do
+not require gradients, `transform` runs as ONE fused kernel each way (`drtk_amd_ext::transform_pinhole`,
+csrc/transform.hip); otherwise the PyTorch formulation below is used."""
 from typing import Optional, Tuple
 
 import torch as th
@@ -50,5 +52,26 @@ def transform(
     K: Optional[th.Tensor] = None,
     Rt: Optional[th.Tensor] = None,
 ) -> th.Tensor:
-    """World space `[N,V,3]` -> `(x_pix, y_pix, z_cam)`; `v_cam = camrot @ (v - campos)`."""
+    """World space `[N,V,3]` (or one shared `[1,V,3]`) -> `(x_pix, y_pix, z_cam)`;
+    `v_cam = camrot @ (v - campos)`."""
+    if v.is_cuda and v.dtype in (th.float32, th.float64):
+        if not ((camrot is not None and campos is not None) ^ (Rt is not None)):
+            raise ValueError("You must provide exactly one of Rt or (campos, camrot).")
+        if not ((focal is not None and princpt is not None) ^ (K is not None)):
+            raise ValueError("You must provide exactly one of K or (focal, princpt).")
+        if campos is None:
+            camrot = Rt[:, :3, :3]
+            campos = -(camrot.transpose(-2, -1) @ Rt[:, :3, 3:4])[..., 0]
+        if focal is None:
+            focal = K[:, :2, :2]
+            princpt = K[:, :2, 2]
+        cams = (campos, camrot, focal, princpt)
+        if not (th.is_grad_enabled() and any(c.requires_grad for c in cams)):
+            from drtk_amd.utils import load_torch_ops
+
+            load_torch_ops("drtk.rasterize_ext")
+            if v.shape[0] != 1 and v.stride(0) == 0:
+                v = v[:1]  # expanded world-space vertices: keep them shared, the kernel broadcasts
+            return th.ops.drtk_amd_ext.transform_pinhole(v, *cams)
+        return transform_with_v_cam(v, *cams)[0]
     return transform_with_v_cam(v, campos, camrot, focal, princpt, K, Rt)[0]

@@ -132,6 +132,24 @@ int drtk_amd_edge_grad_backward_fused(
     int64_t F, int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix,
     void* workspace, size_t workspace_bytes, drtk_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * transform_pinhole  -- the vertex stage in front of the path; replaces the pure-PyTorch pinhole
+ * branch of drtk.transform (drtk/transform.py:13-119, drtk/utils/projection.py:33-53,486-540):
+ *   v_cam = camrot (v - campos);  v_pix = (focal (v_cam.xy / clamp(v_cam.z)) + princpt, v_cam.z)
+ * v: [N,V,3] (v_sN = 3V) or ONE shared [V,3] (v_sN = 0); campos [N,3], camrot [N,3,3] row-major,
+ * focal [N,2,2], princpt [N,2]; v_pix [N,V,3]; v_cam [N,V,3] or NULL.
+ * The backward gives the gradient wrt v only ([N,V,3], or [V,3] already summed over the views
+ * when v is shared); camera parameters are treated as constants.
+ */
+int drtk_amd_transform_pinhole(
+    drtk_dtype_t dtype, const void* v, int64_t v_sN, const void* campos, const void* camrot,
+    const void* focal, const void* princpt, int64_t N, int64_t V, void* v_pix, void* v_cam,
+    drtk_stream_t stream);
+int drtk_amd_transform_pinhole_backward(
+    drtk_dtype_t dtype, const void* v, int64_t v_sN, const void* campos, const void* camrot,
+    const void* focal, const void* princpt, const void* grad_v_pix, int64_t N, int64_t V,
+    void* grad_v, drtk_stream_t stream);
+
 /* Diagnostics: compares the rasterizer's reciprocal-based exact division with the IEEE `/` on `count`
  * pseudo-random operand pairs on the device; *d_mismatches (device memory) receives the number of
  * differing results (must be 0). */

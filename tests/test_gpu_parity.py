@@ -274,3 +274,39 @@ def test_exact_division_matches_ieee(dtype):
 
     for seed in (1, 2):
         assert capi.selftest_exact_div(dtype, seed=seed, count=1 << 30) == 0
+
+
+@pytest.mark.parametrize("dtype", [th.float32, th.float64])
+@pytest.mark.parametrize("shared", [True, False])
+def test_transform_pinhole_matches_pytorch_formulation(dtype, shared):
+    """Fused pinhole transform (forward and gradient wrt v) against the reference's pure-PyTorch
+    formulation (drtk/utils/projection.py:33-53,486-540) evaluated in float64 on the CPU."""
+    from drtk_amd import synthetic as S
+    from drtk_amd.transform import transform, transform_with_v_cam
+
+    N = 5
+    v0, _ = S.uv_sphere(14, 18, dtype=th.float64)
+    v0[3, 2] = -3.0  # one vertex exactly at z_cam ~ 0 for camera 0 region: exercises the z clamp
+    cams64 = S.ring_cameras(N, 320, 240, dtype=th.float64)
+    v64 = (v0[None] if shared else v0[None].repeat(N, 1, 1) + 0.01 * th.arange(N, dtype=th.float64)[:, None, None])
+    v64 = v64.clone().requires_grad_(True)
+    ref, _ = transform_with_v_cam(v64 if not shared else v64.expand(N, -1, -1), *cams64)
+    g = th.rand(ref.shape, dtype=th.float64, generator=th.Generator().manual_seed(5)) * 2 - 1
+    (ref * g).sum().backward()
+
+    v = v64.detach().to(dtype).to(DEV).requires_grad_(True)
+    cams = tuple(c.to(dtype).to(DEV) for c in cams64)
+    out = transform(v, *cams)
+    assert out.shape == ref.shape
+    (out * g.to(dtype).to(DEV)).sum().backward()
+    rtol = 2e-6 if dtype == th.float32 else 1e-12
+    scale = float(ref.abs().max())
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= rtol * scale
+    gscale = float(v64.grad.abs().max())
+    assert v.grad.shape == v64.grad.shape
+    assert float((v.grad.cpu().double() - v64.grad).abs().max()) <= 10 * rtol * gscale
+    # expanded (stride-0) input takes the shared path too
+    if shared:
+        v2 = v64.detach().to(dtype).to(DEV)[0].requires_grad_(True)
+        out2 = transform(v2[None].expand(N, -1, -1), *cams)
+        assert th.equal(out2, out)
