@@ -48,6 +48,10 @@ EXPORTS = [
     "drtk_amd_edge_grad_backward",
     "drtk_amd_edge_grad_backward_fused_workspace_bytes",
     "drtk_amd_edge_grad_backward_fused",
+    "drtk_amd_interpolation_matrix",
+    "drtk_amd_interpolation_matrix_backward",
+    "drtk_amd_interpolation_normal_matrix_values",
+    "drtk_amd_interpolation_normal_matrix_values_backward",
     "drtk_amd_transform_pinhole",
     "drtk_amd_transform_pinhole_backward",
     "drtk_amd_selftest_exact_div",
@@ -186,6 +190,80 @@ def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires
             _i(C), _i(F), _i(vi_sN), _i(H), _i(W), _p(ag), _p(bg), _stream(attrs, stream)),
         "interpolate_backward")
     return ag, bg
+
+
+def interpolation_matrix(vi, index_img, bary_img, stream=None):
+    """-> (crow_indices, col_indices, values, row_pixels); row_pixels/crow are built with torch ops
+    (the caller's side of the C ABI), columns and values by drtk_amd_interpolation_matrix."""
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, H, W = index_img.shape
+    vi_c, vi_sN, F = _vi(vi, N)
+    row_pixels = th.nonzero(index_img.reshape(-1).ne(-1)).reshape(-1)
+    R = row_pixels.numel()
+    crow = th.arange(0, 3 * R + 1, 3, dtype=th.int64, device=index_img.device)
+    col = th.empty(3 * R, dtype=th.int64, device=index_img.device)
+    values = th.empty(3 * R, dtype=bary_img.dtype, device=bary_img.device)
+    _check(
+        lib().drtk_amd_interpolation_matrix(
+            ctypes.c_int(_dt(bary_img)), _p(vi_c), _p(index_img), _p(bary_img), _p(row_pixels), _i(R), _i(N), _i(F),
+            _i(vi_sN), _i(H), _i(W), _p(col), _p(values), _stream(bary_img, stream)),
+        "interpolation_matrix")
+    return crow, col, values, row_pixels
+
+
+def interpolation_matrix_backward(grad_values, vi, index_img, row_pixels, stream=None):
+    grad_values = grad_values.contiguous()
+    index_img = index_img.contiguous()
+    row_pixels = row_pixels.contiguous()
+    N, H, W = index_img.shape
+    vi_c, vi_sN, F = _vi(vi, N)
+    bg = th.empty(N, 3, H, W, dtype=grad_values.dtype, device=grad_values.device)
+    _check(
+        lib().drtk_amd_interpolation_matrix_backward(
+            ctypes.c_int(_dt(grad_values)), _p(grad_values), _p(vi_c), _p(index_img), _p(row_pixels),
+            _i(row_pixels.numel()), _i(N), _i(F), _i(vi_sN), _i(H), _i(W), _p(bg), _stream(grad_values, stream)),
+        "interpolation_matrix_backward")
+    return bg
+
+
+def _pairs(pair_indices, N):
+    assert pair_indices.dtype == th.int32 and pair_indices.shape[-1] == 9
+    if pair_indices.ndim == 2:
+        return pair_indices.contiguous(), 0, pair_indices.shape[0]
+    if pair_indices.shape[0] == N and N > 1 and pair_indices.stride(0) == 0:
+        return pair_indices[0].contiguous(), 0, pair_indices.shape[1]
+    p = pair_indices.contiguous()
+    return p, p.shape[1] * 9, p.shape[1]
+
+
+def interpolation_normal_matrix_values(pair_indices, index_img, bary_img, nnz, stream=None):
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, H, W = index_img.shape
+    pr, pair_sN, F = _pairs(pair_indices, N)
+    values = th.empty(nnz, dtype=bary_img.dtype, device=bary_img.device)
+    _check(
+        lib().drtk_amd_interpolation_normal_matrix_values(
+            ctypes.c_int(_dt(bary_img)), _p(pr), _p(index_img), _p(bary_img), _i(N), _i(F), _i(pair_sN), _i(H), _i(W),
+            _i(nnz), _p(values), _stream(bary_img, stream)),
+        "interpolation_normal_matrix_values")
+    return values
+
+
+def interpolation_normal_matrix_values_backward(grad_values, pair_indices, index_img, bary_img, stream=None):
+    grad_values = grad_values.contiguous()
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, H, W = index_img.shape
+    pr, pair_sN, F = _pairs(pair_indices, N)
+    bg = th.empty(N, 3, H, W, dtype=bary_img.dtype, device=bary_img.device)
+    _check(
+        lib().drtk_amd_interpolation_normal_matrix_values_backward(
+            ctypes.c_int(_dt(bary_img)), _p(grad_values), _p(pr), _p(index_img), _p(bary_img), _i(N), _i(F),
+            _i(pair_sN), _i(H), _i(W), _p(bg), _stream(bary_img, stream)),
+        "interpolation_normal_matrix_values_backward")
+    return bg
 
 
 def edge_grad_backward_workspace_bytes(dtype, N, H, W) -> int:

@@ -85,7 +85,7 @@ __device__ __forceinline__ void scatter_runs(
   // vertex ids to the global fallback), so a plain read-modify-write is race free.
   auto flush = [&](int k, int c, int start, T acc, bool exclusive) {
     if (dbg & 32) return;
-    const int s = slot[k * kRunPad + start];
+    const int s = slot ? slot[k * kRunPad + start] : -1; // slot == nullptr: no table, always direct
     if (s >= 0) {
       if (exclusive) {
         LdsPtr q = (LdsPtr)(vals + s * stride + c);

@@ -133,6 +133,37 @@ int drtk_amd_edge_grad_backward_fused(
     void* workspace, size_t workspace_bytes, drtk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sparse interpolation operators -- the remaining ops of the reference's interpolate_ext:
+ *
+ * interpolation_matrix           replaces interpolation_matrix_cuda (interpolate_kernel.cu:699-770):
+ *   one CSR row per foreground pixel (row_pixels = flat [N*H*W] indices of index_img != -1, ascending,
+ *   computed by the caller), 3 entries per row: vertex columns sorted ascending with their
+ *   barycentric weights.  crow_indices is arange(0, 3R+1, 3) and is left to the caller.
+ * interpolation_matrix_backward  replaces interpolation_matrix_cuda_backward (:772-819): scatters
+ *   d values back to bary_grad [N,3,H,W] (zero-filled here).
+ * interpolation_normal_matrix_values[_backward]  replace ..._values_cuda[_backward] (:821-907):
+ *   values[pair_indices[n,tri,3i+j]] += bary_i * bary_j over foreground pixels (values zero-filled
+ *   here); pair_indices [N,F,9] int32 with batch stride pair_sN (0 = shared).  The CSR pattern itself
+ *   (crow / col / pair_indices) is topology-only host work done by the torch shim.
+ */
+int drtk_amd_interpolation_matrix(
+    drtk_dtype_t dtype, const int32_t* vi, const int32_t* index_img, const void* bary_img,
+    const int64_t* row_pixels, int64_t R, int64_t N, int64_t F, int64_t vi_sN, int64_t H, int64_t W,
+    int64_t* col_indices, void* values, drtk_stream_t stream);
+int drtk_amd_interpolation_matrix_backward(
+    drtk_dtype_t dtype, const void* grad_values, const int32_t* vi, const int32_t* index_img,
+    const int64_t* row_pixels, int64_t R, int64_t N, int64_t F, int64_t vi_sN, int64_t H, int64_t W,
+    void* bary_grad, drtk_stream_t stream);
+int drtk_amd_interpolation_normal_matrix_values(
+    drtk_dtype_t dtype, const int32_t* pair_indices, const int32_t* index_img, const void* bary_img,
+    int64_t N, int64_t F, int64_t pair_sN, int64_t H, int64_t W, int64_t nnz, void* values,
+    drtk_stream_t stream);
+int drtk_amd_interpolation_normal_matrix_values_backward(
+    drtk_dtype_t dtype, const void* grad_values, const int32_t* pair_indices, const int32_t* index_img,
+    const void* bary_img, int64_t N, int64_t F, int64_t pair_sN, int64_t H, int64_t W, void* bary_grad,
+    drtk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * transform_pinhole  -- the vertex stage in front of the path; replaces the pure-PyTorch pinhole
  * branch of drtk.transform (drtk/transform.py:13-119, drtk/utils/projection.py:33-53,486-540):
  *   v_cam = camrot (v - campos);  v_pix = (focal (v_cam.xy / clamp(v_cam.z)) + princpt, v_cam.z)

@@ -57,7 +57,23 @@ extern "C" {
   int drtk_oracle_edge_grad_backward_##SFX(                                                       \
       const REAL* v_pix, const REAL* img, const int32_t* index_img, const int32_t* vi,            \
       const REAL* grad_output, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN,         \
-      int64_t H, int64_t W, double max_dp_dr, REAL* grad_v_pix_img, int nthreads);
+      int64_t H, int64_t W, double max_dp_dr, REAL* grad_v_pix_img, int nthreads);                 \
+  /* sparse interpolation operators, interpolate_kernel_cpu.cpp:411-693 (single-threaded) */      \
+  int drtk_oracle_interpolation_matrix_##SFX(                                                     \
+      const int32_t* vi, const int32_t* index_img, const REAL* bary_img,                          \
+      const int64_t* row_pixels, int64_t R, int64_t N, int64_t F, int64_t vi_sN, int64_t H,       \
+      int64_t W, int64_t* col_indices, REAL* values);                                             \
+  int drtk_oracle_interpolation_matrix_backward_##SFX(                                            \
+      const REAL* grad_values, const int32_t* vi, const int32_t* index_img,                       \
+      const int64_t* row_pixels, int64_t R, int64_t N, int64_t F, int64_t vi_sN, int64_t H,       \
+      int64_t W, REAL* bary_grad);                                                                \
+  int drtk_oracle_normal_matrix_values_##SFX(                                                     \
+      const int32_t* pair_indices, const int32_t* index_img, const REAL* bary_img, int64_t N,     \
+      int64_t F, int64_t pair_sN, int64_t H, int64_t W, REAL* values);                            \
+  int drtk_oracle_normal_matrix_values_backward_##SFX(                                            \
+      const REAL* grad_values, const int32_t* pair_indices, const int32_t* index_img,             \
+      const REAL* bary_img, int64_t N, int64_t F, int64_t pair_sN, int64_t H, int64_t W,          \
+      REAL* bary_grad);
 
 DRTK_ORACLE_DECL(f32, float)
 DRTK_ORACLE_DECL(f64, double)

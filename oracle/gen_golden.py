@@ -55,6 +55,41 @@ def run_scene(B, Bfast, sc):
     return out
 
 
+def run_sparse(ref, sc, outs):
+    """Sparse interpolation operators (interpolate_kernel_cpu.cpp:411-693) from the reference's
+    strict build on a scene's index/bary images.  The A^T A pattern (crow/col/pair_indices) is
+    topology-only host code that lives in an anonymous namespace of interpolate_module.cpp and is
+    not reachable without the module's CUDA half, so it comes from the oracle's restatement and is
+    pinned here by a property of REFERENCE outputs: the reference's normal-matrix values scattered
+    through that pattern must equal A^T A of the reference's interpolation matrix."""
+    import oracle as O
+
+    vi, index, bary = sc["vi"], outs["index_img"], outs["render_bary"]
+    N, V = index.shape[0], sc["v"].shape[1]
+    vib = (vi[None].expand(N, -1, -1) if vi.ndim == 2 else vi).contiguous()
+    crow, col, values, rows = ref.interpolation_matrix(vib, index, bary)
+    g = th.Generator().manual_seed(77)
+    g_im = th.rand(values.shape, generator=g, dtype=th.float64).to(values.dtype)
+    im_bwd = ref.interpolation_matrix_backward(g_im, vib, index, bary, rows)
+    p_crow, p_col, pair = O.normal_matrix_structure(vib, V)
+    nnz = p_col.numel()
+    nm_values = ref.normal_matrix_values(pair, index, bary, nnz)
+    g_nm = th.rand(nnz, generator=g, dtype=th.float64).to(values.dtype)
+    nm_bwd = ref.normal_matrix_values_backward(g_nm, pair, index, bary)
+    A = th.sparse_csr_tensor(crow, col, values.double(), size=(rows.numel(), V)).to_dense()
+    AtA = th.sparse_csr_tensor(p_crow, p_col, nm_values.double(), size=(V, V)).to_dense()
+    err = (A.T @ A - AtA).abs().max().item()
+    tol = 1e-4 if values.dtype == th.float32 else 1e-11
+    assert err < tol, f"pattern pin failed: |A^T A - scatter(values)| = {err}"
+    return dict(g_im=g_im, g_nm=g_nm), dict(
+        col_indices=col.to(th.int32), values=values, row_pixels=rows.to(th.int32), im_bary_grad=im_bwd,
+        nm_crow=p_crow.to(th.int32), nm_col=p_col.to(th.int32), nm_pair=pair, nm_values=nm_values, nm_bary_grad=nm_bwd,
+    )
+
+
+SPARSE_SCENES = (("spheres", th.float32, "f32"), ("ragged", th.float32, "f32"), ("tutorial3", th.float64, "f64"))
+
+
 def save(name, inputs, outputs):
     arrs = {}
     for k, val in inputs.items():
@@ -122,6 +157,8 @@ def main():
             print(f"{name}/{tag}: covered {(outs['index_img'] >= 0).sum().item()} px, "
                   f"index px differing under --fast-math: {nd}")
             save(f"{name}_{tag}", sc, outs)
+            if (name, dtype, tag) in SPARSE_SCENES:
+                save(f"sparse_{name}_{tag}", *run_sparse(ref_build.load("strict"), sc, outs))
 
     # end-to-end step (SURVEY.md §8d definition) on the sphere scene
     ops = make_ops(B)

@@ -11,6 +11,7 @@ import ctypes
 import os
 
 import torch
+import torch as th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libdrtk_oracle.so")
@@ -154,3 +155,81 @@ def edge_grad_backward(v_pix, img, index_img, vi, grad_output, max_dp_dr=1e4, nt
           _p(grad_output), _i64(N), _i64(V), _i64(C), _i64(F), _i64(vi_sN), _i64(H), _i64(W),
           ctypes.c_double(max_dp_dr), _p(g), ctypes.c_int(nthreads))
     return g
+
+
+# ---- sparse interpolation operators (interpolate_kernel_cpu.cpp:411-693, interpolate_module.cpp:167-241)
+
+
+def _batched_vi(vi, n):
+    return vi[None].expand(n, -1, -1) if vi.ndim == 2 else (vi.expand(n, -1, -1) if vi.shape[0] == 1 else vi)
+
+
+def interpolation_matrix(vi, index_img, bary_img):
+    """Returns (crow_indices, col_indices, values, row_pixels) like interpolation_matrix_cpu."""
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, H, W = index_img.shape
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    row_pixels = th.nonzero(index_img.reshape(-1).ne(-1)).reshape(-1).contiguous()
+    R = row_pixels.numel()
+    crow = th.arange(0, R * 3 + 1, 3, dtype=th.int64)
+    col = th.empty(R * 3, dtype=th.int64)
+    values = th.empty(R * 3, dtype=bary_img.dtype)
+    _call("interpolation_matrix", _sfx(bary_img), _p(vi_c), _p(index_img), _p(bary_img), _p(row_pixels), _i64(R),
+          _i64(N), _i64(F), _i64(vi_sN), _i64(H), _i64(W), _p(col), _p(values))
+    return crow, col, values, row_pixels
+
+
+def interpolation_matrix_backward(grad_values, vi, index_img, bary_img, row_pixels):
+    index_img = index_img.contiguous()
+    N, H, W = index_img.shape
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    g = grad_values.contiguous()
+    rp = row_pixels.contiguous()
+    bary_grad = th.zeros(N, 3, H, W, dtype=g.dtype)
+    _call("interpolation_matrix_backward", _sfx(g), _p(g), _p(vi_c), _p(index_img), _p(rp), _i64(rp.numel()), _i64(N),
+          _i64(F), _i64(vi_sN), _i64(H), _i64(W), _p(bary_grad))
+    return bary_grad
+
+
+def normal_matrix_structure(vi, num_vertices):
+    """CSR pattern of A^T A and the per-face pair lookup (interpolate_module.cpp:167-241):
+    returns (crow_indices int64 [V+1], col_indices int64 [nnz], pair_indices int32 [N,F,9])."""
+    import numpy as np
+
+    v = vi.cpu().numpy().astype(np.int64)
+    assert v.ndim == 3
+    assert (v >= 0).all() and (v < num_vertices).all(), "vi contains a vertex index outside [0, num_vertices)"
+    keys = (v[:, :, :, None] * num_vertices + v[:, :, None, :]).reshape(-1)  # [N,F,3(i),3(j)] -> rows[i]*V + rows[j]
+    uniq = np.unique(keys)
+    rows = uniq // max(num_vertices, 1)
+    cols = uniq - rows * num_vertices
+    counts = np.bincount(rows, minlength=num_vertices)[:num_vertices]
+    crow = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    pair = np.searchsorted(uniq, keys).astype(np.int32).reshape(v.shape[0], v.shape[1], 9)
+    return th.from_numpy(crow), th.from_numpy(cols.astype(np.int64)), th.from_numpy(pair)
+
+
+def normal_matrix_values(pair_indices, index_img, bary_img, nnz):
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    pair = pair_indices.contiguous()
+    N, H, W = index_img.shape
+    F = pair.shape[1]
+    values = th.zeros(nnz, dtype=bary_img.dtype)
+    _call("normal_matrix_values", _sfx(bary_img), _p(pair), _p(index_img), _p(bary_img), _i64(N), _i64(F), _i64(F * 9),
+          _i64(H), _i64(W), _p(values))
+    return values
+
+
+def normal_matrix_values_backward(grad_values, pair_indices, index_img, bary_img):
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    pair = pair_indices.contiguous()
+    g = grad_values.contiguous()
+    N, H, W = index_img.shape
+    F = pair.shape[1]
+    bary_grad = th.zeros(N, 3, H, W, dtype=bary_img.dtype)
+    _call("normal_matrix_values_backward", _sfx(bary_img), _p(g), _p(pair), _p(index_img), _p(bary_img), _i64(N),
+          _i64(F), _i64(F * 9), _i64(H), _i64(W), _p(bary_grad))
+    return bary_grad

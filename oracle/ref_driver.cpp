@@ -93,6 +93,30 @@ torch::Tensor ref_edge_grad_fwd_check(
   return edge_grad_estimator_cpu_fwd(v_pix, v_pix_img, vi, img, index_img, max_dp_dr);
 }
 
+std::vector<torch::Tensor> ref_interpolation_matrix(
+    const torch::Tensor& vi, const torch::Tensor& index_img, const torch::Tensor& bary_img) {
+  auto r = interpolation_matrix_cpu(vi, index_img, bary_img);
+  return {std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r)};
+}
+
+torch::Tensor ref_interpolation_matrix_backward(
+    const torch::Tensor& grad_values, const torch::Tensor& vi, const torch::Tensor& index_img,
+    const torch::Tensor& bary_img, const torch::Tensor& row_pixels) {
+  return interpolation_matrix_cpu_backward(grad_values, vi, index_img, bary_img, row_pixels);
+}
+
+torch::Tensor ref_normal_matrix_values(
+    const torch::Tensor& pair_indices, const torch::Tensor& index_img, const torch::Tensor& bary_img,
+    int64_t nnz) {
+  return interpolation_normal_matrix_values_cpu(pair_indices, index_img, bary_img, nnz);
+}
+
+torch::Tensor ref_normal_matrix_values_backward(
+    const torch::Tensor& grad_values, const torch::Tensor& pair_indices, const torch::Tensor& index_img,
+    const torch::Tensor& bary_img) {
+  return interpolation_normal_matrix_values_cpu_backward(grad_values, pair_indices, index_img, bary_img);
+}
+
 } // namespace
 
 // TORCH_LIBRARY stringifies its first argument, so expand REF_NS through one more macro level.
@@ -112,6 +136,18 @@ DRTK_REF_LIBRARY(REF_NS, m) {
   m.def(
       "edge_grad_backward(Tensor v_pix, Tensor img, Tensor index_img, Tensor vi, Tensor grad_outputs, float max_dp_dr) -> Tensor",
       &ref_edge_grad_backward);
+  m.def(
+      "interpolation_matrix(Tensor vi, Tensor index_img, Tensor bary_img) -> Tensor[]",
+      &ref_interpolation_matrix);
+  m.def(
+      "interpolation_matrix_backward(Tensor grad_values, Tensor vi, Tensor index_img, Tensor bary_img, Tensor row_pixels) -> Tensor",
+      &ref_interpolation_matrix_backward);
+  m.def(
+      "normal_matrix_values(Tensor pair_indices, Tensor index_img, Tensor bary_img, int nnz) -> Tensor",
+      &ref_normal_matrix_values);
+  m.def(
+      "normal_matrix_values_backward(Tensor grad_values, Tensor pair_indices, Tensor index_img, Tensor bary_img) -> Tensor",
+      &ref_normal_matrix_values_backward);
   m.def(
       "edge_grad_fwd_check(Tensor v_pix, Tensor v_pix_img, Tensor vi, Tensor img, Tensor index_img, float max_dp_dr) -> Tensor",
       &ref_edge_grad_fwd_check);

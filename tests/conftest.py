@@ -34,6 +34,19 @@ GOLDEN_SCENES = [
 ]
 
 
+SPARSE_SCENES = ["spheres_f32", "ragged_f32", "tutorial3_f64"]
+
+
+def load_sparse(name):
+    """(vi [N,F,3] contiguous, index_img, bary_img, V, seeded grads, expected outputs) for tests/golden/sparse_<name>.npz;
+    the images are the reference outputs stored in the scene's own fixture."""
+    i, o = load_golden(name)
+    gi, go = load_golden("sparse_" + name)
+    vi, index = i["vi"], o["index_img"]
+    vib = (vi[None].expand(index.shape[0], -1, -1) if vi.ndim == 2 else vi).contiguous()
+    return vib, index, o["render_bary"], i["v"].shape[1], gi, go
+
+
 @pytest.fixture(scope="session")
 def oracle_ops():
     from backends import OracleBackend, make_ops

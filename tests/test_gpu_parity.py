@@ -6,7 +6,7 @@ Bars: index_img and rasterize depth bit-exact; every other float within
 """
 import pytest
 import torch as th
-from conftest import GOLDEN_SCENES, load_golden
+from conftest import GOLDEN_SCENES, SPARSE_SCENES, load_golden, load_sparse
 
 pytestmark = pytest.mark.gpu
 
@@ -311,3 +311,114 @@ def test_transform_pinhole_matches_pytorch_formulation(dtype, shared):
         v2 = v64.detach().to(dtype).to(DEV)[0].requires_grad_(True)
         out2 = transform(v2[None].expand(N, -1, -1), *cams)
         assert th.equal(out2, out)
+
+
+# ---- sparse interpolation operators ------------------------------------------
+
+
+@pytest.mark.parametrize("name", SPARSE_SCENES)
+def test_sparse_operators_capi_match_reference_fixture(name):
+    """C ABI: integer outputs (columns, row pixels) bit-exact; interpolation-matrix values are
+    copies of bary -> bit-exact; atomically accumulated normal-matrix values within 1e-5."""
+    from drtk_amd import capi
+
+    vi, index, bary, V, gi, go = load_sparse(name)
+    dvi, dindex, dbary = dev(vi), dev(index), dev(bary)
+    crow, col, values, rows = capi.interpolation_matrix(dvi, dindex, dbary)
+    R = rows.numel()
+    assert th.equal(crow.cpu(), th.arange(0, 3 * R + 1, 3))
+    assert th.equal(col.cpu().int(), go["col_indices"]) and th.equal(rows.cpu().int(), go["row_pixels"])
+    assert th.equal(values.cpu(), go["values"])
+    bg = capi.interpolation_matrix_backward(dev(gi["g_im"]), dvi, dindex, rows)
+    assert th.equal(bg.cpu(), go["im_bary_grad"])
+    pair, nnz = dev(go["nm_pair"]), go["nm_col"].numel()
+    close(capi.interpolation_normal_matrix_values(pair, dindex, dbary, nnz), go["nm_values"], "normal matrix values")
+    close(capi.interpolation_normal_matrix_values_backward(dev(gi["g_nm"]), pair, dindex, dbary), go["nm_bary_grad"],
+          "normal matrix values backward")
+
+
+@pytest.mark.parametrize("name", SPARSE_SCENES)
+def test_sparse_operators_python_api_and_autograd(name):
+    import drtk_amd
+
+    vi, index, bary, V, gi, go = load_sparse(name)
+    dindex = dev(index)
+    dbary = dev(bary).requires_grad_(True)
+    i, _ = load_golden(name)
+    dvi = dev(i["vi"])  # [F,3] where the scene shares topology: exercises the stride-0 broadcast
+    A = drtk_amd.interpolation_matrix(dvi, dindex, dbary, V)
+    R = go["row_pixels"].numel()
+    assert A.layout == th.sparse_csr and tuple(A.shape) == (R, V)
+    assert th.equal(A.col_indices().cpu().int(), go["col_indices"]) and th.equal(A.values().detach().cpu(), go["values"])
+    (A.values() * dev(gi["g_im"])).sum().backward()
+    assert th.equal(dbary.grad.cpu(), go["im_bary_grad"])
+
+    # A @ X reproduces interpolate() on the foreground pixels
+    attr = dev(i["attr"])
+    if attr.shape[0] == 1 or i["vi"].ndim == 2:
+        X = attr[0]
+        img = drtk_amd.interpolate(attr.expand(index.shape[0], -1, -1).contiguous(), dvi, dindex, dbary.detach())
+        want = img.permute(0, 2, 3, 1).reshape(-1, X.shape[1])[dev(go["row_pixels"]).long()]
+        if all((attr[k] == attr[0]).all() for k in range(attr.shape[0])):
+            close(A.detach() @ X, want, "A @ X vs interpolate", atol=2e-5)
+
+    dbary.grad = None
+    th.ops.drtk_amd_ext.normal_matrix_cache_clear()
+    M = drtk_amd.interpolation_normal_matrix(dvi, dindex, dbary, V)
+    assert M.layout == th.sparse_csr and tuple(M.shape) == (V, V)
+    assert th.equal(M.crow_indices().cpu().int(), go["nm_crow"]) and th.equal(M.col_indices().cpu().int(), go["nm_col"])
+    close(M.values(), go["nm_values"], "normal matrix values (python api)")
+    (M.values() * dev(gi["g_nm"])).sum().backward()
+    close(dbary.grad, go["nm_bary_grad"], "normal matrix backward (python api)")
+    # second call with the same face tensor hits the pattern cache and returns the same device buffers
+    M2 = drtk_amd.interpolation_normal_matrix(dvi, dindex, dbary.detach(), V)
+    hits, misses, _ = th.ops.drtk_amd_ext.normal_matrix_cache_stats()
+    assert hits >= 1 and misses == 1
+    assert M2.col_indices().data_ptr() == M.col_indices().data_ptr()
+    close(M2.values(), go["nm_values"], "normal matrix values (cache hit)")
+    # the values op on its own, with the cached pair table
+    _, _, pair = th.ops.drtk_amd_ext.normal_matrix_structure(
+        dvi[None].expand(index.shape[0], -1, -1) if dvi.ndim == 2 else dvi, V)
+    vals = th.ops.interpolate_ext.interpolation_normal_matrix_values(pair, dindex, dbary.detach(), go["nm_col"].numel())
+    close(vals, go["nm_values"], "interpolation_normal_matrix_values op")
+
+
+def test_sparse_operators_full_size_properties():
+    """BASELINE-size check through size-independent properties: rows of A sum to 1, A^T A (assembled
+    by the values kernel) equals (A^T @ A) computed by torch's sparse matmul, its entries sum to
+    the foreground pixel count, and the matrix is symmetric."""
+    import drtk_amd
+    from drtk_amd import synthetic as S
+
+    N, H, W = 2, 1024, 1024
+    v_pix, vi = S.sphere_views(N, *S.MESH_SIZES["10k"], H, W, lobes=0.15, second_sphere=True, device=DEV)
+    V = v_pix.shape[1]
+    index = drtk_amd.rasterize(v_pix, vi, H, W)
+    _, bary = drtk_amd.render(v_pix, vi, index)
+    A = drtk_amd.interpolation_matrix(vi, index, bary, V)
+    R = int((index != -1).sum())
+    assert A.shape[0] == R and R > 100000
+    close(A.values().view(-1, 3).sum(1), th.ones(R), "rows of A sum to one")
+    cols = A.col_indices().view(-1, 3)
+    assert bool((cols[:, 0] < cols[:, 1]).all()) and bool((cols[:, 1] < cols[:, 2]).all())
+    M = drtk_amd.interpolation_normal_matrix(vi, index, bary, V)
+    close(M.values().sum()[None], th.tensor([float(R)]), "sum of A^T A == #foreground", rtol=1e-4)
+    Ad = A.to_sparse_coo()
+    ref = th.sparse.mm(Ad.t(), Ad).to_dense()
+    got = M.to_dense()
+    close(got, ref, "A^T A", atol=1e-3, rtol=1e-4)
+    close(got, got.T, "symmetry", atol=1e-3, rtol=1e-4)
+
+
+def test_sparse_operators_empty_and_background_only():
+    import drtk_amd
+
+    vi = th.tensor([[0, 1, 2]], dtype=th.int32, device=DEV)
+    index = th.full((2, 8, 8), -1, dtype=th.int32, device=DEV)
+    bary = th.zeros(2, 3, 8, 8, device=DEV, requires_grad=True)
+    A = drtk_amd.interpolation_matrix(vi, index, bary, 3)
+    assert tuple(A.shape) == (0, 3) and A.values().numel() == 0
+    M = drtk_amd.interpolation_normal_matrix(vi, index, bary, 3)
+    assert tuple(M.shape) == (3, 3) and M.values().numel() == 9 and float(M.values().abs().sum()) == 0.0
+    M.values().sum().backward()
+    assert float(bary.grad.abs().sum()) == 0.0

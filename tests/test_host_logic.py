@@ -55,6 +55,9 @@ def test_torch_operator_schemas_match_reference():
         "rasterize_ext::rasterize": "rasterize_ext::rasterize(Tensor v, Tensor vi, int height, int width, bool wireframe) -> Tensor[]",
         "render_ext::render": "render_ext::render(Tensor v, Tensor vi, Tensor index_img) -> Tensor[]",
         "interpolate_ext::interpolate": "interpolate_ext::interpolate(Tensor vert_attributes, Tensor vi, Tensor index_img, Tensor bary_img) -> Tensor",
+        "interpolate_ext::interpolation_matrix": "interpolate_ext::interpolation_matrix(Tensor vi, Tensor index_img, Tensor bary_img) -> (Tensor, Tensor, Tensor, Tensor)",
+        "interpolate_ext::interpolation_normal_matrix": "interpolate_ext::interpolation_normal_matrix(Tensor vi, Tensor index_img, Tensor bary_img, int num_vertices) -> (Tensor, Tensor, Tensor)",
+        "interpolate_ext::interpolation_normal_matrix_values": "interpolate_ext::interpolation_normal_matrix_values(Tensor pair_indices, Tensor index_img, Tensor bary_img, int nnz) -> Tensor",
         "edge_grad_ext::edge_grad_estimator": "edge_grad_ext::edge_grad_estimator(Tensor v_pix, Tensor v_pix_img, Tensor vi, Tensor img, Tensor index_img, float max_dp_dr=10000.) -> Tensor",
     }
     for name, schema in want.items():
@@ -79,6 +82,8 @@ def test_python_api_mirrors_drtk_signatures():
     assert params(drtk_amd.edge_grad_estimator) == [
         ("v_pix", E), ("vi", E), ("bary_img", E), ("img", E), ("index_img", E), ("v_pix_img_hook", None),
         ("max_dp_dr", 1e4)]
+    sparse = [("vi", E), ("index_img", E), ("bary_img", E), ("num_vertices", E)]  # drtk/interpolate.py:53-58,127-132
+    assert params(drtk_amd.interpolation_matrix) == sparse and params(drtk_amd.interpolation_normal_matrix) == sparse
     assert drtk_amd.__version__ == "0.1.0"
 
 
@@ -115,3 +120,72 @@ def test_synthetic_mesh_sizes():
     assert v.shape == (56, 3) and vi.shape == (96, 3) and vi.dtype == th.int32
     vp, _ = S.sphere_views(3, 6, 8, 32, 32)
     assert vp.shape == (3, 56, 3) and (vp[..., 2] > 1.9).all() and (vp[..., 2] < 4.1).all()
+
+
+def test_normal_matrix_pattern_builder_and_cache():
+    """The topology-only half of interpolation_normal_matrix (interpolate_module.cpp:28-262) runs on
+    whatever device vi lives on, so its logic is checked here on CPU tensors: pattern == the
+    oracle's restatement, stride-0 batches analysed once, identity+version keyed LRU of 128."""
+    import drtk_amd  # noqa: F401
+    import oracle as O
+    from conftest import load_sparse
+
+    ops = th.ops.drtk_amd_ext
+    vi, _, _, V, _, go = load_sparse("ragged_f32")
+    ops.normal_matrix_cache_clear()
+    crow, col, pair = ops.normal_matrix_structure(vi, V)
+    assert crow.dtype == th.int64 and col.dtype == th.int64 and pair.dtype == th.int32
+    assert th.equal(crow.int(), go["nm_crow"]) and th.equal(col.int(), go["nm_col"]) and th.equal(pair, go["nm_pair"])
+    assert ops.normal_matrix_cache_stats() == [0, 1, 1]
+    ops.normal_matrix_structure(vi, V)
+    assert ops.normal_matrix_cache_stats() == [1, 1, 1]  # hit: same tensor, same version
+    ops.normal_matrix_structure(vi.clone(), V)
+    assert ops.normal_matrix_cache_stats() == [1, 2, 2]  # another tensor with equal content misses
+    vi.add_(0)  # in-place edit bumps the version counter
+    ops.normal_matrix_structure(vi, V)
+    assert ops.normal_matrix_cache_stats() == [1, 3, 3]
+    ops.normal_matrix_structure(vi, V + 5)  # num_vertices is part of the key
+    assert ops.normal_matrix_cache_stats() == [1, 4, 4]
+
+    # shared topology: a stride-0 batch is analysed once and handed back as a stride-0 expand
+    face = th.tensor([[0, 1, 2], [2, 1, 3]], dtype=th.int32)
+    shared = face[None].expand(4, -1, -1)
+    crow_s, col_s, pair_s = ops.normal_matrix_structure(shared, 4)
+    assert pair_s.shape == (4, 2, 9) and pair_s.stride(0) == 0
+    crow_o, col_o, pair_o = O.normal_matrix_structure(shared.contiguous(), 4)
+    assert th.equal(crow_s, crow_o) and th.equal(col_s, col_o) and th.equal(pair_s.contiguous(), pair_o)
+
+    # eviction: 128 entries
+    ops.normal_matrix_cache_clear()
+    keep = [th.tensor([[[0, 1, 2]]], dtype=th.int32) for _ in range(130)]
+    for t in keep:
+        ops.normal_matrix_structure(t, 3)
+    assert ops.normal_matrix_cache_stats() == [0, 130, 128]
+    ops.normal_matrix_structure(keep[0], 3)  # the oldest was evicted
+    assert ops.normal_matrix_cache_stats()[1] == 131
+    ops.normal_matrix_structure(keep[129], 3)
+    assert ops.normal_matrix_cache_stats()[0] == 1
+    ops.normal_matrix_cache_clear()
+
+    # error behaviour (interpolate_module.cpp:132-137,150-153,181-183)
+    with pytest.raises(RuntimeError, match="outside \\[0, num_vertices\\)"):
+        ops.normal_matrix_structure(face[None], 3)
+    with pytest.raises(RuntimeError, match="non-negative"):
+        ops.normal_matrix_structure(face[None], -1)
+    with pytest.raises(RuntimeError, match="positive when faces are present"):
+        ops.normal_matrix_structure(face[None], 0)
+    crow_e, col_e, pair_e = ops.normal_matrix_structure(th.empty(2, 0, 3, dtype=th.int32), 5)
+    assert crow_e.tolist() == [0] * 6 and col_e.numel() == 0 and pair_e.shape == (2, 0, 9)
+
+
+def test_sparse_ops_cpu_tensors_fail_loudly():
+    import drtk_amd
+
+    vi = th.tensor([[[0, 1, 2]]], dtype=th.int32)
+    index = th.zeros(1, 4, 4, dtype=th.int32)
+    bary = th.full((1, 3, 4, 4), 1 / 3)
+    for fn in (lambda: drtk_amd.interpolation_matrix(vi, index, bary, 3),
+               lambda: drtk_amd.interpolation_normal_matrix(vi, index, bary, 3),
+               lambda: th.ops.interpolate_ext.interpolation_normal_matrix_values(th.zeros(1, 1, 9, dtype=th.int32), index, bary, 9)):
+        with pytest.raises(RuntimeError, match="HIP\\) path only"):
+            fn()

@@ -4,7 +4,7 @@ index/depth images, every forward float tensor, and -- single-threaded, same acc
 every gradient."""
 import pytest
 import torch as th
-from conftest import GOLDEN_SCENES, load_golden
+from conftest import GOLDEN_SCENES, SPARSE_SCENES, load_golden, load_sparse
 
 import oracle as O
 
@@ -106,3 +106,50 @@ def test_two_triangles_trajectory_reproduced_by_oracle(oracle_ops):
             assert abs(float(loss.detach()) - want[it]) <= 1e-3 * want[it] + 1e-9, (it, float(loss.detach()), want[it])
         optim.step()
     assert float(loss.detach()) < 0.2 * want[0]
+
+
+@pytest.mark.parametrize("name", SPARSE_SCENES)
+def test_oracle_sparse_operators_match_reference_fixture(name):
+    """interpolation_matrix / normal-matrix values, forward and backward: bit-exact against the
+    reference's CPU kernels (interpolate_kernel_cpu.cpp:411-693)."""
+    vi, index, bary, V, gi, go = load_sparse(name)
+    crow, col, values, rows = O.interpolation_matrix(vi, index, bary)
+    R = rows.numel()
+    assert R == int((index != -1).sum()) and th.equal(crow, th.arange(0, 3 * R + 1, 3))
+    assert th.equal(col.int(), go["col_indices"]) and th.equal(values, go["values"])
+    assert th.equal(rows.int(), go["row_pixels"])
+    assert (col.view(-1, 3)[:, 0] < col.view(-1, 3)[:, 1]).all() and (col.view(-1, 3)[:, 1] < col.view(-1, 3)[:, 2]).all()
+    assert th.equal(O.interpolation_matrix_backward(gi["g_im"], vi, index, bary, rows), go["im_bary_grad"])
+    p_crow, p_col, pair = O.normal_matrix_structure(vi, V)
+    assert th.equal(p_crow.int(), go["nm_crow"]) and th.equal(p_col.int(), go["nm_col"]) and th.equal(pair, go["nm_pair"])
+    nnz = p_col.numel()
+    assert th.equal(O.normal_matrix_values(pair, index, bary, nnz), go["nm_values"])
+    assert th.equal(O.normal_matrix_values_backward(gi["g_nm"], pair, index, bary), go["nm_bary_grad"])
+
+
+@pytest.mark.parametrize("name", SPARSE_SCENES)
+def test_sparse_pattern_is_pinned_by_reference_values(name):
+    """The A^T A pattern is restated topology code; pin it with reference outputs only: the
+    reference's normal-matrix values placed through the pattern equal A^T A of the reference's
+    interpolation matrix, the pattern is symmetric, sorted and duplicate-free."""
+    vi, index, bary, V, _, go = load_sparse(name)
+    R = go["row_pixels"].numel()
+    A = th.sparse_csr_tensor(th.arange(0, 3 * R + 1, 3), go["col_indices"].long(), go["values"].double(), size=(R, V))
+    crow, col = go["nm_crow"].long(), go["nm_col"].long()
+    AtA = th.sparse_csr_tensor(crow, col, go["nm_values"].double(), size=(V, V)).to_dense()
+    ref = A.to_dense().T @ A.to_dense()
+    tol = 1e-4 if go["values"].dtype == th.float32 else 1e-11
+    assert (AtA - ref).abs().max() < tol
+    rows = th.repeat_interleave(th.arange(V), crow[1:] - crow[:-1])
+    keys = rows * V + col
+    assert (keys[1:] > keys[:-1]).all()
+    dense_pat = th.zeros(V, V, dtype=th.bool)
+    dense_pat[rows, col] = True
+    assert th.equal(dense_pat, dense_pat.T)
+    # every referenced vertex has its diagonal; the pattern is exactly the face adjacency
+    adj = th.zeros(V, V, dtype=th.bool)
+    f = vi.reshape(-1, 3).long()
+    for a in range(3):
+        for b in range(3):
+            adj[f[:, a], f[:, b]] = True
+    assert th.equal(dense_pat, adj)
