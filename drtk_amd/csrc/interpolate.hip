@@ -280,6 +280,160 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   }
 }
 
+// Backward, wide-channel fast path (vertex + bary gradients, C % 16 == 0, 16-byte aligned rows).
+//
+// Same tiling and phase structure as interpolate_backward_kernel<.., 16>, but written so that no
+// memory round trip is ever waited for in isolation (the generic kernel's phase 1 is a chain of up
+// to nine dependent global waits per row -- index, corners, bary, then go/attribute loads per
+// 4-channel block -- and PMC shows its waves parked on s_waitcnt 72 % of their life):
+//   * the triangle and corner ids of all four rows are fetched once, up front;
+//   * every global load of a row (16 grad_out planes, 3 bary planes, 12 attribute float4) is issued
+//     in one batch, and the NEXT row's grad_out/bary batch is issued before the current row's
+//     phase 2, so it lands while the wave is busy in LDS;
+//   * the per-pixel bary-gradient dot products run after phase 2 and read grad_out back from the
+//     LDS staging rows, which frees the registers for the prefetch.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
+    const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
+    const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
+    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
+    int dbg) {
+  using V4 = typename Vec4<T>::type;
+  constexpr int CH = 16;
+  constexpr int kWaves = kBlock / kWave;
+  constexpr int kPasses = kTileRows / kWaves;
+  static_assert(kPasses == 4, "row pipeline below is written for 4 rows per wave");
+  __shared__ __attribute__((aligned(16))) T s_g[kWaves][CH * kRunPad];
+  __shared__ __attribute__((aligned(16))) T s_b[kWaves][3 * kRunPad];
+  __shared__ int32_t s_vid[kWaves][3 * kRunPad];
+
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int wave = threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int x = txi * kWave + lane;
+  const int y0 = tyi * kTileRows + wave * kPasses;
+  const T* attrs_n = attrs + int64_t(n) * V * C;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  T* attr_grad_n = attr_grad + int64_t(n) * V * C;
+  const T* go_n = grad_out + int64_t(n) * C * HW;
+  const T* bary_n = bary_img + int64_t(n) * 3 * HW;
+  T* bgrad_n = bary_grad + int64_t(n) * 3 * HW;
+
+  auto load_tr = [&](int ps) -> int32_t {
+    const int y = y0 + ps;
+    return (ps < kPasses && x < W && y < H) ? index_img[int64_t(n) * HW + int64_t(y) * W + x] : -1;
+  };
+  auto load_face = [&](int32_t t, int32_t& a0, int32_t& a1, int32_t& a2) {
+    a0 = a1 = a2 = 0;
+    if (t != -1) {
+      const int32_t* face = vi_n + int64_t(t) * 3;
+      a0 = face[0], a1 = face[1], a2 = face[2];
+    }
+  };
+
+  for (int c0 = 0; c0 < C; c0 += CH) {
+    T G[CH], B[3];
+    auto load_row = [&](int ps, bool cov) { // grad_out + bary of row ps; zeros where uncovered
+      const int64_t pix = int64_t(y0 + ps) * W + x;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) G[c] = cov ? go_n[int64_t(c0 + c) * HW + pix] : T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) B[k] = cov ? bary_n[int64_t(k) * HW + pix] : T(0);
+    };
+    // rotating state: row ps (tr, v*), row ps+1 (tr_n, vn*), row ps+2 (tr_nn)
+    int32_t tr = load_tr(0), tr_n = load_tr(1), tr_nn = -1;
+    int32_t v0, v1, v2, vn0 = 0, vn1 = 0, vn2 = 0;
+    load_face(tr, v0, v1, v2);
+    load_row(0, tr != -1);
+#pragma unroll 1
+    for (int ps = 0; ps < kPasses; ++ps) {
+      const int y = y0 + ps;
+      const int64_t pix = int64_t(y) * W + x;
+      const bool covered = tr != -1;
+      // 1. stage this row
+#pragma unroll
+      for (int c = 0; c < CH; ++c) s_g[wave][c * kRunPad + lane] = G[c];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s_b[wave][k * kRunPad + lane] = B[k];
+      s_vid[wave][0 * kRunPad + lane] = v0;
+      s_vid[wave][1 * kRunPad + lane] = v1;
+      s_vid[wave][2 * kRunPad + lane] = v2;
+      unsigned long long heads, cov;
+      run_masks(tr, heads, cov);
+      // 2. first half of the attribute rows of this row's triangles (consumed after phase 2)
+      constexpr int QH = CH / 8; // float4 per corner and half
+      const T* a0 = attrs_n + int64_t(v0) * C + c0;
+      const T* a1 = attrs_n + int64_t(v1) * C + c0;
+      const T* a2 = attrs_n + int64_t(v2) * C + c0;
+      V4 A0[QH], A1[QH], A2[QH];
+      if (covered) {
+#pragma unroll
+        for (int q = 0; q < QH; ++q) {
+          A0[q] = *reinterpret_cast<const V4*>(a0 + 4 * q);
+          A1[q] = *reinterpret_cast<const V4*>(a1 + 4 * q);
+          A2[q] = *reinterpret_cast<const V4*>(a2 + 4 * q);
+        }
+      }
+      // 3. the next row's operands (and the ids of the row after it) fly under phase 2
+      if (ps + 1 < kPasses) {
+        load_row(ps + 1, tr_n != -1);
+        load_face(tr_n, vn0, vn1, vn2);
+        tr_nn = load_tr(ps + 2);
+      }
+      wave_lds_sync();
+      // 4. phase 2: run sums per (corner, channel) lane -> one 64-byte atomic request per corner and run
+      //    (a per-vertex LDS table in front of the atomics was measured slower here: 1.01 vs 0.83 ms)
+      if (cov != 0 && !(dbg & 1)) {
+        const T* sg = s_g[wave];
+        const T* sb = s_b[wave];
+        scatter_runs<T>(
+            heads, cov, nullptr, s_vid[wave], 3 * CH, CH, static_cast<T*>(nullptr), 0, attr_grad_n, C, c0,
+            [sg, sb](int k, int c, int g4, T* xv) {
+              const V4 a = *reinterpret_cast<const V4*>(sg + c * kRunPad + 4 * g4);
+              const V4 b = *reinterpret_cast<const V4*>(sb + k * kRunPad + 4 * g4);
+              xv[0] = a.x * b.x, xv[1] = a.y * b.y, xv[2] = a.z * b.z, xv[3] = a.w * b.w;
+            }, dbg);
+      }
+      // 5. bary gradient: interpolate_kernel.cu:238-246 accumulation order (channels ascending)
+      T bg0 = T(0), bg1 = T(0), bg2 = T(0);
+      if (covered && !(dbg & 8)) {
+        V4 D0[QH], D1[QH], D2[QH]; // second half: requested now, used after the first half's products
+#pragma unroll
+        for (int q = 0; q < QH; ++q) {
+          D0[q] = *reinterpret_cast<const V4*>(a0 + 4 * (QH + q));
+          D1[q] = *reinterpret_cast<const V4*>(a1 + 4 * (QH + q));
+          D2[q] = *reinterpret_cast<const V4*>(a2 + 4 * (QH + q));
+        }
+        auto dot4 = [&](int q4, const V4& u0, const V4& u1, const V4& u2) {
+          const T g0 = s_g[wave][(4 * q4 + 0) * kRunPad + lane], g1 = s_g[wave][(4 * q4 + 1) * kRunPad + lane];
+          const T g2 = s_g[wave][(4 * q4 + 2) * kRunPad + lane], g3 = s_g[wave][(4 * q4 + 3) * kRunPad + lane];
+          bg0 += g0 * u0.x, bg1 += g0 * u1.x, bg2 += g0 * u2.x;
+          bg0 += g1 * u0.y, bg1 += g1 * u1.y, bg2 += g1 * u2.y;
+          bg0 += g2 * u0.z, bg1 += g2 * u1.z, bg2 += g2 * u2.z;
+          bg0 += g3 * u0.w, bg1 += g3 * u1.w, bg2 += g3 * u2.w;
+        };
+#pragma unroll
+        for (int q = 0; q < QH; ++q) dot4(q, A0[q], A1[q], A2[q]);
+#pragma unroll
+        for (int q = 0; q < QH; ++q) dot4(QH + q, D0[q], D1[q], D2[q]);
+      }
+      if (x < W && y < H) { // channel chunks accumulate in ascending order, like the reference's loop
+        T* bgp = bgrad_n + pix;
+        if (c0 == 0) {
+          bgp[0] = bg0, bgp[HW] = bg1, bgp[2 * HW] = bg2;
+        } else if (covered) {
+          bgp[0] += bg0, bgp[HW] += bg1, bgp[2 * HW] += bg2;
+        }
+      }
+      wave_lds_sync();
+      tr = tr_n, v0 = vn0, v1 = vn1, v2 = vn2;
+      tr_n = tr_nn;
+    }
+  }
+}
+
 template <typename T>
 int interpolate_impl(
     const T* attrs, const int32_t* vi, const int32_t* index_img, const T* bary_img, int64_t N,
@@ -333,7 +487,15 @@ int interpolate_backward_impl(
       vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad,  \
       debug_flags())
   const bool small_c = C <= 4;
-  if (attr_grad && bary_grad) {
+  // float only: the double instantiation would need > 256 VGPRs for the same pipeline
+  const bool wide = sizeof(T) == 4 && attr_grad && bary_grad && cvec && (C % 16 == 0) && !(debug_flags() & 128);
+  if (wide) {
+    if constexpr (sizeof(T) == 4) {
+      hipLaunchKernelGGL(
+          (interpolate_backward_wide_kernel<T>), grid, block, 0, stream, grad_out, attrs, vi, index_img, bary_img,
+          V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags());
+    }
+  } else if (attr_grad && bary_grad) {
     if (small_c) {
       if (cvec) LAUNCH(true, true, 4, 4); else LAUNCH(true, true, 1, 4);
     } else {
