@@ -19,7 +19,7 @@ INC = os.path.join(ROOT, "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-KERNEL_SRCS = ["rasterize.hip", "render.hip", "interpolate.hip", "edge_grad.hip", "transform.hip", "interp_matrix.hip", "capi.hip"]
+KERNEL_SRCS = ["rasterize.hip", "render.hip", "interpolate.hip", "edge_grad.hip", "transform.hip", "interp_matrix.hip", "mipmap.hip", "capi.hip"]
 HEADERS = ["common.hpp", "segscatter.hpp"]
 LIB = os.path.join(PKG, "libdrtk_amd.so")
 OPS = os.path.join(PKG, "drtk_amd_torch_ops.so")
@@ -73,7 +73,7 @@ def build_torch_ops(force=False, verbose=True):
     libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
     inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{INC}", "-I/opt/rocm/include"]
     cmd = [
-        os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall",
+        os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-array-bounds",
         "-Wno-unknown-pragmas", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
         f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", *inc, src, "-o", OPS,
         f"-L{PKG}", "-ldrtk_amd", "-Wl,-rpath,$ORIGIN", f"-L{libdir}", "-ltorch", "-ltorch_cpu",

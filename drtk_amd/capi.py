@@ -52,6 +52,8 @@ EXPORTS = [
     "drtk_amd_interpolation_matrix_backward",
     "drtk_amd_interpolation_normal_matrix_values",
     "drtk_amd_interpolation_normal_matrix_values_backward",
+    "drtk_amd_mipmap_grid_sampler_2d",
+    "drtk_amd_mipmap_grid_sampler_2d_backward",
     "drtk_amd_transform_pinhole",
     "drtk_amd_transform_pinhole_backward",
     "drtk_amd_selftest_exact_div",
@@ -264,6 +266,55 @@ def interpolation_normal_matrix_values_backward(grad_values, pair_indices, index
             _i(pair_sN), _i(H), _i(W), _p(bg), _stream(bary_img, stream)),
         "interpolation_normal_matrix_values_backward")
     return bg
+
+
+def _level_table(levels):
+    lv = [t.contiguous() for t in levels]
+    n = len(lv)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lv])
+    lh = (ctypes.c_int64 * n)(*[t.shape[2] for t in lv])
+    lw = (ctypes.c_int64 * n)(*[t.shape[3] for t in lv])
+    return lv, ptrs, lh, lw
+
+
+def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0, interpolation_mode=0,
+                           align_corners=False, force_max_aniso=False, clip_grad=False, stream=None):
+    lv, ptrs, lh, lw = _level_table(levels)
+    grid = grid.contiguous()
+    vt = vt_dxdy_img.contiguous()
+    N, C = lv[0].shape[:2]
+    H, W = grid.shape[1:3]
+    out = th.empty(N, C, H, W, dtype=lv[0].dtype, device=lv[0].device)
+    _check(
+        lib().drtk_amd_mipmap_grid_sampler_2d(
+            ctypes.c_int(_dt(lv[0])), ptrs, lh, lw, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i(N), _i(C), _i(H), _i(W),
+            ctypes.c_int(max_aniso), ctypes.c_int(padding_mode), ctypes.c_int(interpolation_mode),
+            ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)), ctypes.c_int(bool(clip_grad)),
+            _p(out), _stream(lv[0], stream)),
+        "mipmap_grid_sampler_2d")
+    return out
+
+
+def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_aniso, padding_mode=0,
+                                    interpolation_mode=0, align_corners=False, force_max_aniso=False,
+                                    clip_grad=False, stream=None):
+    lv, ptrs, lh, lw = _level_table(levels)
+    grid = grid.contiguous()
+    vt = vt_dxdy_img.contiguous()
+    grad_out = grad_out.contiguous()
+    N, C = lv[0].shape[:2]
+    H, W = grid.shape[1:3]
+    glv = [th.empty_like(t) for t in lv]
+    gptrs = (ctypes.c_void_p * len(lv))(*[t.data_ptr() for t in glv])
+    ggrid = th.empty_like(grid)
+    _check(
+        lib().drtk_amd_mipmap_grid_sampler_2d_backward(
+            ctypes.c_int(_dt(lv[0])), _p(grad_out), ptrs, lh, lw, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i(N), _i(C),
+            _i(H), _i(W), ctypes.c_int(max_aniso), ctypes.c_int(padding_mode), ctypes.c_int(interpolation_mode),
+            ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)), ctypes.c_int(bool(clip_grad)),
+            gptrs, _p(ggrid), _stream(lv[0], stream)),
+        "mipmap_grid_sampler_2d_backward")
+    return glv, ggrid
 
 
 def edge_grad_backward_workspace_bytes(dtype, N, H, W) -> int:

@@ -1,0 +1,539 @@
+// mipmap_grid_sampler_2d -- grid_sample with trilinear mip selection and anisotropic taps, forward
+// and backward.
+//
+// Reference: src/mipmap_grid_sampler/mipmap_grid_sampler_kernel.cu:20-897 (device code), built on
+// PyTorch's grid-sampler primitives (ATen/native/cuda/GridSampler.cuh, UpSample.cuh -- unnormalize,
+// clip / reflect, safe_downgrade_to_int_range, cubic convolution with A = -0.75).
+//
+// Reference shape: one thread per output pixel; for every tap and mip level it walks the channels
+// and read-modify-writes the *global* output once per corner (4 RMW per tap, level and channel).
+// Here: lane = output pixel as well (the uv field is pixel-ordered, so grid / Jacobian loads are one
+// 8- and one 16-byte vector per lane and the channel planes of the output are written coalesced),
+// but
+//   * the tap geometry (source index, padding, corner offsets and weights -- or the 4+4 bicubic
+//     coordinates) is computed once per (tap, level) and reused by all channels,
+//   * channels accumulate in registers in blocks of four and every output element is stored once,
+//   * the level table lives in LDS (levels are selected per lane, so a kernel-argument array would
+//     be indexed through scratch memory).
+// Accumulation order per output element is the reference's (taps, then level d1 / d1+1, then
+// corners), so results match the CPU restatement to rounding of the transcendental log2 only.
+// The forward pass ignores align_corners exactly like the reference (:423 forces it to false);
+// the backward pass honours it (:641 ff).
+#include "common.hpp"
+
+namespace drtk_amd {
+namespace {
+
+constexpr int kMaxLevels = 11; // mipmap_grid_sampler_kernel.cu:16
+
+struct LevelTable {
+  const void* ptr[kMaxLevels];
+  void* grad[kMaxLevels];
+  int h[kMaxLevels];
+  int w[kMaxLevels];
+};
+
+__device__ __forceinline__ float sqrt_rn(float x) {
+  return __fsqrt_rn(x);
+}
+__device__ __forceinline__ double sqrt_rn(double x) {
+  return __dsqrt_rn(x);
+}
+
+// GridSampler.cuh primitives -------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T unnormalize(T coord, int size, bool align_corners, T* grad_in) {
+  if (align_corners) {
+    *grad_in = static_cast<T>(size - 1) / 2;
+    return ((coord + 1.f) / 2) * (size - 1);
+  }
+  *grad_in = static_cast<T>(size) / 2;
+  return ((coord + 1.f) * size - 1) / 2;
+}
+template <typename T>
+__device__ __forceinline__ T clip_coord(T in, int limit, T* grad_in) {
+  if (in <= T(0)) {
+    *grad_in = T(0);
+    return T(0);
+  }
+  const T mx = static_cast<T>(limit - 1);
+  if (in >= mx) {
+    *grad_in = T(0);
+    return mx;
+  }
+  *grad_in = T(1);
+  return in;
+}
+template <typename T>
+__device__ __forceinline__ T clip_plain(T in, int limit) { // ::min(limit-1, ::max(in, 0))
+  const T hi = static_cast<T>(limit - 1);
+  const T lo = in > T(0) ? in : T(0);
+  return hi < lo ? hi : lo;
+}
+template <typename T>
+__device__ __forceinline__ T reflect_coord(T in, int twice_low, int twice_high, T* grad_in) {
+  if (twice_low == twice_high) {
+    *grad_in = T(0);
+    return T(0);
+  }
+  int mult = 1;
+  const T mn = static_cast<T>(twice_low) / 2;
+  const T span = static_cast<T>(twice_high - twice_low) / 2;
+  in = in - mn;
+  if (in < T(0)) {
+    mult = -1;
+    in = -in;
+  }
+  const T extra = fmod(in, span);
+  const int flips = static_cast<int>(floor(in / span));
+  if (flips % 2 == 0) {
+    *grad_in = static_cast<T>(mult);
+    return extra + mn;
+  }
+  *grad_in = static_cast<T>(-mult);
+  return span - extra + mn;
+}
+template <typename T>
+__device__ __forceinline__ T safe_int_range(T x) {
+  if (x > static_cast<T>(INT32_MAX - 1) || x < static_cast<T>(INT32_MIN) || !isfinite(static_cast<double>(x)))
+    return T(-100.0);
+  return x;
+}
+template <typename T>
+__device__ __forceinline__ T compute_coordinates(T coord, int size, int padding, bool align_corners) {
+  T unused;
+  if (padding == 1) {
+    coord = clip_plain(coord, size);
+  } else if (padding == 2) {
+    coord = align_corners ? reflect_coord(coord, 0, 2 * (size - 1), &unused) : reflect_coord(coord, -1, 2 * size - 1, &unused);
+    coord = clip_plain(coord, size);
+  }
+  return safe_int_range(coord);
+}
+template <typename T>
+__device__ __forceinline__ T source_index(T coord, int size, int padding, bool align_corners, T* grad_in) {
+  T g_un, g_clip = T(1), g_refl = T(1);
+  coord = unnormalize(coord, size, align_corners, &g_un);
+  if (padding == 1) {
+    coord = clip_coord(coord, size, &g_clip);
+    g_un = g_un * g_clip;
+  } else if (padding == 2) {
+    coord = align_corners ? reflect_coord(coord, 0, 2 * (size - 1), &g_refl) : reflect_coord(coord, -1, 2 * size - 1, &g_refl);
+    coord = clip_coord(coord, size, &g_clip);
+    g_un = g_un * g_refl * g_clip;
+  }
+  *grad_in = g_un;
+  return safe_int_range(coord);
+}
+template <typename T>
+__device__ __forceinline__ void cubic_coeffs(T co[4], T t) { // UpSample.cuh get_cubic_upsampling_coefficients
+  const T A = T(-0.75);
+  T x = t + T(1.0);
+  co[0] = ((A * x - 5 * A) * x + 8 * A) * x - 4 * A;
+  x = t;
+  co[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  x = T(1.0) - t;
+  co[2] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  x = x + T(1.0);
+  co[3] = ((A * x - 5 * A) * x + 8 * A) * x - 4 * A;
+}
+template <typename T>
+__device__ __forceinline__ void cubic_coeffs_grad(T co[4], T t) { // grid_utils.h:130-144
+  const T A = T(-0.75);
+  T x = -1 - t;
+  co[0] = (-3 * A * x - 10 * A) * x - 8 * A;
+  x = -t;
+  co[1] = (-3 * (A + 2) * x - 2 * (A + 3)) * x;
+  x = 1 - t;
+  co[2] = (3 * (A + 2) * x - 2 * (A + 3)) * x;
+  x = 2 - t;
+  co[3] = (3 * A * x - 10 * A) * x + 8 * A;
+}
+
+// Per-pixel tap setup: mipmap_grid_sampler_kernel.cu:441-508 (== :679-746 in the backward kernel).
+template <typename T>
+struct Taps {
+  T u, v, du, dv, a;
+  int d1, n;
+};
+template <typename T>
+__device__ __forceinline__ Taps<T> setup_taps(
+    const T* __restrict__ grid, const T* __restrict__ vt, int64_t index, int inp_H, int inp_W, int mipmaps,
+    int max_aniso, bool force_max_aniso, bool clip_grad) {
+  Taps<T> t;
+  T dudx, dvdx, dudy, dvdy;
+  if constexpr (sizeof(T) == 4) {
+    const float2 g = *reinterpret_cast<const float2*>(grid + index * 2);
+    const float4 j = *reinterpret_cast<const float4*>(vt + index * 4);
+    t.u = g.x, t.v = g.y;
+    dudx = j.x, dvdx = j.y, dudy = j.z, dvdy = j.w;
+  } else {
+    const double2 g = *reinterpret_cast<const double2*>(grid + index * 2);
+    const double2 j0 = *reinterpret_cast<const double2*>(vt + index * 4);
+    const double2 j1 = *reinterpret_cast<const double2*>(vt + index * 4 + 2);
+    t.u = g.x, t.v = g.y;
+    dudx = j0.x, dvdx = j0.y, dudy = j1.x, dvdy = j1.y;
+  }
+  // footprint lengths (:455-456, written with pow there): sqrt(a*a + b*b + 1e-12) with IEEE multiply and
+  // sqrt -- the tap count below is a discontinuous function of them, so they are evaluated in the one
+  // form that is bit-reproducible everywhere
+  const T ax = fabs(dudx * inp_W), bx = fabs(dvdx * inp_H);
+  const T ay = fabs(dudy * inp_W), by = fabs(dvdy * inp_H);
+  const T px = sqrt_rn(ax * ax + bx * bx + 1e-12f);
+  const T py = sqrt_rn(ay * ay + by * by + 1e-12f);
+  const T p_max = px > py ? px : py;
+  const T p_min = px < py ? px : py;
+  T Nf = ceil(p_max / p_min);
+  if (static_cast<T>(max_aniso) < Nf) Nf = static_cast<T>(max_aniso);
+  if (p_min == 0.0 || Nf == 0) Nf = 1;
+  T lambda_ = log2(p_max / Nf);
+  if (isnan(lambda_) || isinf(lambda_)) lambda_ = 0.0f;
+  const double lim = static_cast<double>(mipmaps - 1) - 1e-6;
+  T l = static_cast<T>(static_cast<double>(lambda_) < lim ? static_cast<double>(lambda_) : lim);
+  if (clip_grad && lambda_ > static_cast<T>(mipmaps - 1)) {
+    const T p_max_corrected = exp2(l) * Nf;
+    const T scaling = p_max_corrected / p_max;
+    dudx *= scaling;
+    dvdx *= scaling;
+    dudy *= scaling;
+    dvdy *= scaling;
+  }
+  l = static_cast<T>(static_cast<double>(l) > 0.0 ? static_cast<double>(l) : 0.0);
+  t.d1 = static_cast<int>(floor(l));
+  t.a = l - static_cast<T>(t.d1);
+  t.n = force_max_aniso ? max_aniso : static_cast<int>(Nf);
+  if (px > py) {
+    t.du = dudx, t.dv = dvdx;
+  } else {
+    t.du = dudy, t.dv = dvdy;
+  }
+  return t;
+}
+
+// Bilinear corner geometry of one (tap, level): offsets (or -1 when out of bounds) and weights.
+template <typename T>
+struct Quad {
+  int o_nw, o_ne, o_sw, o_se;
+  T nw, ne, sw, se;
+  T ix, iy;
+  int ix_nw, iy_nw;
+  T mx, my;
+};
+template <typename T>
+__device__ __forceinline__ Quad<T> bilinear_quad(T x, T y, int H, int W, int padding, bool align_corners) {
+  Quad<T> q;
+  q.ix = source_index(x, W, padding, align_corners, &q.mx);
+  q.iy = source_index(y, H, padding, align_corners, &q.my);
+  q.ix_nw = static_cast<int>(floor(q.ix));
+  q.iy_nw = static_cast<int>(floor(q.iy));
+  const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
+  q.nw = (ix_se - q.ix) * (iy_se - q.iy);
+  q.ne = (q.ix - q.ix_nw) * (iy_se - q.iy);
+  q.sw = (ix_se - q.ix) * (q.iy - q.iy_nw);
+  q.se = (q.ix - q.ix_nw) * (q.iy - q.iy_nw);
+  const bool x0 = q.ix_nw >= 0 && q.ix_nw < W, x1 = ix_se >= 0 && ix_se < W;
+  const bool y0 = q.iy_nw >= 0 && q.iy_nw < H, y1 = iy_se >= 0 && iy_se < H;
+  q.o_nw = (x0 && y0) ? q.iy_nw * W + q.ix_nw : -1;
+  q.o_ne = (x1 && y0) ? q.iy_nw * W + ix_se : -1;
+  q.o_sw = (x0 && y1) ? iy_se * W + q.ix_nw : -1;
+  q.o_se = (x1 && y1) ? iy_se * W + ix_se : -1;
+  return q;
+}
+
+// Bicubic footprint of one (tap, level): 4 column and 4 row indices after padding (-1: zero tap).
+template <typename T>
+struct Cubic {
+  int xi[4], yi[4];
+  T tx, ty, mx, my;
+};
+template <typename T>
+__device__ __forceinline__ Cubic<T> bicubic_footprint(T x, T y, int H, int W, int padding, bool align_corners) {
+  Cubic<T> c;
+  const T ix = unnormalize(x, W, align_corners, &c.mx);
+  const T iy = unnormalize(y, H, align_corners, &c.my);
+  const T ix_nw = floor(ix), iy_nw = floor(iy);
+  c.tx = ix - ix_nw;
+  c.ty = iy - iy_nw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int xv = static_cast<int>(compute_coordinates<T>(ix_nw - 1 + i, W, padding, align_corners));
+    const int yv = static_cast<int>(compute_coordinates<T>(iy_nw - 1 + i, H, padding, align_corners));
+    c.xi[i] = (xv >= 0 && xv < W) ? xv : -1;
+    c.yi[i] = (yv >= 0 && yv < H) ? yv : -1;
+  }
+  return c;
+}
+
+__device__ __forceinline__ void stage_levels(const LevelTable& lv, int mipmaps, const void** s_ptr, void** s_grad, int* s_h, int* s_w) {
+  if (threadIdx.x < kMaxLevels) {
+    const int i = threadIdx.x < mipmaps ? threadIdx.x : 0;
+    s_ptr[threadIdx.x] = lv.ptr[i];
+    s_grad[threadIdx.x] = lv.grad[i];
+    s_h[threadIdx.x] = lv.h[i];
+    s_w[threadIdx.x] = lv.w[i];
+  }
+  __syncthreads();
+}
+
+constexpr int kChBlock = 4; // channels accumulated in registers per sweep over the taps
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
+    LevelTable lv, int mipmaps, const T* __restrict__ grid, const T* __restrict__ vt, int64_t count, int C,
+    int64_t HW, int max_aniso, int padding, bool force_max_aniso, bool clip_grad, T* __restrict__ out) {
+  __shared__ const void* s_ptr[kMaxLevels];
+  __shared__ void* s_grad[kMaxLevels];
+  __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
+  const int64_t index = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (index >= count) return;
+  const int64_t n = index / HW;
+  const bool align_corners = false; // mipmap_grid_sampler_kernel.cu:423
+  const Taps<T> t = setup_taps<T>(grid, vt, index, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+  const int n_lv = mipmaps > 1 ? 2 : 1;
+  T* out_px = out + n * C * HW + (index - n * HW);
+  const T alpha_1 = t.a / t.n;
+  const T alpha_2 = static_cast<T>((1.0 - t.a) / t.n);
+
+  for (int c0 = 0; c0 < C; c0 += kChBlock) {
+    T acc[kChBlock];
+#pragma unroll
+    for (int cc = 0; cc < kChBlock; ++cc) acc[cc] = T(0);
+    for (int i = 0; i < t.n; ++i) {
+      const double f = (i + 1.0) / (t.n + 1.0) * 2.0 - 1.0;
+      const T x = t.u + static_cast<T>(t.du * f), y = t.v + static_cast<T>(t.dv * f);
+      for (int s = 0; s < n_lv; ++s) {
+        const int d = t.d1 + s;
+        const int h = s_h[d], w = s_w[d];
+        const int64_t plane = int64_t(h) * w;
+        const T* base = static_cast<const T*>(s_ptr[d]) + (n * C + c0) * plane;
+        const T alpha = s == 0 ? alpha_2 : alpha_1;
+        if constexpr (MODE == 0) {
+          const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
+#pragma unroll
+          for (int cc = 0; cc < kChBlock; ++cc) {
+            if (c0 + cc < C) {
+              const T* p = base + cc * plane;
+              if (q.o_nw >= 0) acc[cc] += p[q.o_nw] * q.nw * alpha;
+              if (q.o_ne >= 0) acc[cc] += p[q.o_ne] * q.ne * alpha;
+              if (q.o_sw >= 0) acc[cc] += p[q.o_sw] * q.sw * alpha;
+              if (q.o_se >= 0) acc[cc] += p[q.o_se] * q.se * alpha;
+            }
+          }
+        } else {
+          const Cubic<T> cb = bicubic_footprint<T>(x, y, h, w, padding, align_corners);
+          T cx[4], cy[4];
+          cubic_coeffs(cx, cb.tx);
+          cubic_coeffs(cy, cb.ty);
+#pragma unroll
+          for (int cc = 0; cc < kChBlock; ++cc) {
+            if (c0 + cc < C) {
+              const T* p = base + cc * plane;
+              T co[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                T xv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[k] = (cb.yi[r] >= 0 && cb.xi[k] >= 0) ? p[cb.yi[r] * w + cb.xi[k]] : T(0);
+                co[r] = xv[0] * cx[0] + xv[1] * cx[1] + xv[2] * cx[2] + xv[3] * cx[3];
+              }
+              acc[cc] += (co[0] * cy[0] + co[1] * cy[1] + co[2] * cy[2] + co[3] * cy[3]) * alpha;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < kChBlock; ++cc) {
+      if (c0 + cc < C) out_px[int64_t(c0 + cc) * HW] = acc[cc];
+    }
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
+    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid,
+    const T* __restrict__ vt, int64_t count, int C, int64_t HW, int max_aniso, int padding, bool align_corners,
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid) {
+  __shared__ const void* s_ptr[kMaxLevels];
+  __shared__ void* s_grad[kMaxLevels];
+  __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
+  const int64_t index = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (index >= count) return;
+  const int64_t n = index / HW;
+  const Taps<T> t = setup_taps<T>(grid, vt, index, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+  const int n_lv = mipmaps > 1 ? 2 : 1;
+  const T* gout_px = grad_out + n * C * HW + (index - n * HW);
+  const T alpha_1 = t.a / t.n;
+  const T alpha_2 = static_cast<T>((1.0 - t.a) / t.n);
+  T acc_x = T(0), acc_y = T(0);
+  for (int i = 0; i < t.n; ++i) {
+    const double f = (i + 1.0) / (t.n + 1.0) * 2.0 - 1.0;
+    const T x = t.u + static_cast<T>(t.du * f), y = t.v + static_cast<T>(t.dv * f);
+    for (int s = 0; s < n_lv; ++s) {
+      const int d = t.d1 + s;
+      const int h = s_h[d], w = s_w[d];
+      const int64_t plane = int64_t(h) * w;
+      const T* inp = static_cast<const T*>(s_ptr[d]) + n * C * plane;
+      T* ginp = static_cast<T*>(s_grad[d]) + n * C * plane;
+      const T alpha = s == 0 ? alpha_2 : alpha_1;
+      T gix = T(0), giy = T(0);
+      if constexpr (MODE == 0) {
+        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
+        const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
+        for (int c = 0; c < C; ++c) {
+          const T* p = inp + c * plane;
+          T* gp = ginp + c * plane;
+          const T gOut = gout_px[int64_t(c) * HW] * alpha;
+          if (q.o_nw >= 0) atomic_add_global(gp + q.o_nw, q.nw * gOut);
+          if (q.o_ne >= 0) atomic_add_global(gp + q.o_ne, q.ne * gOut);
+          if (q.o_sw >= 0) atomic_add_global(gp + q.o_sw, q.sw * gOut);
+          if (q.o_se >= 0) atomic_add_global(gp + q.o_se, q.se * gOut);
+          if (q.o_nw >= 0) {
+            const T val = p[q.o_nw];
+            gix -= val * (iy_se - q.iy) * gOut;
+            giy -= val * (ix_se - q.ix) * gOut;
+          }
+          if (q.o_ne >= 0) {
+            const T val = p[q.o_ne];
+            gix += val * (iy_se - q.iy) * gOut;
+            giy -= val * (q.ix - q.ix_nw) * gOut;
+          }
+          if (q.o_sw >= 0) {
+            const T val = p[q.o_sw];
+            gix -= val * (q.iy - q.iy_nw) * gOut;
+            giy += val * (ix_se - q.ix) * gOut;
+          }
+          if (q.o_se >= 0) {
+            const T val = p[q.o_se];
+            gix += val * (q.iy - q.iy_nw) * gOut;
+            giy += val * (q.ix - q.ix_nw) * gOut;
+          }
+        }
+        acc_x += q.mx * gix;
+        acc_y += q.my * giy;
+      } else {
+        const Cubic<T> cb = bicubic_footprint<T>(x, y, h, w, padding, align_corners);
+        T xc[4], yc[4], xg[4], yg[4];
+        cubic_coeffs(xc, cb.tx);
+        cubic_coeffs(yc, cb.ty);
+        cubic_coeffs_grad(xg, cb.tx);
+        cubic_coeffs_grad(yg, cb.ty);
+        for (int c = 0; c < C; ++c) {
+          const T* p = inp + c * plane;
+          T* gp = ginp + c * plane;
+          const T gOut = gout_px[int64_t(c) * HW] * alpha;
+#pragma unroll
+          for (int i2 = 0; i2 < 4; ++i2) {
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+              const bool ok = cb.xi[i2] >= 0 && cb.yi[j2] >= 0;
+              const int o = ok ? cb.yi[j2] * w + cb.xi[i2] : 0;
+              if (ok) atomic_add_global(gp + o, gOut * xc[i2] * yc[j2]);
+              const T val = ok ? p[o] : T(0);
+              gix -= gOut * val * (xg[i2] * yc[j2]);
+              giy -= gOut * val * (yg[j2] * xc[i2]);
+            }
+          }
+        }
+        acc_x += cb.mx * gix;
+        acc_y += cb.my * giy;
+      }
+    }
+  }
+  grad_grid[index * 2 + 0] = acc_x;
+  grad_grid[index * 2 + 1] = acc_y;
+}
+
+int fill_table(
+    LevelTable& lv, const void* const* levels, void* const* grad_levels, const int64_t* level_h,
+    const int64_t* level_w, int mipmaps, int64_t N, int64_t C) {
+  if (mipmaps < 1 || mipmaps > kMaxLevels || !levels || !level_h || !level_w) return DRTK_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < kMaxLevels; ++i) {
+    const int j = i < mipmaps ? i : 0;
+    if (level_h[j] <= 0 || level_w[j] <= 0 || level_h[j] * level_w[j] >= (int64_t(1) << 31)) return DRTK_ERR_INVALID_ARGUMENT;
+    if (N * C > 0 && !levels[j]) return DRTK_ERR_INVALID_ARGUMENT;
+    lv.ptr[i] = levels[j];
+    lv.grad[i] = grad_levels ? grad_levels[j] : nullptr;
+    lv.h[i] = static_cast<int>(level_h[j]);
+    lv.w[i] = static_cast<int>(level_w[j]);
+  }
+  return DRTK_OK;
+}
+
+} // namespace
+} // namespace drtk_amd
+
+using namespace drtk_amd;
+
+extern "C" int drtk_amd_mipmap_grid_sampler_2d(
+    drtk_dtype_t dtype, const void* const* levels, const int64_t* level_h, const int64_t* level_w, int mipmaps,
+    const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W, int max_aniso,
+    int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso, int clip_grad, void* out,
+    drtk_stream_t stream) {
+  (void)align_corners; // ignored by the reference's forward kernel (:423)
+  if (N < 0 || C < 0 || H < 0 || W < 0 || C >= (1 << 20) || max_aniso < 1 || padding_mode < 0 || padding_mode > 2 ||
+      (interpolation_mode != 0 && interpolation_mode != 2) || (dtype != DRTK_F32 && dtype != DRTK_F64))
+    return DRTK_ERR_INVALID_ARGUMENT;
+  LevelTable lv;
+  const int st = fill_table(lv, levels, nullptr, level_h, level_w, mipmaps, N, C);
+  if (st != DRTK_OK) return st;
+  const int64_t count = N * H * W;
+  if (count == 0 || C == 0) return DRTK_OK;
+  if (!grid || !vt_dxdy_img || !out) return DRTK_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid_dim(static_cast<unsigned>(ceil_div(count, kBlock)));
+#define LAUNCH(T, MODE)                                                                                   \
+  hipLaunchKernelGGL(                                                                                     \
+      (mipmap_forward_kernel<T, MODE>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grid), \
+      static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, force_max_aniso != 0,  \
+      clip_grad != 0, static_cast<T*>(out))
+  if (dtype == DRTK_F32) {
+    if (interpolation_mode == 0) LAUNCH(float, 0); else LAUNCH(float, 2);
+  } else {
+    if (interpolation_mode == 0) LAUNCH(double, 0); else LAUNCH(double, 2);
+  }
+#undef LAUNCH
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}
+
+extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
+    drtk_dtype_t dtype, const void* grad_out, const void* const* levels, const int64_t* level_h,
+    const int64_t* level_w, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H,
+    int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso,
+    int clip_grad, void* const* grad_levels, void* grad_grid, drtk_stream_t stream) {
+  if (N < 0 || C < 0 || H < 0 || W < 0 || C >= (1 << 20) || max_aniso < 1 || padding_mode < 0 || padding_mode > 2 ||
+      (interpolation_mode != 0 && interpolation_mode != 2) || (dtype != DRTK_F32 && dtype != DRTK_F64) || !grad_levels)
+    return DRTK_ERR_INVALID_ARGUMENT;
+  LevelTable lv;
+  const int st = fill_table(lv, levels, grad_levels, level_h, level_w, mipmaps, N, C);
+  if (st != DRTK_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t es = dtype == DRTK_F32 ? 4 : 8;
+  for (int i = 0; i < mipmaps; ++i) { // :1120-1123 zeros_like
+    const size_t bytes = es * N * C * level_h[i] * level_w[i];
+    if (bytes > 0) {
+      if (!grad_levels[i]) return DRTK_ERR_INVALID_ARGUMENT;
+      if (hipMemsetAsync(grad_levels[i], 0, bytes, s) != hipSuccess) return DRTK_ERR_LAUNCH;
+    }
+  }
+  const int64_t count = N * H * W;
+  if (count == 0) return DRTK_OK;
+  if (!grid || !vt_dxdy_img || !grad_grid || (C > 0 && !grad_out)) return DRTK_ERR_INVALID_ARGUMENT;
+  const dim3 grid_dim(static_cast<unsigned>(ceil_div(count, kBlock)));
+#define LAUNCH(T, MODE)                                                                                       \
+  hipLaunchKernelGGL(                                                                                         \
+      (mipmap_backward_kernel<T, MODE>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grad_out), \
+      static_cast<const T*>(grid), static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, \
+      align_corners != 0, force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid))
+  if (dtype == DRTK_F32) {
+    if (interpolation_mode == 0) LAUNCH(float, 0); else LAUNCH(float, 2);
+  } else {
+    if (interpolation_mode == 0) LAUNCH(double, 0); else LAUNCH(double, 2);
+  }
+#undef LAUNCH
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}

@@ -9,6 +9,7 @@
 //   interpolate_ext::interpolate      src/interpolate/interpolate_module.cpp:376-433,584-669
 //   interpolate_ext::interpolation_matrix / interpolation_normal_matrix[_values]   :28-310,435-669
 //   edge_grad_ext::edge_grad_estimator   src/edge_grad/edge_grad_module.cpp:18-224
+//   mipmap_grid_sampler_ext::mipmap_grid_sampler_2d   src/mipmap_grid_sampler/mipmap_grid_sampler_module.cpp:16-266
 //
 // This file is host-only C++ (no device code); the kernels live in libdrtk_amd.so.  There is NO
 // CPU compute path: the CPU key is registered only to fail with a clear message.
@@ -887,6 +888,217 @@ Tensor normal_matrix_values_autocast(
 }
 
 // ---------------------------------------------------------------------------------------------
+// mipmap_grid_sampler_2d (mipmap_grid_sampler_module.cpp:16-266 ; mipmap_grid_sampler_kernel.cu:899-1249)
+// ---------------------------------------------------------------------------------------------
+struct LevelArgs {
+  std::vector<Tensor> holders;
+  std::vector<const void*> ptrs;
+  std::vector<int64_t> h, w;
+};
+LevelArgs prep_levels(at::TensorList input) {
+  LevelArgs a;
+  for (const Tensor& t : input) {
+    a.holders.push_back(t.contiguous());
+    a.ptrs.push_back(a.holders.back().data_ptr());
+    a.h.push_back(t.size(2));
+    a.w.push_back(t.size(3));
+  }
+  return a;
+}
+
+Tensor mipmap_grid_sampler_2d_hip(
+    at::TensorList input, const Tensor& grid, const Tensor& vt_dxdy_img, int64_t max_aniso, int64_t padding_mode,
+    int64_t interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) {
+  // mipmap_grid_sampler_kernel.cu:909-1000
+  const int64_t mipmaps = static_cast<int64_t>(input.size());
+  TORCH_CHECK(mipmaps >= 1, "mipmap_aniso_grid_sampler_2d(): expected input to have at least one mipmap level");
+  TORCH_CHECK(mipmaps <= 11, "mipmap_aniso_grid_sampler_2d(): at most 11 mipmap levels are supported");
+  TORCH_CHECK(
+      input[0].defined() && grid.defined(),
+      "mipmap_aniso_grid_sampler_2d(): expected input and grid to not be undefined, but input is ", input,
+      " and grid is ", grid);
+  const auto input_opt = input[0].options();
+  const auto grid_opt = grid.options();
+  TORCH_CHECK(
+      input_opt.device() == grid_opt.device(),
+      "mipmap_aniso_grid_sampler_2d(): expected input and grid to be on same device, but input is on ",
+      input_opt.device(), " and grid is on ", grid_opt.device());
+  TORCH_CHECK(
+      input_opt.dtype() == grid_opt.dtype(),
+      "mipmap_aniso_grid_sampler_2d(): expected input and grid to have same dtype, but input has ", input_opt.dtype(),
+      " and grid has ", grid_opt.dtype());
+  TORCH_CHECK(
+      input_opt.layout() == at::kStrided && grid_opt.layout() == at::kStrided,
+      "mipmap_aniso_grid_sampler_2d(): expected input and grid to have torch.strided layout, but input has ",
+      input_opt.layout(), " and grid has ", grid_opt.layout());
+  TORCH_CHECK(
+      (input[0].dim() == 4) && input[0].dim() == grid.dim() && input[0].dim() + 1 == vt_dxdy_img.dim(),
+      "mipmap_aniso_grid_sampler_2d(): expected 4D input and grid with same number of dimensions and 5D vt_dxdy_img, "
+      "but got input with sizes ", input[0].sizes(), " and grid with sizes ", grid.sizes(),
+      " and vt_dxdy_img with sizes ", vt_dxdy_img.sizes());
+  TORCH_CHECK(
+      input[0].size(0) == grid.size(0) && input[0].size(0) == vt_dxdy_img.size(0),
+      "mipmap_aniso_grid_sampler_2d(): expected grid, vt_dxdy_img and input to have same batch size, but got input "
+      "with sizes ", input[0].sizes(), " and grid with sizes ", grid.sizes(), " and vt_dxdy_img with sizes ",
+      vt_dxdy_img.sizes());
+  TORCH_CHECK(
+      grid.size(-1) == input[0].dim() - 2, "mipmap_aniso_grid_sampler_2d(): expected grid to have size ",
+      input[0].dim() - 2, " in last dimension, but got grid with sizes ", grid.sizes());
+  TORCH_CHECK(
+      vt_dxdy_img.size(-1) == input[0].dim() - 2 && vt_dxdy_img.size(-2) == input[0].dim() - 2,
+      "mipmap_aniso_grid_sampler_2d(): expected vt_dxdy_img to have size ", input[0].dim() - 2,
+      " in last two dimension, but got grid with sizes ", grid.sizes());
+  TORCH_CHECK(
+      vt_dxdy_img.size(1) == grid.size(1) && vt_dxdy_img.size(2) == grid.size(2) && vt_dxdy_img.device() == grid.device() &&
+          vt_dxdy_img.dtype() == grid.dtype(),
+      "mipmap_aniso_grid_sampler_2d(): expected vt_dxdy_img to match grid in device, dtype and spatial size");
+  for (int64_t i = 1; i < mipmaps; i++) {
+    TORCH_CHECK(
+        input_opt.device() == input[i].options().device() && input_opt.dtype() == input[i].options().dtype() &&
+            input_opt.layout() == input[i].options().layout() && input[0].dim() == input[i].dim() &&
+            input[0].size(0) == input[i].size(0) && input[0].size(1) == input[i].size(1),
+        "mipmap_aniso_grid_sampler_2d(): expected all inputs to have same device, dtype, layout, and first two "
+        "dimensions");
+  }
+  for (int64_t l = 0; l < mipmaps; l++) {
+    for (int64_t i = 2; i < input[l].dim(); i++) {
+      TORCH_CHECK(
+          input[l].size(i) > 0, "grid_sampler(): expected input to have non-empty spatial dimensions, but input has sizes ",
+          input[l].sizes(), " with dimension ", i, " being empty");
+    }
+  }
+  TORCH_CHECK(max_aniso >= 1, "mipmap_aniso_grid_sampler_2d(): expected max_aniso >= 1");
+  TORCH_CHECK(
+      padding_mode >= 0 && padding_mode <= 2 && (interpolation_mode == 0 || interpolation_mode == 2),
+      "mipmap_aniso_grid_sampler_2d(): unsupported padding_mode / interpolation_mode");
+  const drtk_dtype_t dt = dtype_of(input[0], "mipmap_aniso_grid_sampler_2d_kernel");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input[0].device());
+  const LevelArgs lv = prep_levels(input);
+  const auto grid_c = grid.contiguous();
+  const auto vt_c = vt_dxdy_img.contiguous();
+  const int64_t N = input[0].size(0), C = input[0].size(1), H = grid.size(1), W = grid.size(2);
+  auto out = at::empty({N, C, H, W}, input[0].options());
+  check_status(
+      drtk_amd_mipmap_grid_sampler_2d(
+          dt, lv.ptrs.data(), lv.h.data(), lv.w.data(), static_cast<int>(mipmaps), grid_c.data_ptr(), vt_c.data_ptr(), N,
+          C, H, W, static_cast<int>(std::min<int64_t>(max_aniso, 1 << 20)), static_cast<int>(padding_mode),
+          static_cast<int>(interpolation_mode), align_corners, force_max_ansio, clip_grad, out.data_ptr(),
+          current_stream(input[0])),
+      "mipmap_aniso_grid_sampler_2d");
+  return out;
+}
+
+std::tuple<std::vector<Tensor>, Tensor> mipmap_grid_sampler_2d_backward_hip(
+    const Tensor& grad_output, const std::vector<Tensor>& input, const Tensor& grid, const Tensor& vt_dxdy_img,
+    int64_t max_aniso, int64_t padding_mode, int64_t interpolation_mode, bool align_corners, bool force_max_ansio,
+    bool clip_grad) {
+  const drtk_dtype_t dt = dtype_of(input[0], "mipmap_aniso_grid_sampler_2d_backward_kernel");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input[0].device());
+  const LevelArgs lv = prep_levels(input);
+  const auto grid_c = grid.contiguous();
+  const auto vt_c = vt_dxdy_img.contiguous();
+  const auto go_c = grad_output.to(input[0].scalar_type()).contiguous();
+  std::vector<Tensor> grad_input;
+  std::vector<void*> gptrs;
+  for (const Tensor& t : input) { // zero-filled by the call (:1120-1123)
+    grad_input.push_back(at::empty(t.sizes(), t.options()));
+    gptrs.push_back(grad_input.back().data_ptr());
+  }
+  auto grad_grid = at::empty(grid.sizes(), grid.options());
+  const int64_t N = input[0].size(0), C = input[0].size(1), H = grid.size(1), W = grid.size(2);
+  check_status(
+      drtk_amd_mipmap_grid_sampler_2d_backward(
+          dt, go_c.data_ptr(), lv.ptrs.data(), lv.h.data(), lv.w.data(), static_cast<int>(input.size()),
+          grid_c.data_ptr(), vt_c.data_ptr(), N, C, H, W, static_cast<int>(std::min<int64_t>(max_aniso, 1 << 20)),
+          static_cast<int>(padding_mode), static_cast<int>(interpolation_mode), align_corners, force_max_ansio, clip_grad,
+          gptrs.data(), grad_grid.data_ptr(), current_stream(input[0])),
+      "mipmap_aniso_grid_sampler_2d_backward");
+  return {grad_input, grad_grid};
+}
+
+Tensor mipmap_grid_sampler_2d_cpu(
+    at::TensorList, const Tensor&, const Tensor&, int64_t, int64_t, int64_t, bool, bool, bool) {
+  no_cpu("mipmap_aniso_grid_sampler_2d");
+}
+
+Tensor mipmap_grid_sampler_2d_op(
+    at::TensorList input, const Tensor& grid, const Tensor& vt_dxdy_img, int64_t max_aniso, int64_t padding_mode,
+    int64_t interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("mipmap_grid_sampler_ext::mipmap_grid_sampler_2d", "")
+                       .typed<decltype(mipmap_grid_sampler_2d_op)>();
+  return op.call(input, grid, vt_dxdy_img, max_aniso, padding_mode, interpolation_mode, align_corners, force_max_ansio, clip_grad);
+}
+
+// A torch::autograd::Function cannot take a TensorList whose members need gradients, so -- like the
+// reference (mipmap_grid_sampler_module.cpp:44-181) -- the pyramid is spread over 11 optional slots.
+using OptTensor = std::optional<Tensor>;
+class MipmapGridSample2DFunction : public torch::autograd::Function<MipmapGridSample2DFunction> {
+ public:
+  static tensor_list forward(
+      AutogradContext* ctx, const Tensor& grid, const Tensor& vt_dxdy_img, int64_t max_aniso, int64_t padding_mode,
+      int64_t interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad, const Tensor& input0,
+      const OptTensor& i1, const OptTensor& i2, const OptTensor& i3, const OptTensor& i4, const OptTensor& i5,
+      const OptTensor& i6, const OptTensor& i7, const OptTensor& i8, const OptTensor& i9, const OptTensor& i10) {
+    std::vector<Tensor> input = {input0};
+    for (const OptTensor* o : {&i1, &i2, &i3, &i4, &i5, &i6, &i7, &i8, &i9, &i10}) {
+      if (o->has_value()) input.push_back(o->value());
+    }
+    ctx->set_materialize_grads(false);
+    std::vector<Tensor> save_list(input.begin(), input.end());
+    save_list.push_back(grid);
+    save_list.push_back(vt_dxdy_img);
+    ctx->save_for_backward(save_list);
+    bool requires_grad = grid.requires_grad(); // :95-99
+    for (const auto& inp : input) requires_grad = requires_grad || inp.requires_grad();
+    ctx->saved_data["data"] = std::make_tuple(
+        static_cast<int64_t>(input.size()), requires_grad, max_aniso, padding_mode, interpolation_mode, align_corners,
+        force_max_ansio, clip_grad);
+    at::AutoDispatchBelowADInplaceOrView g;
+    return {mipmap_grid_sampler_2d_op(
+        input, grid, vt_dxdy_img, max_aniso, padding_mode, interpolation_mode, align_corners, force_max_ansio, clip_grad)};
+  }
+  static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+    int64_t mipmaps, max_aniso, padding_mode, interpolation_mode;
+    bool requires_grad, align_corners, force_max_ansio, clip_grad;
+    std::tie(mipmaps, requires_grad, max_aniso, padding_mode, interpolation_mode, align_corners, force_max_ansio, clip_grad) =
+        ctx->saved_data["data"].to<std::tuple<int64_t, bool, int64_t, int64_t, int64_t, bool, bool, bool>>();
+    tensor_list grads(19);
+    if (!requires_grad || !grad_outputs[0].defined()) return grads;
+    const auto saved = ctx->get_saved_variables();
+    const std::vector<Tensor> input(saved.begin(), saved.begin() + mipmaps);
+    auto g = mipmap_grid_sampler_2d_backward_hip(
+        grad_outputs[0], input, saved[mipmaps], saved[mipmaps + 1], max_aniso, padding_mode, interpolation_mode,
+        align_corners, force_max_ansio, clip_grad);
+    grads[0] = std::get<1>(g); // grid; slots 1..7 (vt_dxdy_img and the scalars) stay undefined
+    for (int64_t i = 0; i < mipmaps; ++i) grads[8 + i] = std::get<0>(g)[i];
+    return grads;
+  }
+};
+
+Tensor mipmap_grid_sampler_2d_autograd(
+    at::TensorList input, const Tensor& grid, const Tensor& vt_dxdy_img, int64_t max_aniso, int64_t padding_mode,
+    int64_t interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) {
+  TORCH_CHECK(
+      input.size() >= 1 && input.size() <= 11,
+      "mipmap_aniso_grid_sampler_2d(): expected between 1 and 11 mipmap levels, but got ", input.size());
+  auto opt = [&](size_t i) { return input.size() > i ? OptTensor(input[i]) : OptTensor(); };
+  return MipmapGridSample2DFunction::apply(
+      grid, vt_dxdy_img, max_aniso, padding_mode, interpolation_mode, align_corners, force_max_ansio, clip_grad, input[0],
+      opt(1), opt(2), opt(3), opt(4), opt(5), opt(6), opt(7), opt(8), opt(9), opt(10))[0];
+}
+
+Tensor mipmap_grid_sampler_2d_autocast(
+    at::TensorList input, const Tensor& grid, const Tensor& vt_dxdy_img, int64_t max_aniso, int64_t padding_mode,
+    int64_t interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) {
+  c10::impl::ExcludeDispatchKeyGuard no_autocast(c10::DispatchKey::Autocast);
+  return mipmap_grid_sampler_2d_op(
+      at::autocast::cached_cast(at::kFloat, input), at::autocast::cached_cast(at::kFloat, grid),
+      at::autocast::cached_cast(at::kFloat, vt_dxdy_img), max_aniso, padding_mode, interpolation_mode, align_corners,
+      force_max_ansio, clip_grad);
+}
+
+// ---------------------------------------------------------------------------------------------
 // edge_grad_estimator
 // ---------------------------------------------------------------------------------------------
 Tensor edge_grad_fwd_hip(
@@ -1302,6 +1514,23 @@ TORCH_LIBRARY_IMPL(edge_grad_ext, CUDA, m) {
 TORCH_LIBRARY_IMPL(edge_grad_ext, CPU, m) {
   m.impl("edge_grad_estimator", &edge_grad_cpu);
   m.impl("edge_grad_estimator_fused", &edge_grad_fused_cpu);
+}
+
+TORCH_LIBRARY(mipmap_grid_sampler_ext, m) {
+  m.def(
+      "mipmap_grid_sampler_2d(Tensor[] x, Tensor grid, Tensor vt_dxdy_img, int max_aniso, int padding_mode, int interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) -> Tensor");
+}
+TORCH_LIBRARY_IMPL(mipmap_grid_sampler_ext, Autograd, m) {
+  m.impl("mipmap_grid_sampler_2d", &mipmap_grid_sampler_2d_autograd);
+}
+TORCH_LIBRARY_IMPL(mipmap_grid_sampler_ext, Autocast, m) {
+  m.impl("mipmap_grid_sampler_2d", mipmap_grid_sampler_2d_autocast);
+}
+TORCH_LIBRARY_IMPL(mipmap_grid_sampler_ext, CUDA, m) {
+  m.impl("mipmap_grid_sampler_2d", &mipmap_grid_sampler_2d_hip);
+}
+TORCH_LIBRARY_IMPL(mipmap_grid_sampler_ext, CPU, m) { // the reference registers no CPU kernel either
+  m.impl("mipmap_grid_sampler_2d", &mipmap_grid_sampler_2d_cpu);
 }
 
 // drtk_amd's own namespace (extensions with no reference counterpart)

@@ -1,8 +1,9 @@
 """Loader for the native torch-operator library.
 
 The reference loads one `drtk/<name>_ext*.so` per extension through `importlib` +
-`torch.ops.load_library` (drtk/utils/load_torch_ops.py:14-28).  drtk_amd ships all four operator
-namespaces (`rasterize_ext`, `render_ext`, `interpolate_ext`, `edge_grad_ext`) in ONE in-tree
+`torch.ops.load_library` (drtk/utils/load_torch_ops.py:14-28).  drtk_amd ships its operator
+namespaces (`rasterize_ext`, `render_ext`, `interpolate_ext`, `edge_grad_ext`,
+`mipmap_grid_sampler_ext`) in ONE in-tree
 library, `drtk_amd/drtk_amd_torch_ops.so`, which links `drtk_amd/libdrtk_amd.so` (HIP kernels +
 C ABI).  Loading fails loudly: there is no eager/PyTorch fallback for these ops.
 """
@@ -23,6 +24,7 @@ _NAMESPACES = {
     "drtk.render_ext": "render_ext",
     "drtk.interpolate_ext": "interpolate_ext",
     "drtk.edge_grad_ext": "edge_grad_ext",
+    "drtk.mipmap_grid_sampler_ext": "mipmap_grid_sampler_ext",
 }
 
 

@@ -164,6 +164,30 @@ int drtk_amd_interpolation_normal_matrix_values_backward(
     drtk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * mipmap_grid_sampler_2d -- grid_sample with trilinear mip selection and anisotropic taps; replaces
+ * mipmap_aniso_grid_sampler_2d_cuda / _cuda_backward (mipmap_grid_sampler_kernel.cu:899-1249).
+ *   levels[l]    device pointer of mip level l, contiguous [N,C,level_h[l],level_w[l]], l < mipmaps <= 11
+ *                (the arrays levels / level_h / level_w / grad_levels themselves are HOST arrays)
+ *   grid         [N,H,W,2] uv in [-1,1];  vt_dxdy_img [N,H,W,2,2] = [[du/dx, dv/dx],[du/dy, dv/dy]]
+ *   out          [N,C,H,W]
+ *   padding_mode 0 zeros | 1 border | 2 reflection;  interpolation_mode 0 bilinear | 2 bicubic
+ *   align_corners is ignored by the forward pass and honoured by the backward pass -- as in the
+ *   reference (:423 vs :641-897).
+ * Backward: grad_levels[l] (same shapes as levels, zero-filled here) and grad_grid [N,H,W,2]
+ * (fully written); no gradient is defined for vt_dxdy_img.
+ */
+int drtk_amd_mipmap_grid_sampler_2d(
+    drtk_dtype_t dtype, const void* const* levels, const int64_t* level_h, const int64_t* level_w,
+    int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W,
+    int max_aniso, int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso,
+    int clip_grad, void* out, drtk_stream_t stream);
+int drtk_amd_mipmap_grid_sampler_2d_backward(
+    drtk_dtype_t dtype, const void* grad_out, const void* const* levels, const int64_t* level_h,
+    const int64_t* level_w, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C,
+    int64_t H, int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners,
+    int force_max_aniso, int clip_grad, void* const* grad_levels, void* grad_grid, drtk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * transform_pinhole  -- the vertex stage in front of the path; replaces the pure-PyTorch pinhole
  * branch of drtk.transform (drtk/transform.py:13-119, drtk/utils/projection.py:33-53,486-540):
  *   v_cam = camrot (v - campos);  v_pix = (focal (v_cam.xy / clamp(v_cam.z)) + princpt, v_cam.z)

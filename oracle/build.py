@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libdrtk_oracle.so")
-SRCS = [os.path.join(HERE, f) for f in ("drtk_oracle.c", "drtk_oracle_body.inc", "drtk_oracle.h")]
+SRCS = [os.path.join(HERE, f) for f in ("drtk_oracle.c", "drtk_oracle_body.inc", "drtk_oracle_mipmap.inc", "drtk_oracle.h")]
 
 
 def build(force=False, verbose=True):

@@ -31,6 +31,21 @@ static int drtk_oracle_resolve_threads(int nthreads) {
 #define REAL_SQRT sqrtf
 #define REAL_FABS fabsf
 #include "drtk_oracle_body.inc"
+#define M_SQRT sqrtf
+#define M_FLOOR floorf
+#define M_CEIL ceilf
+#define M_LOG2 log2f
+#define M_EXP2 exp2f
+#define M_FABS fabsf
+#define M_FMOD fmodf
+#include "drtk_oracle_mipmap.inc"
+#undef M_SQRT
+#undef M_FLOOR
+#undef M_CEIL
+#undef M_LOG2
+#undef M_EXP2
+#undef M_FABS
+#undef M_FMOD
 #undef REAL
 #undef SFX
 #undef REAL_EPS
@@ -43,3 +58,11 @@ static int drtk_oracle_resolve_threads(int nthreads) {
 #define REAL_SQRT sqrt
 #define REAL_FABS fabs
 #include "drtk_oracle_body.inc"
+#define M_SQRT sqrt
+#define M_FLOOR floor
+#define M_CEIL ceil
+#define M_LOG2 log2
+#define M_EXP2 exp2
+#define M_FABS fabs
+#define M_FMOD fmod
+#include "drtk_oracle_mipmap.inc"

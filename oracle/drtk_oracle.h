@@ -73,7 +73,20 @@ extern "C" {
   int drtk_oracle_normal_matrix_values_backward_##SFX(                                            \
       const REAL* grad_values, const int32_t* pair_indices, const int32_t* index_img,             \
       const REAL* bary_img, int64_t N, int64_t F, int64_t pair_sN, int64_t H, int64_t W,          \
-      REAL* bary_grad);
+      REAL* bary_grad);                                                                           \
+  /* anisotropic mipmap grid sampler, mipmap_grid_sampler_kernel.cu:20-897 (see                   \
+     drtk_oracle_mipmap.inc; parity PARTIALLY pinned).  `out` is zero-filled by the call;         \
+     grad_levels[l] must be zero-initialised by the caller, grad_grid is fully written. */        \
+  int drtk_oracle_mipmap_grid_sampler_2d_##SFX(                                                   \
+      const REAL* const* levels, const int64_t* lh, const int64_t* lw, int mipmaps,               \
+      const REAL* grid, const REAL* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W,      \
+      int max_aniso, int padding_mode, int interpolation_mode, int align_corners,                 \
+      int force_max_aniso, int clip_grad, REAL* out);                                             \
+  int drtk_oracle_mipmap_grid_sampler_2d_backward_##SFX(                                          \
+      const REAL* grad_out, const REAL* const* levels, const int64_t* lh, const int64_t* lw,      \
+      int mipmaps, const REAL* grid, const REAL* vt_dxdy_img, int64_t N, int64_t C, int64_t H,    \
+      int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners,      \
+      int force_max_aniso, int clip_grad, REAL* const* grad_levels, REAL* grad_grid);
 
 DRTK_ORACLE_DECL(f32, float)
 DRTK_ORACLE_DECL(f64, double)

@@ -233,3 +233,49 @@ def normal_matrix_values_backward(grad_values, pair_indices, index_img, bary_img
     _call("normal_matrix_values_backward", _sfx(bary_img), _p(g), _p(pair), _p(index_img), _p(bary_img), _i64(N),
           _i64(F), _i64(F * 9), _i64(H), _i64(W), _p(bary_grad))
     return bary_grad
+
+
+# ---- anisotropic mipmap grid sampler (mipmap_grid_sampler_kernel.cu) --------------------------------
+
+
+def _levels(levels):
+    lv = [t.contiguous() for t in levels]
+    n = len(lv)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lv])
+    lh = (ctypes.c_int64 * n)(*[t.shape[2] for t in lv])
+    lw = (ctypes.c_int64 * n)(*[t.shape[3] for t in lv])
+    return lv, ptrs, lh, lw
+
+
+def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0, interpolation_mode=0,
+                           align_corners=False, force_max_aniso=False, clip_grad=False):
+    """Forward of mipmap_grid_sampler_ext::mipmap_grid_sampler_2d (enum arguments as the op takes them)."""
+    lv, ptrs, lh, lw = _levels(levels)
+    grid = grid.contiguous()
+    vt = vt_dxdy_img.contiguous()
+    N, C = lv[0].shape[:2]
+    H, W = grid.shape[1:3]
+    out = th.empty(N, C, H, W, dtype=lv[0].dtype)
+    _call("mipmap_grid_sampler_2d", _sfx(lv[0]), ptrs, lh, lw, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i64(N), _i64(C),
+          _i64(H), _i64(W), ctypes.c_int(max_aniso), ctypes.c_int(padding_mode), ctypes.c_int(interpolation_mode),
+          ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)), ctypes.c_int(bool(clip_grad)), _p(out))
+    return out
+
+
+def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_aniso, padding_mode=0,
+                                    interpolation_mode=0, align_corners=False, force_max_aniso=False, clip_grad=False):
+    """-> ([grad per level], grad_grid)."""
+    lv, ptrs, lh, lw = _levels(levels)
+    grid = grid.contiguous()
+    vt = vt_dxdy_img.contiguous()
+    go = grad_out.contiguous()
+    N, C = lv[0].shape[:2]
+    H, W = grid.shape[1:3]
+    glv = [th.zeros_like(t) for t in lv]
+    gptrs = (ctypes.c_void_p * len(lv))(*[t.data_ptr() for t in glv])
+    ggrid = th.empty_like(grid)
+    _call("mipmap_grid_sampler_2d_backward", _sfx(lv[0]), _p(go), ptrs, lh, lw, ctypes.c_int(len(lv)), _p(grid), _p(vt),
+          _i64(N), _i64(C), _i64(H), _i64(W), ctypes.c_int(max_aniso), ctypes.c_int(padding_mode),
+          ctypes.c_int(interpolation_mode), ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)),
+          ctypes.c_int(bool(clip_grad)), gptrs, _p(ggrid))
+    return glv, ggrid

@@ -47,6 +47,39 @@ def load_sparse(name):
     return vib, index, o["render_bary"], i["v"].shape[1], gi, go
 
 
+MIPMAP_CASES = [
+    "bilinear_border_a4", "bilinear_zeros_a1", "bilinear_reflection_a2", "bicubic_border_a3", "bicubic_zeros_a2_f64",
+    "bilinear_border_a8_f64", "single_level_a2",
+]
+
+
+def load_mipmap(name):
+    """tests/golden/mipmap_<name>.npz -> dict(tex=[levels], grid, vt, grad_out, max_aniso, mode, padding,
+    out, grad_tex=[...], grad_grid): inputs and the outputs / autograd gradients of the reference's
+    pure-PyTorch model (oracle/gen_golden_mipmap.py; force_max_aniso=True, clip_grad=False)."""
+    z = np.load(os.path.join(GOLDEN, "mipmap_" + name + ".npz"))
+    L = int(z["in_levels"])
+    t = lambda k: th.from_numpy(np.ascontiguousarray(z[k]))  # noqa: E731
+    return dict(
+        tex=[t(f"in_tex{i}") for i in range(L)], grid=t("in_grid"), vt=t("in_vt_dxdy_img"), grad_out=t("in_grad_out"),
+        max_aniso=int(z["in_max_aniso"]), mode=int(z["in_mode"]), padding=int(z["in_padding"]), out=t("out_out"),
+        grad_tex=[t(f"out_grad_tex{i}") for i in range(L)], grad_grid=t("out_grad_grid"))
+
+
+def mipmap_inputs(seed, N, C, size, levels, H, W, dtype=th.float32, jscale=0.05):
+    """Seeded synthetic inputs of the same family as the fixtures (for oracle-vs-HIP comparisons in
+    the modes the reference model cannot run)."""
+    g = th.Generator().manual_seed(seed)
+    tex = [th.rand(N, C, size, size, generator=g, dtype=th.float64).to(dtype)]
+    for _ in range(levels - 1):
+        tex.append(th.nn.functional.avg_pool2d(tex[-1], 2))
+    grid = (th.rand(N, H, W, 2, generator=g, dtype=th.float64) * 2.4 - 1.2).to(dtype)
+    jac = th.randn(N, H, W, 2, 2, generator=g, dtype=th.float64) * jscale
+    jac[..., 0, :] *= th.rand(N, H, W, 1, generator=g, dtype=th.float64) * 4 + 0.05
+    gout = (th.rand(N, C, H, W, generator=g, dtype=th.float64) * 2 - 1).to(dtype)
+    return tex, grid, jac.to(dtype), gout
+
+
 @pytest.fixture(scope="session")
 def oracle_ops():
     from backends import OracleBackend, make_ops

@@ -58,6 +58,7 @@ def test_torch_operator_schemas_match_reference():
         "interpolate_ext::interpolation_matrix": "interpolate_ext::interpolation_matrix(Tensor vi, Tensor index_img, Tensor bary_img) -> (Tensor, Tensor, Tensor, Tensor)",
         "interpolate_ext::interpolation_normal_matrix": "interpolate_ext::interpolation_normal_matrix(Tensor vi, Tensor index_img, Tensor bary_img, int num_vertices) -> (Tensor, Tensor, Tensor)",
         "interpolate_ext::interpolation_normal_matrix_values": "interpolate_ext::interpolation_normal_matrix_values(Tensor pair_indices, Tensor index_img, Tensor bary_img, int nnz) -> Tensor",
+        "mipmap_grid_sampler_ext::mipmap_grid_sampler_2d": "mipmap_grid_sampler_ext::mipmap_grid_sampler_2d(Tensor[] x, Tensor grid, Tensor vt_dxdy_img, int max_aniso, int padding_mode, int interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) -> Tensor",
         "edge_grad_ext::edge_grad_estimator": "edge_grad_ext::edge_grad_estimator(Tensor v_pix, Tensor v_pix_img, Tensor vi, Tensor img, Tensor index_img, float max_dp_dr=10000.) -> Tensor",
     }
     for name, schema in want.items():
@@ -82,6 +83,9 @@ def test_python_api_mirrors_drtk_signatures():
     assert params(drtk_amd.edge_grad_estimator) == [
         ("v_pix", E), ("vi", E), ("bary_img", E), ("img", E), ("index_img", E), ("v_pix_img_hook", None),
         ("max_dp_dr", 1e4)]
+    assert params(drtk_amd.mipmap_grid_sample) == [
+        ("input", E), ("grid", E), ("vt_dxdy_img", E), ("max_aniso", E), ("mode", "bilinear"), ("padding_mode", "zeros"),
+        ("align_corners", None), ("force_max_aniso", False), ("clip_grad", False)]  # drtk/mipmap_grid_sample.py:17-27
     sparse = [("vi", E), ("index_img", E), ("bary_img", E), ("num_vertices", E)]  # drtk/interpolate.py:53-58,127-132
     assert params(drtk_amd.interpolation_matrix) == sparse and params(drtk_amd.interpolation_normal_matrix) == sparse
     assert drtk_amd.__version__ == "0.1.0"

@@ -1,0 +1,75 @@
+"""CPU: the restatement of the anisotropic mipmap grid sampler (oracle/drtk_oracle_mipmap.inc)
+against fixtures produced by the reference's own pure-PyTorch model drtk.mipmap_grid_sample_ref
+(force_max_aniso=True, clip_grad=False -- the configuration the reference documents as equal to its
+CUDA kernel), forward and gradients; plus self-consistency of the modes no executable reference
+covers here (adaptive tap count, clip_grad)."""
+import pytest
+import torch as th
+from conftest import MIPMAP_CASES, load_mipmap, mipmap_inputs
+
+import oracle as O
+
+
+def _tol(ref, dtype):
+    scale = max(1.0, float(ref.abs().max()))
+    return (2e-6 if dtype == th.float32 else 1e-11) * scale
+
+
+@pytest.mark.parametrize("name", MIPMAP_CASES)
+def test_oracle_matches_reference_model_fixture(name):
+    c = load_mipmap(name)
+    dt = c["grid"].dtype
+    out = O.mipmap_grid_sampler_2d(c["tex"], c["grid"], c["vt"], c["max_aniso"], c["padding"], c["mode"], False, True, False)
+    assert (out - c["out"]).abs().max() <= _tol(c["out"], dt)
+    glv, gg = O.mipmap_grid_sampler_2d_backward(
+        c["grad_out"], c["tex"], c["grid"], c["vt"], c["max_aniso"], c["padding"], c["mode"], False, True, False)
+    assert (gg - c["grad_grid"]).abs().max() <= _tol(c["grad_grid"], dt)
+    for g, ref in zip(glv, c["grad_tex"]):
+        assert (g - ref).abs().max() <= _tol(ref, dt)
+
+
+def test_forward_ignores_align_corners_backward_does_not():
+    """Reference quirk (mipmap_grid_sampler_kernel.cu:423): the forward kernel overrides
+    align_corners with false; the backward kernel honours it."""
+    tex, grid, vt, gout = mipmap_inputs(3, 1, 2, 16, 2, 8, 8)
+    a = O.mipmap_grid_sampler_2d(tex, grid, vt, 2, 1, 0, False, True, False)
+    b = O.mipmap_grid_sampler_2d(tex, grid, vt, 2, 1, 0, True, True, False)
+    assert th.equal(a, b)
+    _, ga = O.mipmap_grid_sampler_2d_backward(gout, tex, grid, vt, 2, 1, 0, False, True, False)
+    _, gb = O.mipmap_grid_sampler_2d_backward(gout, tex, grid, vt, 2, 1, 0, True, True, False)
+    assert not th.equal(ga, gb)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_adaptive_taps_and_clip_grad_are_self_consistent(mode):
+    """No executable reference for these modes: check what must hold by construction.
+    * isotropic footprint => one tap => identical to max_aniso=1;
+    * a constant texture is reproduced for border padding whatever the tap count / clip_grad;
+    * the texture gradients sum to the sum of grad_out (weights sum to 1) under border padding;
+    * grad_grid equals a central finite difference of the forward pass in float64."""
+    tex, grid, vt, gout = mipmap_inputs(5, 1, 2, 32, 3, 10, 10, th.float64)
+    iso = th.zeros_like(vt)
+    iso[..., 0, 0] = 0.04
+    iso[..., 1, 1] = 0.04
+    a = O.mipmap_grid_sampler_2d(tex, grid, iso, 8, 1, mode, False, False, False)
+    b = O.mipmap_grid_sampler_2d(tex, grid, iso, 1, 1, mode, False, False, False)
+    assert th.equal(a, b)
+    const = [th.full_like(t, 0.75) for t in tex]
+    for clip in (False, True):
+        out = O.mipmap_grid_sampler_2d(const, grid, vt * 6, 8, 1, mode, False, False, clip)
+        assert (out - 0.75).abs().max() < 1e-12
+        glv, gg = O.mipmap_grid_sampler_2d_backward(gout, tex, grid, vt * 6, 8, 1, mode, False, False, clip)
+        assert abs(float(sum(g.sum() for g in glv)) - float(gout.sum())) < 1e-9
+    # finite differences of the forward pass wrt the grid (zeros padding keeps it smooth inside)
+    inner = grid * 0.6
+    glv, gg = O.mipmap_grid_sampler_2d_backward(gout, tex, inner, vt, 4, 0, mode, False, False, False)
+    eps = 1e-6
+    for k in range(2):
+        d = th.zeros_like(inner)
+        d[..., k] = eps
+        fp = O.mipmap_grid_sampler_2d(tex, inner + d, vt, 4, 0, mode, False, False, False)
+        fm = O.mipmap_grid_sampler_2d(tex, inner - d, vt, 4, 0, mode, False, False, False)
+        fd = ((fp - fm) / (2 * eps) * gout).sum(1)
+        err = (fd - gg[..., k]).abs()
+        # bilinear is piecewise linear in uv: the difference quotient is wrong only across a texel boundary
+        assert float((err > 1e-4 * (1 + gg[..., k].abs())).float().mean()) < (0.02 if mode == 0 else 0.001)
