@@ -1079,9 +1079,8 @@ class MipmapGridSample2DFunction : public torch::autograd::Function<MipmapGridSa
 Tensor mipmap_grid_sampler_2d_autograd(
     at::TensorList input, const Tensor& grid, const Tensor& vt_dxdy_img, int64_t max_aniso, int64_t padding_mode,
     int64_t interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) {
-  TORCH_CHECK(
-      input.size() >= 1 && input.size() <= 11,
-      "mipmap_aniso_grid_sampler_2d(): expected between 1 and 11 mipmap levels, but got ", input.size());
+  TORCH_CHECK(input.size() >= 1, "mipmap_aniso_grid_sampler_2d(): expected input to have at least one mipmap level");
+  TORCH_CHECK(input.size() <= 11, "mipmap_aniso_grid_sampler_2d(): at most 11 mipmap levels are supported");
   auto opt = [&](size_t i) { return input.size() > i ? OptTensor(input[i]) : OptTensor(); };
   return MipmapGridSample2DFunction::apply(
       grid, vt_dxdy_img, max_aniso, padding_mode, interpolation_mode, align_corners, force_max_ansio, clip_grad, input[0],
