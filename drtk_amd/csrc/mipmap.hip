@@ -386,10 +386,13 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
           const T* p = inp + c * plane;
           T* gp = ginp + c * plane;
           const T gOut = gout_px[int64_t(c) * HW] * alpha;
-          if (q.o_nw >= 0) atomic_add_global(gp + q.o_nw, q.nw * gOut);
-          if (q.o_ne >= 0) atomic_add_global(gp + q.o_ne, q.ne * gOut);
-          if (q.o_sw >= 0) atomic_add_global(gp + q.o_sw, q.sw * gOut);
-          if (q.o_se >= 0) atomic_add_global(gp + q.o_se, q.se * gOut);
+          // a zero upstream gradient (masked background) adds nothing: skip its four atomics
+          if (gOut != T(0)) {
+            if (q.o_nw >= 0) atomic_add_global(gp + q.o_nw, q.nw * gOut);
+            if (q.o_ne >= 0) atomic_add_global(gp + q.o_ne, q.ne * gOut);
+            if (q.o_sw >= 0) atomic_add_global(gp + q.o_sw, q.sw * gOut);
+            if (q.o_se >= 0) atomic_add_global(gp + q.o_se, q.se * gOut);
+          }
           if (q.o_nw >= 0) {
             const T val = p[q.o_nw];
             gix -= val * (iy_se - q.iy) * gOut;
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
             for (int j2 = 0; j2 < 4; ++j2) {
               const bool ok = cb.xi[i2] >= 0 && cb.yi[j2] >= 0;
               const int o = ok ? cb.yi[j2] * w + cb.xi[i2] : 0;
-              if (ok) atomic_add_global(gp + o, gOut * xc[i2] * yc[j2]);
+              if (ok && gOut != T(0)) atomic_add_global(gp + o, gOut * xc[i2] * yc[j2]);
               const T val = ok ? p[o] : T(0);
               gix -= gOut * val * (xg[i2] * yc[j2]);
               giy -= gOut * val * (yg[j2] * xc[i2]);

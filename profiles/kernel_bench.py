@@ -19,6 +19,8 @@ ap.add_argument("--views", type=int, default=8)
 ap.add_argument("--mesh", default="100k")
 ap.add_argument("--res", type=int, default=2048)
 ap.add_argument("--channels", type=int, default=16)
+ap.add_argument("--tex", type=int, default=4096)
+ap.add_argument("--uvscale", type=float, default=1.0)
 a = ap.parse_args()
 dev = "cuda:0"
 nl, no = S.MESH_SIZES[a.mesh]
@@ -43,6 +45,31 @@ kernels = {
     "interpolate_backward": lambda: capi.interpolate_backward(go, attr, vi, index, bary, True, True),
     "render_backward": lambda: capi.render_backward(v, vi, index, gd, gb),
 }
+if "mipmap" in a.only:
+    # textured shading of the same views: the sphere's own lat/long atlas as uv
+    # (smooth, anisotropic towards the limb and the poles), RGB texture with its full pyramid,
+    # Jacobian from finite differences of the uv image.  --tex picks the texture size: 4096 gives
+    # ~1-2 texels per pixel (levels 0-1), 16384-equivalent minification is emulated with --uvscale.
+    S = a.tex
+    gt = th.Generator(device=dev).manual_seed(1)
+    tex = [th.rand(a.views, 3, S, S, device=dev, generator=gt)]
+    while tex[-1].shape[-1] > 1 and len(tex) < 11:  # the op takes at most 11 levels
+        tex.append(th.nn.functional.avg_pool2d(tex[-1], 2))
+    vid = th.arange(v.shape[1], device=dev)
+    uv_attr = th.stack([(vid % no).float() / no, (vid // no).float() / nl], -1)[None].expand(a.views, -1, -1).contiguous()
+    uv = capi.interpolate(uv_attr, vi, index, bary).permute(0, 2, 3, 1).contiguous() * a.uvscale  # [N,H,W,2]
+    uv = th.where((index != -1)[..., None], uv, th.zeros_like(uv))
+    uvn = (uv % 1.0) * 2 - 1
+    jac = th.zeros(a.views, H, W, 2, 2, device=dev)
+    jac[:, :, :-1, 0, :] = uv[:, :, 1:] - uv[:, :, :-1]
+    jac[:, :-1, :, 1, :] = uv[:, 1:] - uv[:, :-1]
+    jac = th.where(jac.abs() > 0.25 * a.uvscale, th.zeros_like(jac), jac).contiguous()  # atlas seam / silhouette
+    gmo = th.rand(a.views, 3, H, W, device=dev, generator=gt) * (index != -1)[:, None]  # masked like a real loss
+    kernels["mipmap_fwd"] = lambda: capi.mipmap_grid_sampler_2d(tex, uvn, jac, 8, 1, 0)
+    kernels["mipmap_bwd"] = lambda: capi.mipmap_grid_sampler_2d_backward(gmo, tex, uvn, jac, 8, 1, 0)
+    kernels["mipmap_fwd_bicubic"] = lambda: capi.mipmap_grid_sampler_2d(tex, uvn, jac, 8, 1, 2)
+    kernels["mipmap_bwd_bicubic"] = lambda: capi.mipmap_grid_sampler_2d_backward(gmo, tex, uvn, jac, 8, 1, 2)
+    kernels["torch_grid_sample_fwd"] = lambda: th.nn.functional.grid_sample(tex[0], uvn, mode="bilinear", padding_mode="border", align_corners=False)
 th.cuda.synchronize()
 for name, fn in kernels.items():
     if a.only and name not in a.only.split(","):
