@@ -7,6 +7,7 @@ from drtk_amd.interpolate import interpolate, interpolation_matrix, interpolatio
 from drtk_amd.mipmap_grid_sample import mipmap_grid_sample  # noqa: F401
 from drtk_amd.rasterize import rasterize, rasterize_with_depth  # noqa: F401
 from drtk_amd.render import render  # noqa: F401
+from drtk_amd.screen_space_uv_derivative import screen_space_uv_derivative  # noqa: F401
 from drtk_amd.transform import transform, transform_with_v_cam  # noqa: F401
 
 __version__ = "0.1.0"

@@ -54,6 +54,7 @@ EXPORTS = [
     "drtk_amd_interpolation_normal_matrix_values_backward",
     "drtk_amd_mipmap_grid_sampler_2d",
     "drtk_amd_mipmap_grid_sampler_2d_backward",
+    "drtk_amd_screen_space_uv_derivative",
     "drtk_amd_transform_pinhole",
     "drtk_amd_transform_pinhole_backward",
     "drtk_amd_selftest_exact_div",
@@ -315,6 +316,27 @@ def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_ani
             gptrs, _p(ggrid), _stream(lv[0], stream)),
         "mipmap_grid_sampler_2d_backward")
     return glv, ggrid
+
+
+def screen_space_uv_derivative(v, vt, vi, vti, index_img, bary_img, mask, campos, camrot, focal, stream=None):
+    """v [N,V,3] or shared [V,3]; vt [N,T,2] or shared [T,2]; mask bool/uint8 [N,H,W] or None."""
+    index_img = index_img.contiguous()
+    bary_img = bary_img.contiguous()
+    N, H, W = index_img.shape
+    v_c, vt_c = v.contiguous(), vt.contiguous()
+    v_sN = 0 if v_c.ndim == 2 else v_c.shape[1] * 3
+    vt_sN = 0 if vt_c.ndim == 2 else vt_c.shape[1] * 2
+    V, T = v_c.shape[-2], vt_c.shape[-2]
+    vi_c, vti_c = vi.contiguous(), vti.contiguous()
+    m = None if mask is None else mask.to(th.uint8).contiguous()
+    out = th.empty(N, H, W, 2, 2, dtype=bary_img.dtype, device=bary_img.device)
+    _check(
+        lib().drtk_amd_screen_space_uv_derivative(
+            ctypes.c_int(_dt(bary_img)), _p(v_c), _i(v_sN), _p(vt_c), _i(vt_sN), _p(vi_c), _p(vti_c), _p(index_img),
+            _p(bary_img), _p(m), _p(campos.contiguous()), _p(camrot.contiguous()), _p(focal.contiguous()), _i(N), _i(V),
+            _i(T), _i(vi_c.shape[0]), _i(H), _i(W), _p(out), _stream(bary_img, stream)),
+        "screen_space_uv_derivative")
+    return out
 
 
 def edge_grad_backward_workspace_bytes(dtype, N, H, W) -> int:

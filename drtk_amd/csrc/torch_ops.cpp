@@ -1097,6 +1097,49 @@ Tensor mipmap_grid_sampler_2d_autocast(
       force_max_ansio, clip_grad);
 }
 
+// screen_space_uv_derivative: drtk/screen_space_uv_derivative.py:15-80 as one kernel (forward only)
+Tensor screen_space_uv_derivative_hip(
+    const Tensor& v, const Tensor& vt, const Tensor& vi, const Tensor& vti, const Tensor& index_img,
+    const Tensor& bary_img, const Tensor& mask, const Tensor& campos, const Tensor& camrot, const Tensor& focal) {
+  const char* op = "screen_space_uv_derivative";
+  TORCH_CHECK(v.dim() == 3 && v.size(2) == 3, op, "(): expected v to be [N,V,3], got ", v.sizes()); // geometry.py:60-61
+  TORCH_CHECK(vt.dim() == 3 && vt.size(2) == 2, op, "(): expected vt to be [N,T,2], got ", vt.sizes());
+  TORCH_CHECK(vt.size(0) == v.size(0), op, "(): expected vt to have the same batch size as v, got ", vt.size(0), " and ", v.size(0));
+  TORCH_CHECK(vi.dim() == 2 && vi.size(1) == 3 && vti.sizes() == vi.sizes(), op, "(): expected vi and vti to be [F,3]");
+  TORCH_CHECK(vi.dtype() == at::kInt && vti.dtype() == at::kInt && index_img.dtype() == at::kInt, op, "(): expected int32 vi, vti and index_img");
+  TORCH_CHECK(index_img.dim() == 3 && bary_img.dim() == 4 && bary_img.size(1) == 3 && bary_img.size(0) == index_img.size(0) &&
+                  bary_img.size(2) == index_img.size(1) && bary_img.size(3) == index_img.size(2),
+              op, "(): expected index_img [N,H,W] and bary_img [N,3,H,W]");
+  const int64_t N = index_img.size(0), H = index_img.size(1), W = index_img.size(2);
+  TORCH_CHECK(v.size(0) == N && campos.sizes() == at::IntArrayRef({N, 3}) && camrot.sizes() == at::IntArrayRef({N, 3, 3}) &&
+                  focal.sizes() == at::IntArrayRef({N, 2, 2}),
+              op, "(): expected v, campos [N,3], camrot [N,3,3], focal [N,2,2] to share the batch size of index_img");
+  TORCH_CHECK(mask.sizes() == index_img.sizes() && (mask.dtype() == at::kBool || mask.dtype() == at::kByte), op, "(): expected a bool mask [N,H,W]");
+  TORCH_CHECK(v.dtype() == vt.dtype() && v.dtype() == bary_img.dtype() && v.dtype() == campos.dtype() && v.dtype() == camrot.dtype() &&
+                  v.dtype() == focal.dtype(), op, "(): expected v, vt, bary_img and the camera tensors to share one dtype");
+  TORCH_CHECK(v.is_cuda(), op, "(): drtk_amd implements the MI355X (HIP) path only; got CPU tensors");
+  for (const Tensor* t : {&vt, &vi, &vti, &index_img, &bary_img, &mask, &campos, &camrot, &focal})
+    TORCH_CHECK(t->device() == v.device(), op, "(): expected all inputs to be on same device");
+  const drtk_dtype_t dt = dtype_of(v, op);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
+  // view-shared geometry (stride-0 batch) is passed once
+  const bool v_shared = N > 1 && v.stride(0) == 0, vt_shared = N > 1 && vt.stride(0) == 0;
+  const auto v_c = (v_shared ? v.select(0, 0) : v).contiguous();
+  const auto vt_c = (vt_shared ? vt.select(0, 0) : vt).contiguous();
+  const auto vi_c = vi.contiguous(), vti_c = vti.contiguous(), idx_c = index_img.contiguous(), bary_c = bary_img.contiguous();
+  const auto mask_c = mask.to(at::kByte).contiguous();
+  const auto cp_c = campos.contiguous(), cr_c = camrot.contiguous(), f_c = focal.contiguous();
+  auto out = at::empty({N, H, W, 2, 2}, bary_img.options());
+  check_status(
+      drtk_amd_screen_space_uv_derivative(
+          dt, v_c.data_ptr(), v_shared ? 0 : v.size(1) * 3, vt_c.data_ptr(), vt_shared ? 0 : vt.size(1) * 2,
+          vi_c.data_ptr<int32_t>(), vti_c.data_ptr<int32_t>(), idx_c.data_ptr<int32_t>(), bary_c.data_ptr(),
+          mask_c.data_ptr<uint8_t>(), cp_c.data_ptr(), cr_c.data_ptr(), f_c.data_ptr(), N, v.size(1), vt.size(1), vi.size(0), H,
+          W, out.data_ptr(), current_stream(v)),
+      op);
+  return out;
+}
+
 // ---------------------------------------------------------------------------------------------
 // edge_grad_estimator
 // ---------------------------------------------------------------------------------------------
@@ -1535,6 +1578,9 @@ TORCH_LIBRARY_IMPL(mipmap_grid_sampler_ext, CPU, m) { // the reference registers
 // drtk_amd's own namespace (extensions with no reference counterpart)
 TORCH_LIBRARY(drtk_amd_ext, m) {
   m.def("transform_pinhole(Tensor v, Tensor campos, Tensor camrot, Tensor focal, Tensor princpt) -> Tensor");
+  m.def(
+      "screen_space_uv_derivative(Tensor v, Tensor vt, Tensor vi, Tensor vti, Tensor index_img, Tensor bary_img, Tensor mask, Tensor campos, Tensor camrot, Tensor focal) -> Tensor",
+      &screen_space_uv_derivative_hip);
   // topology-only: the cached A^T A pattern (crow_indices, col_indices, pair_indices) on vi's device
   m.def("normal_matrix_structure(Tensor vi, int num_vertices) -> (Tensor, Tensor, Tensor)", &normal_matrix_structure_any);
   m.def("normal_matrix_cache_stats() -> int[]", &normal_matrix_cache_stats);

@@ -1,0 +1,136 @@
+// screen_space_uv_derivative -- per-pixel Jacobian of the texture coordinates wrt the pixel position,
+// [[du/dx, dv/dx], [du/dy, dv/dy]], the `vt_dxdy_img` input of mipmap_grid_sample.
+//
+// Reference: drtk/screen_space_uv_derivative.py:15-80, a PyTorch composite over
+//   face_dpdt            drtk/utils/geometry.py:18-82     (dp/dt)^T = ((dt/db)^T)^-1 (dp/db)^T per face
+//   interpolate x2       of the per-face Jacobian (6 channels) and of the face's vertex positions
+//   project_points_grad  drtk/utils/projection.py:650-709  pinhole Jacobian applied to both rows
+//   linalg.inv_ex + mask
+// which materialises ~40 floats per pixel in intermediate images.  Here it is ONE kernel: lane = pixel,
+// reads index (4 B) + bary (12 B), gathers the triangle's 3 positions and 3 uvs, writes 16 B.
+// The arithmetic follows the composite step by step (including the x*b0 + x*b1 + x*b2 form that
+// `interpolate` gives a per-face constant), the two 2x2 inverses are closed-form adjugates.
+// Pinhole cameras only, like project_points_grad itself (distortion raises NotImplementedError there).
+#include "common.hpp"
+
+namespace drtk_amd {
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
+    const T* __restrict__ v, int64_t v_sN, const T* __restrict__ vt, int64_t vt_sN,
+    const int32_t* __restrict__ vi, const int32_t* __restrict__ vti, const int32_t* __restrict__ index_img,
+    const T* __restrict__ bary_img, const uint8_t* __restrict__ mask, const T* __restrict__ campos,
+    const T* __restrict__ camrot, const T* __restrict__ focal, int64_t HW, T* __restrict__ out) {
+  const int n = blockIdx.y;
+  const int64_t pix = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (pix >= HW) return;
+  const int32_t tr = index_img[int64_t(n) * HW + pix];
+  T o00 = T(0), o01 = T(0), o10 = T(0), o11 = T(0);
+  const bool keep = tr >= 0 && (mask == nullptr || mask[int64_t(n) * HW + pix] != 0);
+  if (keep) {
+    const T* bp = bary_img + int64_t(n) * 3 * HW + pix;
+    const T b0 = bp[0], b1 = bp[HW], b2 = bp[2 * HW];
+    const int32_t* f = vi + int64_t(tr) * 3;
+    const int32_t* ft = vti + int64_t(tr) * 3;
+    const T* v_n = v + int64_t(n) * v_sN;
+    const T* vt_n = vt + int64_t(n) * vt_sN;
+    T p[3][3], t[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const T* q = v_n + int64_t(f[k]) * 3;
+      p[k][0] = q[0], p[k][1] = q[1], p[k][2] = q[2];
+      const T* r = vt_n + int64_t(ft[k]) * 2;
+      t[k][0] = r[0], t[k][1] = r[1];
+    }
+    // face_dpdt: dtdb_t = [[t1-t0],[t2-t0]] (rows), dpdb_t = [[p1-p0],[p2-p0]]
+    const T a = t[1][0] - t[0][0], b = t[1][1] - t[0][1];
+    const T c = t[2][0] - t[0][0], d = t[2][1] - t[0][1];
+    const T det = a * d - b * c;
+    const T i00 = d / det, i01 = -b / det, i10 = -c / det, i11 = a / det; // inverse(dtdb_t)
+    T dpdt[2][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const T e1 = p[1][j] - p[0][j], e2 = p[2][j] - p[0][j];
+      dpdt[0][j] = i00 * e1 + i01 * e2;
+      dpdt[1][j] = i10 * e1 + i11 * e2;
+    }
+    // the two interpolate() calls: per-face constant -> x*b0 + x*b1 + x*b2 ; positions -> sum b_k p_k
+    T P[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dpdt[0][j] = dpdt[0][j] * b0 + dpdt[0][j] * b1 + dpdt[0][j] * b2;
+      dpdt[1][j] = dpdt[1][j] * b0 + dpdt[1][j] * b1 + dpdt[1][j] * b2;
+      P[j] = p[0][j] * b0 + p[1][j] * b1 + p[2][j] * b2;
+    }
+    // project_points_grad (pinhole)
+    const T* R = camrot + int64_t(n) * 9;
+    const T* cp = campos + int64_t(n) * 3;
+    const T* K = focal + int64_t(n) * 4;
+    const T dx = P[0] - cp[0], dy = P[1] - cp[1], dz = P[2] - cp[2];
+    const T cx = R[0] * dx + R[1] * dy + R[2] * dz;
+    const T cy = R[3] * dx + R[4] * dy + R[5] * dz;
+    T z = R[6] * dx + R[7] * dy + R[8] * dz;
+    const T e = T(1e-8);
+    z = z < T(0) ? (z < -e ? z : -e) : (z > e ? z : e);
+    const T zz = z * z;
+    T J[2][2]; // J[i][j] = d p_pix[j] / d t[i]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const T gx = R[0] * dpdt[i][0] + R[1] * dpdt[i][1] + R[2] * dpdt[i][2];
+      const T gy = R[3] * dpdt[i][0] + R[4] * dpdt[i][1] + R[5] * dpdt[i][2];
+      const T gz = R[6] * dpdt[i][0] + R[7] * dpdt[i][1] + R[8] * dpdt[i][2];
+      const T px = (gx * z - cx * gz) / zz;
+      const T py = (gy * z - cy * gz) / zz;
+      J[i][0] = K[0] * px + K[1] * py;
+      J[i][1] = K[2] * px + K[3] * py;
+    }
+    // vt_dxdy = inverse(J): [i][j] = d t[j] / d p_pix[i]
+    const T dj = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    o00 = J[1][1] / dj;
+    o01 = -J[0][1] / dj;
+    o10 = -J[1][0] / dj;
+    o11 = J[0][0] / dj;
+  }
+  T* o = out + (int64_t(n) * HW + pix) * 4;
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<float4*>(o) = make_float4(o00, o01, o10, o11);
+  } else {
+    o[0] = o00, o[1] = o01, o[2] = o10, o[3] = o11;
+  }
+}
+
+} // namespace
+} // namespace drtk_amd
+
+using namespace drtk_amd;
+
+extern "C" int drtk_amd_screen_space_uv_derivative(
+    drtk_dtype_t dtype, const void* v, int64_t v_sN, const void* vt, int64_t vt_sN, const int32_t* vi,
+    const int32_t* vti, const int32_t* index_img, const void* bary_img, const uint8_t* mask, const void* campos,
+    const void* camrot, const void* focal, int64_t N, int64_t V, int64_t T_, int64_t F, int64_t H, int64_t W,
+    void* out, drtk_stream_t stream) {
+  if (N < 0 || V < 0 || T_ < 0 || F < 0 || H < 0 || W < 0 || N > 65535 || H * W >= (int64_t(1) << 31) ||
+      (v_sN != 0 && v_sN != V * 3) || (vt_sN != 0 && vt_sN != T_ * 2) || (dtype != DRTK_F32 && dtype != DRTK_F64))
+    return DRTK_ERR_INVALID_ARGUMENT;
+  if (N * H * W == 0) return DRTK_OK;
+  if (!index_img || !bary_img || !out || !campos || !camrot || !focal || (F > 0 && (!vi || !vti || !v || !vt)))
+    return DRTK_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N));
+  if (dtype == DRTK_F32) {
+    hipLaunchKernelGGL(
+        (uv_derivative_kernel<float>), grid, dim3(kBlock), 0, s, static_cast<const float*>(v), v_sN,
+        static_cast<const float*>(vt), vt_sN, vi, vti, index_img, static_cast<const float*>(bary_img), mask,
+        static_cast<const float*>(campos), static_cast<const float*>(camrot), static_cast<const float*>(focal), H * W,
+        static_cast<float*>(out));
+  } else {
+    hipLaunchKernelGGL(
+        (uv_derivative_kernel<double>), grid, dim3(kBlock), 0, s, static_cast<const double*>(v), v_sN,
+        static_cast<const double*>(vt), vt_sN, vi, vti, index_img, static_cast<const double*>(bary_img), mask,
+        static_cast<const double*>(campos), static_cast<const double*>(camrot), static_cast<const double*>(focal),
+        H * W, static_cast<double*>(out));
+  }
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}

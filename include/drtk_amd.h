@@ -188,6 +188,23 @@ int drtk_amd_mipmap_grid_sampler_2d_backward(
     int force_max_aniso, int clip_grad, void* const* grad_levels, void* grad_grid, drtk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * screen_space_uv_derivative -- vt_dxdy_img [N,H,W,2,2] = [[du/dx, dv/dx],[du/dy, dv/dy]] per pixel, the
+ * Jacobian input of mipmap_grid_sampler_2d; replaces the PyTorch composite
+ * drtk/screen_space_uv_derivative.py:15-80 (face_dpdt + 2x interpolate + project_points_grad + inv_ex +
+ * mask) with one kernel.  Pinhole cameras only (as project_points_grad, projection.py:650-709).
+ *   v [N,V,3] world-space (v_sN = 3V, or 0 for one shared [V,3]);  vt [N,T,2] (vt_sN = 2T or 0)
+ *   vi, vti [F,3] int32;  index_img [N,H,W];  bary_img [N,3,H,W];  mask [N,H,W] uint8 or NULL
+ *   campos [N,3], camrot [N,3,3], focal [N,2,2].   Pixels with index -1 or mask 0 are written 0.
+ * Forward only (the reference composite is differentiable through autograd; its consumer,
+ * mipmap_grid_sampler_2d, defines no gradient for this input).
+ */
+int drtk_amd_screen_space_uv_derivative(
+    drtk_dtype_t dtype, const void* v, int64_t v_sN, const void* vt, int64_t vt_sN, const int32_t* vi,
+    const int32_t* vti, const int32_t* index_img, const void* bary_img, const uint8_t* mask,
+    const void* campos, const void* camrot, const void* focal, int64_t N, int64_t V, int64_t T, int64_t F,
+    int64_t H, int64_t W, void* out, drtk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * transform_pinhole  -- the vertex stage in front of the path; replaces the pure-PyTorch pinhole
  * branch of drtk.transform (drtk/transform.py:13-119, drtk/utils/projection.py:33-53,486-540):
  *   v_cam = camrot (v - campos);  v_pix = (focal (v_cam.xy / clamp(v_cam.z)) + princpt, v_cam.z)

@@ -9,6 +9,8 @@ clip_grad=False (and high_quality=False on the model side).  Each fixture holds 
 model's output and its autograd gradients wrt every mip level and the grid.
 
     python oracle/gen_golden_mipmap.py      # rewrites tests/golden/mipmap_*.npz
+    python oracle/gen_golden_mipmap.py --uv # rewrites tests/golden/uv_derivative_*.npz (own process: it binds
+                                            # interpolate_ext::interpolate to the reference's CPU kernel)
 """
 import builtins
 import os
@@ -19,6 +21,7 @@ import numpy as np
 import torch as th
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 ROOT = os.path.dirname(HERE)
 OUT = os.path.join(ROOT, "tests", "golden")
 REF = "/root/reference"
@@ -86,5 +89,60 @@ def main():
         print(f"  {path}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--uv" not in sys.argv:
     main()
+
+
+# ---- screen_space_uv_derivative: the reference's own PyTorch composite, run on CPU ---------------------
+def gen_uv_derivative():
+    """drtk.screen_space_uv_derivative (drtk/screen_space_uv_derivative.py:15-80) calls
+    th.ops.interpolate_ext.interpolate; in this process that op is bound to the reference's own CPU kernel
+    (oracle/_ref, built from /root/reference/src/interpolate) so the whole composite is the reference's code."""
+    import ref_build
+
+    ref_build.build(verbose=False)
+    rs = ref_build.load("strict")
+    lib = th.library.Library("interpolate_ext", "DEF")
+    lib.define("interpolate(Tensor vert_attributes, Tensor vi, Tensor index_img, Tensor bary_img) -> Tensor")
+    lib.impl("interpolate", lambda a, vi, idx, bary: rs.interpolate(a.contiguous(), vi.contiguous(), idx, bary), "CPU")
+    import_reference_model()
+    sys.path.insert(0, REF)
+    from drtk.screen_space_uv_derivative import screen_space_uv_derivative  # noqa: E402
+
+    sys.path.remove(REF)
+    for name, dtype in (("f32", th.float32), ("f64", th.float64)):
+        g = th.Generator().manual_seed(5)
+        n, gsz, H, W = 2, 7, 40, 48
+        # a perturbed grid mesh in front of two cameras, separate uv topology (vti != vi)
+        ys, xs = th.meshgrid(th.linspace(-1, 1, gsz, dtype=th.float64), th.linspace(-1, 1, gsz, dtype=th.float64), indexing="ij")
+        v = th.stack([xs, ys, th.zeros_like(xs)], -1).reshape(-1, 3)
+        v = v + th.randn(v.shape, generator=g, dtype=th.float64) * th.tensor([0.04, 0.04, 0.15], dtype=th.float64)
+        quads = [(r * gsz + c, r * gsz + c + 1, (r + 1) * gsz + c, (r + 1) * gsz + c + 1) for r in range(gsz - 1) for c in range(gsz - 1)]
+        vi = th.tensor([t for a, b, c2, d in quads for t in ((a, b, c2), (b, d, c2))], dtype=th.int32)
+        vti = th.arange(vi.numel(), dtype=th.int32).view(-1, 3)  # every corner has its own uv
+        uv_v = (v[:, :2] * 0.4 + 0.5) + th.randn(v.shape[0], 2, generator=g, dtype=th.float64) * 0.02
+        vt = uv_v[vi.long().reshape(-1)] + th.randn(vi.numel(), 2, generator=g, dtype=th.float64) * 0.003
+        ang = th.tensor([0.25, -0.4], dtype=th.float64)
+        camrot = th.stack([th.tensor([[th.cos(a), 0, th.sin(a)], [0, 1, 0], [-th.sin(a), 0, th.cos(a)]], dtype=th.float64) for a in ang])
+        campos = -(camrot.transpose(1, 2) @ th.tensor([0.0, 0.0, 3.0], dtype=th.float64))
+        focal = th.stack([th.eye(2, dtype=th.float64) * 1.1 * W, th.tensor([[1.2 * W, 3.0], [0.0, 1.0 * W]], dtype=th.float64)])
+        princpt = th.tensor([[W / 2, H / 2], [W / 2 + 2, H / 2 - 1]], dtype=th.float64)
+        v, vt, camrot, campos, focal, princpt = (t.to(dtype) for t in (v, vt, camrot, campos, focal, princpt))
+        vN, vtN = v[None].expand(n, -1, -1).contiguous(), vt[None].expand(n, -1, -1).contiguous()
+        v_cam = (camrot[:, None] @ (vN - campos[:, None])[..., None])[..., 0]
+        v_pix = th.cat([(focal[:, None] @ (v_cam[..., :2] / v_cam[..., 2:3])[..., None])[..., 0] + princpt[:, None], v_cam[..., 2:3]], -1).contiguous()
+        vib = vi[None].expand(n, -1, -1).contiguous()
+        _, index = rs.rasterize(v_pix, vib, H, W)
+        _, bary = rs.render(v_pix, vib, index)
+        mask = index != -1
+        out = screen_space_uv_derivative(vN, vtN, vi, vti, index, bary, mask, campos, camrot, focal)
+        arrs = {"in_v": vN.numpy(), "in_vt": vtN.numpy(), "in_vi": vi.numpy(), "in_vti": vti.numpy(), "in_index_img": index.numpy(),
+                "in_bary_img": bary.numpy(), "in_campos": campos.numpy(), "in_camrot": camrot.numpy(), "in_focal": focal.numpy(),
+                "out_vt_dxdy_img": out.numpy()}
+        path = os.path.join(OUT, f"uv_derivative_{name}.npz")
+        np.savez_compressed(path, **arrs)
+        print(f"  {path}: {os.path.getsize(path) / 1024:.1f} KiB, covered {int(mask.sum())} px, max |J| {float(out.abs().max()):.3f}")
+
+
+if __name__ == "__main__" and "--uv" in sys.argv:
+    gen_uv_derivative()

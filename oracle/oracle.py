@@ -279,3 +279,38 @@ def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_ani
           ctypes.c_int(interpolation_mode), ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)),
           ctypes.c_int(bool(clip_grad)), gptrs, _p(ggrid))
     return glv, ggrid
+
+
+# ---- screen_space_uv_derivative (drtk/screen_space_uv_derivative.py:15-80) ---------------------------
+def screen_space_uv_derivative(v, vt, vi, vti, index_img, bary_img, mask, campos, camrot, focal):
+    """CPU restatement of the reference's PyTorch composite, step by step, on top of the oracle's own
+    `interpolate`: face_dpdt (drtk/utils/geometry.py:71-82) -> interpolate of the per-face Jacobian and of
+    the face vertex positions with a de-indexed face list -> project_points_grad (pinhole,
+    drtk/utils/projection.py:683-699) -> 2x2 inverse -> mask.  Pinned against a fixture produced by the
+    reference's own function (oracle/gen_golden_mipmap.py)."""
+    vi_l, vti_l = vi.long(), vti.long()
+    v012 = v[:, vi_l]  # [N,F,3,3]
+    vt012 = vt[:, vti_l]  # [N,F,3,2]
+    dpdb_t = v012[:, :, 1:3] - v012[:, :, 0:1]
+    dtdb_t = vt012[:, :, 1:3] - vt012[:, :, 0:1]
+    dpdt_t = th.inverse(dtdb_t) @ dpdb_t  # [N,F,2,3]
+    N, F = dpdt_t.shape[:2]
+    dpdt3 = dpdt_t[:, :, None].expand(-1, -1, 3, -1, -1)
+    vi_dis = th.arange(0, 3 * F, dtype=th.int32).view(-1, 3)
+    dpdt_img = interpolate(dpdt3.reshape(N, F * 3, 6).contiguous(), vi_dis, index_img, bary_img).permute(0, 2, 3, 1)
+    dpdt_img = dpdt_img.reshape(*dpdt_img.shape[:3], 2, 3)
+    vf_img = interpolate(v012.reshape(N, F * 3, 3).contiguous(), vi_dis, index_img, bary_img).permute(0, 2, 3, 1)
+    vf_img = vf_img[:, :, :, None].expand(-1, -1, -1, 2, -1)
+    v_grad = dpdt_img.reshape(N, -1, 3)
+    vv = vf_img.reshape(N, -1, 3)
+    v_cam_grad = (camrot[:, None] @ v_grad[..., None])[..., 0]
+    v_cam = (camrot[:, None] @ (vv - campos[:, None])[..., None])[..., 0]
+    z = v_cam[:, :, 2:3]
+    z_grad = v_cam_grad[:, :, 2:3]
+    z = th.where(z < 0, z.clamp(max=-1e-8), z.clamp(min=1e-8))
+    v_proj_grad = (v_cam_grad[:, :, 0:2] * z - v_cam[:, :, 0:2] * z_grad) / z**2.0
+    v_pix_grad = (focal[:, None] @ v_proj_grad[..., None])[..., 0]
+    J = v_pix_grad.view(*dpdt_img.shape[:3], 2, 2)
+    out, _ = th.linalg.inv_ex(J)
+    out[~mask, :, :] = 0
+    return out

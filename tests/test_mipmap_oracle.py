@@ -73,3 +73,19 @@ def test_adaptive_taps_and_clip_grad_are_self_consistent(mode):
         err = (fd - gg[..., k]).abs()
         # bilinear is piecewise linear in uv: the difference quotient is wrong only across a texel boundary
         assert float((err > 1e-4 * (1 + gg[..., k].abs())).float().mean()) < (0.02 if mode == 0 else 0.001)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_uv_derivative_restatement_matches_reference_composite(tag):
+    """oracle.screen_space_uv_derivative vs the fixture produced by the reference's own
+    drtk.screen_space_uv_derivative (its interpolate calls served by the reference's CPU kernel)."""
+    from conftest import load_golden
+
+    i, o = load_golden("uv_derivative_" + tag)
+    mask = i["index_img"] != -1
+    got = O.screen_space_uv_derivative(i["v"], i["vt"], i["vi"], i["vti"], i["index_img"], i["bary_img"], mask, i["campos"],
+                                       i["camrot"], i["focal"])
+    ref = o["vt_dxdy_img"]
+    tol = (1e-6 if tag == "f32" else 1e-13) * max(1.0, float(ref.abs().max()))
+    assert (got - ref).abs().max() <= tol
+    assert float(ref[~mask].abs().sum()) == 0.0 and float(ref[mask].abs().min()) >= 0.0
