@@ -275,6 +275,29 @@ __device__ __forceinline__ void stage_levels(const LevelTable& lv, int mipmaps, 
   __syncthreads();
 }
 
+template <typename T>
+using GlobalPtr = __attribute__((address_space(1))) T*;
+
+// float/double atomic add through an explicitly global pointer (global_atomic_add_f32 / _f64)
+template <typename T>
+__device__ __forceinline__ void atomic_add_g1(GlobalPtr<T> p, T v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// two horizontally adjacent texels, loaded with one element-aligned 8/16-byte access
+template <typename T>
+struct PairOf;
+template <>
+struct PairOf<float> {
+  typedef float type __attribute__((ext_vector_type(2), aligned(4)));
+};
+template <>
+struct PairOf<double> {
+  typedef double type __attribute__((ext_vector_type(2), aligned(8)));
+};
+template <typename T>
+using Pair = typename PairOf<T>::type;
+
 constexpr int kChBlock = 4; // channels accumulated in registers per sweep over the taps
 
 template <typename T, int MODE>
@@ -306,18 +329,36 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
         const int d = t.d1 + s;
         const int h = s_h[d], w = s_w[d];
         const int64_t plane = int64_t(h) * w;
-        const T* base = static_cast<const T*>(s_ptr[d]) + (n * C + c0) * plane;
+        // the level pointers come back from LDS as generic pointers: pin them to the global address
+        // space, otherwise every texel access is a flat_load / flat_atomic
+        const GlobalPtr<const T> base = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + (n * C + c0) * plane);
         const T alpha = s == 0 ? alpha_2 : alpha_1;
         if constexpr (MODE == 0) {
           const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
 #pragma unroll
           for (int cc = 0; cc < kChBlock; ++cc) {
             if (c0 + cc < C) {
-              const T* p = base + cc * plane;
-              if (q.o_nw >= 0) acc[cc] += p[q.o_nw] * q.nw * alpha;
-              if (q.o_ne >= 0) acc[cc] += p[q.o_ne] * q.ne * alpha;
-              if (q.o_sw >= 0) acc[cc] += p[q.o_sw] * q.sw * alpha;
-              if (q.o_se >= 0) acc[cc] += p[q.o_se] * q.se * alpha;
+              const GlobalPtr<const T> p = base + cc * plane;
+              // the two texels of a row are adjacent in memory: one 8-byte (4-byte aligned) load per row
+              T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
+              if (q.o_nw >= 0 && q.o_ne >= 0) {
+                const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_nw);
+                v_nw = t2.x, v_ne = t2.y;
+              } else {
+                if (q.o_nw >= 0) v_nw = p[q.o_nw];
+                if (q.o_ne >= 0) v_ne = p[q.o_ne];
+              }
+              if (q.o_sw >= 0 && q.o_se >= 0) {
+                const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_sw);
+                v_sw = t2.x, v_se = t2.y;
+              } else {
+                if (q.o_sw >= 0) v_sw = p[q.o_sw];
+                if (q.o_se >= 0) v_se = p[q.o_se];
+              }
+              if (q.o_nw >= 0) acc[cc] += v_nw * q.nw * alpha;
+              if (q.o_ne >= 0) acc[cc] += v_ne * q.ne * alpha;
+              if (q.o_sw >= 0) acc[cc] += v_sw * q.sw * alpha;
+              if (q.o_se >= 0) acc[cc] += v_se * q.se * alpha;
             }
           }
         } else {
@@ -328,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
 #pragma unroll
           for (int cc = 0; cc < kChBlock; ++cc) {
             if (c0 + cc < C) {
-              const T* p = base + cc * plane;
+              const GlobalPtr<const T> p = base + cc * plane;
               T co[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
@@ -375,23 +416,23 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
       const int d = t.d1 + s;
       const int h = s_h[d], w = s_w[d];
       const int64_t plane = int64_t(h) * w;
-      const T* inp = static_cast<const T*>(s_ptr[d]) + n * C * plane;
-      T* ginp = static_cast<T*>(s_grad[d]) + n * C * plane;
+      const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * C * plane);
+      const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + n * C * plane);
       const T alpha = s == 0 ? alpha_2 : alpha_1;
       T gix = T(0), giy = T(0);
       if constexpr (MODE == 0) {
         const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
         const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
         for (int c = 0; c < C; ++c) {
-          const T* p = inp + c * plane;
-          T* gp = ginp + c * plane;
+          const GlobalPtr<const T> p = inp + c * plane;
+          const GlobalPtr<T> gp = ginp + c * plane;
           const T gOut = gout_px[int64_t(c) * HW] * alpha;
           // a zero upstream gradient (masked background) adds nothing: skip its four atomics
           if (gOut != T(0)) {
-            if (q.o_nw >= 0) atomic_add_global(gp + q.o_nw, q.nw * gOut);
-            if (q.o_ne >= 0) atomic_add_global(gp + q.o_ne, q.ne * gOut);
-            if (q.o_sw >= 0) atomic_add_global(gp + q.o_sw, q.sw * gOut);
-            if (q.o_se >= 0) atomic_add_global(gp + q.o_se, q.se * gOut);
+            if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * gOut);
+            if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * gOut);
+            if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * gOut);
+            if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gOut);
           }
           if (q.o_nw >= 0) {
             const T val = p[q.o_nw];
@@ -424,8 +465,8 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
         cubic_coeffs_grad(xg, cb.tx);
         cubic_coeffs_grad(yg, cb.ty);
         for (int c = 0; c < C; ++c) {
-          const T* p = inp + c * plane;
-          T* gp = ginp + c * plane;
+          const GlobalPtr<const T> p = inp + c * plane;
+          const GlobalPtr<T> gp = ginp + c * plane;
           const T gOut = gout_px[int64_t(c) * HW] * alpha;
 #pragma unroll
           for (int i2 = 0; i2 < 4; ++i2) {
@@ -433,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
             for (int j2 = 0; j2 < 4; ++j2) {
               const bool ok = cb.xi[i2] >= 0 && cb.yi[j2] >= 0;
               const int o = ok ? cb.yi[j2] * w + cb.xi[i2] : 0;
-              if (ok && gOut != T(0)) atomic_add_global(gp + o, gOut * xc[i2] * yc[j2]);
+              if (ok && gOut != T(0)) atomic_add_g1(gp + o, gOut * xc[i2] * yc[j2]);
               const T val = ok ? p[o] : T(0);
               gix -= gOut * val * (xg[i2] * yc[j2]);
               giy -= gOut * val * (yg[j2] * xc[i2]);
