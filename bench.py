@@ -71,7 +71,7 @@ OP_KERNELS = {
     "edge_grad_backward": ["edge_dots_kernel", "edge_gather"],
     "edge_grad_backward_fused": ["edge_dots_kernel", "edge_scatter4_kernel"],
     "interpolate_backward_vpix": ["interpolate_backward_kernel<float, true, false"],
-    "interpolate_backward": ["interpolate_backward_kernel<float, true, true"],
+    "interpolate_backward": ["interpolate_backward_wide_kernel<float>", "interpolate_backward_kernel<float, true, true, 4, 16>"],
     "render_backward": ["render_backward_kernel"],
 }
 
