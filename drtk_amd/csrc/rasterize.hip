@@ -31,6 +31,7 @@ namespace drtk_amd {
 namespace {
 
 constexpr uint32_t kCulled = 0xFFFFFFFFu;
+constexpr uint32_t kFacingBit = 0x80000000u; // in tri_range.y: triangle has positive orientation (den > 0)
 constexpr int kMaxSmallTiles = 4; // bins hold at most this many entries per triangle
 
 // Exact per-triangle setup (rasterize_kernel.cu:73-113,133-141).
@@ -42,6 +43,7 @@ struct TriSetup {
   int bb_min_x, bb_min_y, bb_max_x, bb_max_y;
   bool c0, c1, c2;    // canonical edge orientation flags (vi_a <= vi_b)
   bool tl0, tl1, tl2; // top-left classification
+  uint32_t z_lo_bits; // f32 bits of a rigorous lower bound of every depth this triangle can produce (0: none)
 };
 
 // Correctly rounded n / d for 0 <= n, d > 0 from a precomputed r = RN(1/d) (IEEE division, once per
@@ -112,7 +114,7 @@ __device__ __forceinline__ double exact_rcp(double x) {
 template <typename T>
 __device__ __forceinline__ bool tri_bbox(
     const T* __restrict__ v_n, const int32_t* __restrict__ vi_face, int H, int W, int& bx0,
-    int& by0, int& bx1, int& by1) {
+    int& by0, int& bx1, int& by1, bool& positive, float& z_mean) {
   const int32_t vi_0 = static_cast<int32_t>(static_cast<uint32_t>(vi_face[0]) & 0x0FFFFFFFu);
   const int32_t vi_1 = vi_face[1];
   const int32_t vi_2 = vi_face[2];
@@ -127,6 +129,8 @@ __device__ __forceinline__ bool tri_bbox(
   const T v01x = p1x - p0x, v01y = p1y - p0y, v02x = p2x - p0x, v02y = p2y - p0y;
   const T den = v01x * v02y - v01y * v02x;
   if (den == T(0)) return false;
+  positive = den > T(0);
+  z_mean = static_cast<float>((p0z + p1z + p2z) * T(1.0 / 3.0));
   bx0 = max(0, trunc_i32(min_x));
   by0 = max(0, trunc_i32(min_y));
   bx1 = min(W - 1, static_cast<int32_t>(static_cast<uint32_t>(trunc_i32(max_x)) + 1u));
@@ -176,6 +180,23 @@ __device__ __forceinline__ bool tri_setup(
   s.tl0 = pos ? (v12y < T(0) || (v12y == T(0) && v12x > T(0))) : (v12y > T(0) || (v12y == T(0) && v12x < T(0)));
   s.tl1 = pos ? (v02y > T(0) || (v02y == T(0) && v02x < T(0))) : (v02y < T(0) || (v02y == T(0) && v02x > T(0)));
   s.tl2 = pos ? (v01y < T(0) || (v01y == T(0) && v01x > T(0))) : (v01y > T(0) || (v01y == T(0) && v01x < T(0)));
+  // Hierarchical-z bound.  Exactly, depth = 1 / sum_k(b_k / z_k) with b_k >= 0, sum b_k = 1, so depth >= min z.
+  // As evaluated (:148-153) the b_k are rounded quotients of rounded edge functions and need not sum
+  // to one: each edge function and the denominator carry an absolute error <= 8 eps L^2 (L = extent of
+  // the triangle in pixels, +2 for the pixel itself), hence sum b_k <= 1 + 40 eps L^2 / |den|, and the
+  // three products, two additions, the reciprocal and the cast to float add < 1e-6 relative.
+  {
+    const T ext = (max_x - min_x > max_y - min_y ? max_x - min_x : max_y - min_y) + T(2);
+    const T eps = sizeof(T) == 4 ? T(5.97e-8) : T(1.12e-16);
+    const T delta = T(40) * eps * ext * ext / s.abs_denom + T(2e-6);
+    const T zmin = min3(p0z, p1z, p2z);
+    s.z_lo_bits = 0;
+    if (delta < T(0.25)) {
+      const float lo = static_cast<float>(zmin * (T(1) - delta));
+      const uint32_t bits = __float_as_uint(lo);
+      s.z_lo_bits = (lo > 0.0f && bits > 8u) ? bits - 8u : 0u; // 8 ulps below, against the rounding of `lo` itself
+    }
+  }
   return true;
 }
 
@@ -212,7 +233,7 @@ struct BinLayout {
   int tile_shift; // log2(tile size in pixels)
   int tiles_x, tiles_y;
   int64_t tiles_per_view, num_tiles; // per view / total
-  size_t off_count, off_cursor, off_big_count, off_queue, zero_bytes; // zero-filled prefix
+  size_t off_count, off_cursor, off_big_count, off_view_stats, off_queue, zero_bytes; // zero-filled prefix
   size_t off_offset, off_range, off_big_list, off_pairs, off_items, total_bytes;
   int64_t max_items;
 };
@@ -238,12 +259,14 @@ inline BinLayout make_layout(int64_t N, int64_t F, int64_t H, int64_t W) {
   L.tiles_per_view = int64_t(L.tiles_x) * L.tiles_y;
   L.num_tiles = N * L.tiles_per_view;
   size_t o = 0;
-  L.off_count = o;
-  o += align_up(sizeof(int32_t) * L.num_tiles, 256);
-  L.off_cursor = o;
-  o += align_up(sizeof(int32_t) * L.num_tiles, 256);
+  L.off_count = o; // per tile, packed: low word = list entries, high word = entries with positive orientation
+  o += align_up(sizeof(unsigned long long) * L.num_tiles, 256);
+  L.off_cursor = o; // per tile, packed fill cursors: low word = positive entries, high word = negative entries
+  o += align_up(sizeof(unsigned long long) * L.num_tiles, 256);
   L.off_big_count = o;
   o += align_up(sizeof(int32_t) * (N > 0 ? N : 1), 256);
+  L.off_view_stats = o; // per view: {sum z, count} of positively / negatively oriented triangles
+  o += align_up(sizeof(float) * 4 * (N > 0 ? N : 1), 256);
   L.off_queue = o; // [0] next work item, [1] number of work items
   o += 256;
   L.zero_bytes = o;
@@ -294,27 +317,93 @@ __device__ __forceinline__ int wave_agg_inc(int32_t* __restrict__ counters, int 
   return pos;
 }
 
+// Same aggregation on a pair of 32-bit counters packed in one 64-bit word: lanes with `hi` set bump the
+// high word, the others (or, with BOTH, every lane) the low word -- one atomic per distinct key and wave.
+//   count pass (BOTH):  low += lanes, high += lanes with hi        -> {entries, positive entries}
+//   fill pass (!BOTH):  low += lanes without hi, high += lanes with hi; returns this lane's slot in its
+//                       own word's sequence                        -> {positive cursor, negative cursor}
+template <bool BOTH, bool FETCH>
+__device__ __forceinline__ int wave_agg_inc2(unsigned long long* __restrict__ counters, int key, bool on, bool hi) {
+  const int lane = lane_id();
+  unsigned long long todo = __ballot(on);
+  int pos = 0;
+  while (todo) {
+    const int leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+    const int k = __builtin_amdgcn_readlane(key, leader);
+    const bool mine = on && key == k;
+    const unsigned long long same = __ballot(mine);
+    const unsigned long long same_hi = __ballot(mine && hi);
+    const unsigned long long same_lo = BOTH ? same : (same & ~same_hi);
+    unsigned long long base = 0;
+    if (lane == leader) {
+      const unsigned long long add =
+          static_cast<unsigned long long>(__popcll(same_lo)) | (static_cast<unsigned long long>(__popcll(same_hi)) << 32);
+      if (FETCH) {
+        base = atomicAdd(counters + k, add);
+      } else {
+        atomicAdd(counters + k, add);
+      }
+    }
+    if (FETCH) {
+      const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(base & 0xFFFFFFFFull), leader);
+      const unsigned hh = __builtin_amdgcn_readlane(static_cast<int>(base >> 32), leader);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (mine) pos = hi ? static_cast<int>(hh) + __popcll(same_hi & below) : static_cast<int>(lo) + __popcll(same_lo & below);
+    }
+    todo &= ~same;
+  }
+  return pos;
+}
+
 // ---- pass 1: cull, bbox -> tile range, count -------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bin_count_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN, int H,
-    int W, int tile_shift, int tiles_x, int tiles_per_view, int32_t* __restrict__ tile_count,
-    int32_t* __restrict__ big_count, int32_t* __restrict__ big_list, uint2* __restrict__ tri_range) {
+    int W, int tile_shift, int tiles_x, int tiles_per_view, unsigned long long* __restrict__ tile_count,
+    int32_t* __restrict__ big_count, int32_t* __restrict__ big_list,
+    uint2* __restrict__ tri_range, float* __restrict__ view_stats) {
   const int n = blockIdx.y;
   const int f = blockIdx.x * kBlock + threadIdx.x;
   const bool in_range = f < F;
   int bx0, by0, bx1, by1;
   uint2 r = make_uint2(kCulled, kCulled);
   int tx0 = 0, ty0 = 0, tw = 0, ntiles = 0;
+  bool positive = false;
+  float z_mean = 0.0f;
   if (in_range &&
-      tri_bbox<T>(v + int64_t(n) * V * 3, vi + int64_t(n) * vi_sN + int64_t(f) * 3, H, W, bx0, by0, bx1, by1)) {
+      tri_bbox<T>(v + int64_t(n) * V * 3, vi + int64_t(n) * vi_sN + int64_t(f) * 3, H, W, bx0, by0, bx1, by1, positive, z_mean)) {
     tx0 = bx0 >> tile_shift;
     ty0 = by0 >> tile_shift;
     const int tx1 = bx1 >> tile_shift, ty1 = by1 >> tile_shift;
     r.x = static_cast<uint32_t>(tx0) | (static_cast<uint32_t>(tx1) << 16);
-    r.y = static_cast<uint32_t>(ty0) | (static_cast<uint32_t>(ty1) << 16);
+    // tile coordinates are < 2^15: bit 31 of .y carries the orientation for the fill pass
+    r.y = static_cast<uint32_t>(ty0) | (static_cast<uint32_t>(ty1) << 16) | (positive ? kFacingBit : 0u);
     tw = tx1 - tx0 + 1;
     ntiles = tw * (ty1 - ty0 + 1);
+  }
+  // per-view mean depth of either orientation (decides which group the raster pass draws first); a
+  // 1-in-8 sample of the workgroups is plenty for that decision and keeps the four same-address
+  // atomics per view off the critical path
+  if ((blockIdx.x & 7) == 0) {
+    const bool live = ntiles >= 1;
+    float zp = (live && positive) ? z_mean : 0.0f, zn = (live && !positive) ? z_mean : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      zp += __shfl_xor(zp, o);
+      zn += __shfl_xor(zn, o);
+    }
+    const int cp = __popcll(__ballot(live && positive)), cn = __popcll(__ballot(live && !positive));
+    if (lane_id() == 0 && (cp | cn)) {
+      float* st = view_stats + 4 * n;
+      if (cp) {
+        atomic_add_global(st + 0, zp);
+        atomic_add_global(st + 1, static_cast<float>(cp));
+      }
+      if (cn) {
+        atomic_add_global(st + 2, zn);
+        atomic_add_global(st + 3, static_cast<float>(cn));
+      }
+    }
   }
   if (in_range) tri_range[int64_t(n) * F + f] = r;
   const bool small = ntiles >= 1 && ntiles <= kMaxSmallTiles;
@@ -323,7 +412,8 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(
     const bool on = small && s < ntiles;
     const int dy = on ? s / tw : 0;
     const int dx = on ? s - dy * tw : 0;
-    wave_agg_inc<false>(tile_count, base + (ty0 + dy) * tiles_x + tx0 + dx, on);
+    const int t = base + (ty0 + dy) * tiles_x + tx0 + dx;
+    wave_agg_inc2<true, false>(tile_count, t, on, positive);
   }
   const bool big = ntiles > kMaxSmallTiles;
   if (__ballot(big)) {
@@ -339,11 +429,12 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(
 // an atomic counter, so the pole / limb tiles of a mesh (10x the mean triangle count) no longer form
 // a serial tail.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(
-    const int32_t* __restrict__ tile_count, int32_t* __restrict__ tile_offset, int num_tiles,
+    const unsigned long long* __restrict__ tile_count64, int32_t* __restrict__ tile_offset, int num_tiles,
     int tile_shift, uint32_t* __restrict__ items, int32_t* __restrict__ queue) {
   __shared__ int32_t part[1024];
   __shared__ int32_t cls_count[4], cls_base[4];
   const int tid = threadIdx.x;
+  auto tile_count = [&](int i) { return static_cast<int32_t>(tile_count64[i] & 0xFFFFFFFFull); };
   const int chunk = (num_tiles + 1023) / 1024;
   const int begin = tid * chunk;
   const int end = min(begin + chunk, num_tiles);
@@ -354,7 +445,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
   };
   if (tid < 4) cls_count[tid] = 0;
   int32_t sum = 0;
-  for (int i = begin; i < end; ++i) sum += tile_count[i];
+  for (int i = begin; i < end; ++i) sum += tile_count(i);
   part[tid] = sum;
   __syncthreads();
   // Hillis-Steele inclusive scan over the 1024 partial sums
@@ -366,7 +457,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
   }
   int32_t run = part[tid] - sum; // exclusive prefix of this thread's chunk
   for (int i = begin; i < end; ++i) {
-    const int c = tile_count[i];
+    const int c = tile_count(i);
     tile_offset[i] = run;
     run += c;
     const int sl = split_log_of(c);
@@ -385,7 +476,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
   }
   __syncthreads();
   for (int i = begin; i < end; ++i) {
-    const int c = tile_count[i];
+    const int c = tile_count(i);
     const int sl = split_log_of(c);
     const int cls = c == 0 ? 3 : 2 - sl;
     const int n_sub = 1 << (2 * sl);
@@ -397,18 +488,20 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
 // ---- pass 3: write triangle ids into the tile lists -----------------------------------------
 __global__ __launch_bounds__(kBlock) void bin_fill_kernel(
     const uint2* __restrict__ tri_range, int F, int tiles_x, int tiles_per_view,
-    const int32_t* __restrict__ tile_offset, int32_t* __restrict__ tile_cursor,
+    const int32_t* __restrict__ tile_offset, unsigned long long* __restrict__ tile_cursor,
     int32_t* __restrict__ pairs) {
   const int n = blockIdx.y;
   const int f = blockIdx.x * kBlock + threadIdx.x;
   int tx0 = 0, ty0 = 0, tw = 0, ntiles = 0;
+  bool positive = false;
   if (f < F) {
     const uint2 r = tri_range[int64_t(n) * F + f];
     if (r.x != kCulled) {
       tx0 = r.x & 0xFFFF;
       ty0 = r.y & 0xFFFF;
       tw = static_cast<int>(r.x >> 16) - tx0 + 1;
-      ntiles = tw * (static_cast<int>(r.y >> 16) - ty0 + 1);
+      ntiles = tw * (static_cast<int>((r.y & ~kFacingBit) >> 16) - ty0 + 1);
+      positive = (r.y & kFacingBit) != 0;
     }
   }
   const bool small = ntiles >= 1 && ntiles <= kMaxSmallTiles;
@@ -418,8 +511,8 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(
     const int dy = on ? s / tw : 0;
     const int dx = on ? s - dy * tw : 0;
     const int t = base + (ty0 + dy) * tiles_x + tx0 + dx;
-    const int pos = wave_agg_inc<true>(tile_cursor, t, on);
-    if (on) pairs[tile_offset[t] + pos] = f;
+    const int pos = wave_agg_inc2<false, true>(tile_cursor, t, on, !positive); // low: positive, high: negative
+    if (on) pairs[positive ? tile_offset[t] + pos : tile_offset[t + 1] - 1 - pos] = f;
   }
 }
 
@@ -539,6 +632,7 @@ template <typename T, int TILE_SHIFT>
 __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN,
     int H, int W, int tiles_x, int tiles_per_view, const int32_t* __restrict__ tile_offset,
+    const unsigned long long* __restrict__ tile_count, const float* __restrict__ view_stats,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ big_count,
     const int32_t* __restrict__ big_list, const uint2* __restrict__ tri_range,
     const uint32_t* __restrict__ items, int32_t* __restrict__ queue, float* __restrict__ depth_img,
@@ -546,6 +640,7 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
   constexpr int TILE = 1 << TILE_SHIFT;
   constexpr int NPIX = TILE * TILE;
   __shared__ unsigned long long zbuf[NPIX];
+  __shared__ uint32_t s_zmax[(TILE / 8) * (TILE / 8)];
   __shared__ int s_item;
 
   const int tid = threadIdx.x;
@@ -567,52 +662,90 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
     const int x1 = min(x0 + ss - 1, W - 1), y1 = min(y0 + ss - 1, H - 1);
     if (x0 < W && y0 < H) {
       const int rows = y1 - y0 + 1;
-      for (int i = tid; i < (rows << TILE_SHIFT); i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
+      for (int i = tid; i < (ss << TILE_SHIFT); i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
       __syncthreads();
 
       const T* v_n = v + int64_t(n) * V * 3;
       const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+      const int wave = tid / kWave, lane = tid & (kWave - 1);
+      const int nb = ss >> 3; // 8x8-pixel blocks per side of this item's rectangle
 
-      // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively
-      // the list is cut into 4 equal parts, one per wave, so that the waves reach the barrier together
+      // The tile's list is partitioned by orientation (bin_fill): [positive ... | ... negative].  The
+      // group that is nearer on average in this view (on a closed mesh: the visible one) is drawn first;
+      // then the farthest depth of every 8x8 block is known (empty pixels count as infinitely far), and
+      // a triangle of the second group whose depth lower bound lies beyond the farthest depth of all
+      // blocks its clipped bbox touches cannot win a single pixel -- (depth, id) only ever decreases --
+      // so it is dropped before any fragment work.  On a closed mesh that removes the hidden half of
+      // the triangles; on any input the image is unchanged (strict comparison: ties still go by id).
       const int begin = tile_offset[tile], end_all = tile_offset[tile + 1];
-      const int per_wave = (end_all - begin + kRasterBlock / kWave - 1) / (kRasterBlock / kWave);
-      const int wave_begin = begin + (tid / kWave) * per_wave;
-      const int end = min(wave_begin + per_wave, end_all);
-      for (int i0 = wave_begin; i0 < end; i0 += kWave) {
-        const int i = i0 + (tid & (kWave - 1));
-        int f = 0;
-        bool valid = false;
-        TriSetup<T> s = {};
-        if (i < end && !(dbg & 8)) {
-          f = pairs[i];
-          valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
-          valid = valid && s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0;
-        }
-        if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
-      }
-
-      // big triangles (more than kMaxSmallTiles tiles): per-view list, filtered by tile range
-      const int nbig = big_count[n];
-      const int32_t* big_n = big_list + int64_t(n) * F;
-      const uint2* range_n = tri_range + int64_t(n) * F;
-      const int big_per_wave = (nbig + kRasterBlock / kWave - 1) / (kRasterBlock / kWave);
-      const int big_begin = (tid / kWave) * big_per_wave, big_end = min(big_begin + big_per_wave, nbig);
-      for (int i0 = big_begin; i0 < big_end; i0 += kWave) {
-        const int i = i0 + (tid & (kWave - 1));
-        int f = 0;
-        bool valid = false;
-        TriSetup<T> s = {};
-        if (i < big_end) {
-          f = big_n[i];
-          const uint2 r = range_n[f];
-          const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = r.y >> 16;
-          if (tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1) {
+      const int n_pos = static_cast<int>(tile_count[tile] >> 32);
+      const float* st = view_stats + 4 * n;
+      const bool pos_first = st[0] * st[3] <= st[2] * st[1]; // mean z of positive <= mean z of negative
+      for (int phase = 0; phase < 2; ++phase) {
+        const bool take_pos = (phase == 0) == pos_first;
+        const int g_begin = take_pos ? begin : begin + n_pos, g_end = take_pos ? begin + n_pos : end_all;
+        auto accept = [&](const TriSetup<T>& s) -> bool {
+          if (!(s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0)) return false;
+          if (phase == 0 || s.z_lo_bits == 0 || (dbg & 16)) return true;
+          const int cx0 = (max(s.bb_min_x, x0) - x0) >> 3, cx1 = (min(s.bb_max_x, x1) - x0) >> 3;
+          const int cy0 = (max(s.bb_min_y, y0) - y0) >> 3, cy1 = (min(s.bb_max_y, y1) - y0) >> 3;
+          if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 16) return true;
+          uint32_t far = 0;
+          for (int by = cy0; by <= cy1; ++by)
+            for (int bx = cx0; bx <= cx1; ++bx) far = max(far, s_zmax[by * nb + bx]);
+          return !(s.z_lo_bits > far);
+        };
+        // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively;
+        // the group is cut into equal parts, one per wave, so that the waves reach the barrier together
+        const int per_wave = (g_end - g_begin + kRasterBlock / kWave - 1) / (kRasterBlock / kWave);
+        const int wave_begin = g_begin + wave * per_wave;
+        const int end = min(wave_begin + per_wave, g_end);
+        for (int i0 = wave_begin; i0 < end; i0 += kWave) {
+          const int i = i0 + lane;
+          int f = 0;
+          bool valid = false;
+          TriSetup<T> s = {};
+          if (i < end && !(dbg & 8)) {
+            f = pairs[i];
             valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
-            valid = valid && s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0;
+            valid = valid && accept(s);
           }
+          if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
         }
-        if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
+        if (phase == 1) break;
+
+        // big triangles (more than kMaxSmallTiles tiles): per-view list, filtered by tile range; drawn
+        // with the first group whatever their orientation
+        const int nbig = big_count[n];
+        const int32_t* big_n = big_list + int64_t(n) * F;
+        const uint2* range_n = tri_range + int64_t(n) * F;
+        const int big_per_wave = (nbig + kRasterBlock / kWave - 1) / (kRasterBlock / kWave);
+        const int big_begin = wave * big_per_wave, big_end = min(big_begin + big_per_wave, nbig);
+        for (int i0 = big_begin; i0 < big_end; i0 += kWave) {
+          const int i = i0 + lane;
+          int f = 0;
+          bool valid = false;
+          TriSetup<T> s = {};
+          if (i < big_end) {
+            f = big_n[i];
+            const uint2 r = range_n[f];
+            const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = (r.y & ~kFacingBit) >> 16;
+            if (tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1) {
+              valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
+              valid = valid && accept(s);
+            }
+          }
+          if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
+        }
+        __syncthreads();
+        for (int bi = wave; bi < nb * nb; bi += kRasterBlock / kWave) {
+          const int bx = bi % nb, by = bi / nb;
+          uint32_t m = static_cast<uint32_t>(zbuf[(((by << 3) + (lane >> 3)) << TILE_SHIFT) + (bx << 3) + (lane & 7)] >> 32);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) m = max(m, static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), o)));
+          if (lane == 0) s_zmax[bi] = m;
+        }
+        __syncthreads();
       }
       __syncthreads();
 
@@ -710,8 +843,9 @@ int rasterize_impl(
   if (workspace_bytes < L.total_bytes) return DRTK_ERR_WORKSPACE_TOO_SMALL;
   if (N * H * W == 0) return DRTK_OK;
   char* ws = static_cast<char*>(workspace);
-  auto* tile_count = reinterpret_cast<int32_t*>(ws + L.off_count);
-  auto* tile_cursor = reinterpret_cast<int32_t*>(ws + L.off_cursor);
+  auto* tile_count = reinterpret_cast<unsigned long long*>(ws + L.off_count);
+  auto* tile_cursor = reinterpret_cast<unsigned long long*>(ws + L.off_cursor);
+  auto* view_stats = reinterpret_cast<float*>(ws + L.off_view_stats);
   auto* big_count = reinterpret_cast<int32_t*>(ws + L.off_big_count);
   auto* tile_offset = reinterpret_cast<int32_t*>(ws + L.off_offset);
   auto* tri_range = reinterpret_cast<uint2*>(ws + L.off_range);
@@ -727,7 +861,7 @@ int rasterize_impl(
     hipLaunchKernelGGL(
         bin_count_kernel<T>, tri_grid, dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN, (int)H,
         (int)W, L.tile_shift, L.tiles_x, (int)L.tiles_per_view, tile_count, big_count, big_list,
-        tri_range);
+        tri_range, view_stats);
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   hipLaunchKernelGGL(
@@ -746,13 +880,13 @@ int rasterize_impl(
   if (L.tile_shift == 6) {
     hipLaunchKernelGGL(
         (tile_raster_kernel<T, 6>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
-        (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, pairs, big_count, big_list,
-        tri_range, items, queue, depth_img, index_img, debug_flags());
+        (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,
+        big_list, tri_range, items, queue, depth_img, index_img, debug_flags());
   } else {
     hipLaunchKernelGGL(
         (tile_raster_kernel<T, 5>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
-        (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, pairs, big_count, big_list,
-        tri_range, items, queue, depth_img, index_img, debug_flags());
+        (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,
+        big_list, tri_range, items, queue, depth_img, index_img, debug_flags());
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
