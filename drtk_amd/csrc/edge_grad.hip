@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void edge_scatter4_kernel(
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kRows = 4;
-  __shared__ uint16_t s_list[kWaves][kWave * 4];
+  __shared__ uint16_t s_list[kWaves][kWave * 4 * 4]; // kRows rows of 256 pixels
   __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
   __shared__ int32_t s_vid[kWaves][3 * kRunPad];
   __shared__ int32_t s_slot[kWaves][3 * kRunPad];
@@ -523,103 +523,105 @@ __global__ __launch_bounds__(kBlock) void edge_scatter4_kernel(
   wave_lds_sync();
 
   const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll 1
+  // index rows y_base-1 .. y_base+kRows of this lane's 4 pixels, fetched in one batch (each row serves
+  // as centre, as "up" of the row below and as "down" of the row above)
+  int32_t row[kRows + 2][4];
+#pragma unroll
+  for (int r = 0; r < kRows + 2; ++r) {
+    const int y = y_base - 1 + r;
+    if (in_x && y >= 0 && y < H) {
+      const int4 q = *reinterpret_cast<const int4*>(idx_n + int64_t(y) * W + x0);
+      row[r][0] = q.x, row[r][1] = q.y, row[r][2] = q.z, row[r][3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) row[r][j] = -1;
+    }
+  }
+  // edge flags (same stencil domain as edge_gather4_kernel) and pixel-ordered compaction of the whole
+  // 256 x 4 tile: entry = row << 8 | local x, ordered by row then x, so runs of one triangle stay
+  // contiguous and the compacted lanes are ~97 % full instead of ~72 % with one list per row
+  int total = 0;
+#pragma unroll
   for (int r = 0; r < kRows; ++r) {
     const int y = y_base + r;
-    if (y >= H) break;
-    const int64_t pix0 = int64_t(y) * W + x0;
-    int32_t c[4] = {-1, -1, -1, -1}, u[4], d[4];
-    if (in_x) {
-      const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0);
-      c[0] = q.x, c[1] = q.y, c[2] = q.z, c[3] = q.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) u[j] = d[j] = c[j];
-    if (in_x && y >= 1) {
-      const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0 - W);
-      u[0] = q.x, u[1] = q.y, u[2] = q.z, u[3] = q.w;
-    }
-    if (in_x && y < H - 1) {
-      const int4 q = *reinterpret_cast<const int4*>(idx_n + pix0 + W);
-      d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w;
-    }
+    const bool y_ok = y < H; // wave-uniform
+    const int32_t* c = row[r + 1];
     int32_t lprev = __shfl_up(c[3], 1), rnext = __shfl_down(c[0], 1);
-    if (in_x && lane == 0 && x0 >= 1) lprev = idx_n[pix0 - 1];
-    if (in_x && lane == kWave - 1 && x0 + 4 < W) rnext = idx_n[pix0 + 4];
-
-    // edge flags (same stencil domain as edge_gather4_kernel) and pixel-ordered compaction
+    if (y_ok && in_x && lane == 0 && x0 >= 1) lprev = idx_n[int64_t(y) * W + x0 - 1];
+    if (y_ok && in_x && lane == kWave - 1 && x0 + 4 < W) rnext = idx_n[int64_t(y) * W + x0 + 4];
     bool e[4];
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int x = x0 + j;
-      const bool own = in_x && (x < W - 1) && (y < H - 1);
-      const bool left = in_x && (x >= 1) && (y < H - 1);
-      const bool up = in_x && (y >= 1) && (x < W - 1);
+      const bool own = y_ok && in_x && (x < W - 1) && (y < H - 1);
+      const bool left = y_ok && in_x && (x >= 1) && (y < H - 1);
+      const bool up = y_ok && in_x && (y >= 1) && (x < W - 1);
       const int32_t nr = own ? (j < 3 ? c[(j + 1) & 3] : rnext) : c[j];
-      const int32_t nd = own ? d[j] : c[j];
+      const int32_t nd = own ? row[r + 2][j] : c[j];
       const int32_t nl = left ? (j > 0 ? c[(j + 3) & 3] : lprev) : c[j];
-      const int32_t nu = up ? u[j] : c[j];
-      e[j] = c[j] != nr || c[j] != nd || c[j] != nl || c[j] != nu;
+      const int32_t nu = up ? row[r][j] : c[j];
+      e[j] = y_ok && (c[j] != nr || c[j] != nd || c[j] != nl || c[j] != nu);
       cnt += e[j] ? 1 : 0;
     }
     // exclusive prefix of cnt (0..4) over the lanes from three ballots
     const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
-    int pos = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-    const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    int pos = total + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+    total += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (e[j]) s_list[wave][pos++] = static_cast<uint16_t>(lane * 4 + j);
+      if (e[j]) s_list[wave][pos++] = static_cast<uint16_t>((r << 8) | (lane * 4 + j));
+    }
+  }
+  wave_lds_sync();
+
+  for (int t0 = 0; t0 < total; t0 += kWave) {
+    const int t = t0 + lane;
+    const bool act = t < total;
+    int32_t ic = -1;
+    T g[3] = {T(0), T(0), T(0)};
+    T B[3] = {T(0), T(0), T(0)};
+    int32_t vid[3] = {0, 0, 0};
+    if (act) {
+      const int entry = s_list[wave][t];
+      const int y = y_base + (entry >> 8);
+      const int px = sx * (kWave * 4) + (entry & 255);
+      const int64_t pix = int64_t(y) * W + px;
+      ic = idx_n[pix];
+      if (ic >= 0) { // background pixels never receive a gradient
+        const bool own = (px < W - 1) && (y < H - 1);
+        const bool left = (px >= 1) && (y < H - 1);
+        const bool up = (y >= 1) && (px < W - 1);
+        const int32_t ir = own ? idx_n[pix + 1] : ic;
+        const int32_t id = own ? idx_n[pix + W] : ic;
+        const int32_t il = left ? idx_n[pix - 1] : ic;
+        const int32_t iu = up ? idx_n[pix - W] : ic;
+        edge_pixel<T>(v_n, vi_n, gdx_n, gdy_n, pix, px, y, W, ic, ir, id, il, iu, M, g[0], g[1], g[2], vid);
+        B[0] = bary_n[pix], B[1] = bary_n[HW + pix], B[2] = bary_n[2 * HW + pix];
+      }
+    }
+    const bool covered = ic >= 0;
+    const bool use_table = covered && vid[0] != vid[1] && vid[0] != vid[2] && vid[1] != vid[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) s_val[wave][(k * 3 + cc) * kRunPad + lane] = g[cc] * B[k];
+      s_vid[wave][k * kRunPad + lane] = vid[k];
+      s_slot[wave][k * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid[k]) : -1;
+    }
+    unsigned long long heads, cov;
+    run_masks(covered ? ic : -1, heads, cov);
+    wave_lds_sync();
+    if (cov != 0) {
+      const T* sv = s_val[wave];
+      scatter_runs<T>(
+          heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals[wave], 4, grad_n, 3, 0,
+          [sv](int k, int cc, int g4, T* x) {
+            const V4 q = *reinterpret_cast<const V4*>(sv + (k * 3 + cc) * kRunPad + 4 * g4);
+            x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
+          });
     }
     wave_lds_sync();
-
-    for (int t0 = 0; t0 < total; t0 += kWave) {
-      const int t = t0 + lane;
-      const bool act = t < total;
-      int32_t ic = -1;
-      T g[3] = {T(0), T(0), T(0)};
-      T B[3] = {T(0), T(0), T(0)};
-      int32_t vid[3] = {0, 0, 0};
-      if (act) {
-        const int local = s_list[wave][t];
-        const int px = sx * (kWave * 4) + local;
-        const int64_t pix = int64_t(y) * W + px;
-        ic = idx_n[pix];
-        if (ic >= 0) { // background pixels never receive a gradient
-          const bool own = (px < W - 1) && (y < H - 1);
-          const bool left = (px >= 1) && (y < H - 1);
-          const bool up = (y >= 1) && (px < W - 1);
-          const int32_t ir = own ? idx_n[pix + 1] : ic;
-          const int32_t id = own ? idx_n[pix + W] : ic;
-          const int32_t il = left ? idx_n[pix - 1] : ic;
-          const int32_t iu = up ? idx_n[pix - W] : ic;
-          edge_pixel<T>(v_n, vi_n, gdx_n, gdy_n, pix, px, y, W, ic, ir, id, il, iu, M, g[0], g[1], g[2], vid);
-          B[0] = bary_n[pix], B[1] = bary_n[HW + pix], B[2] = bary_n[2 * HW + pix];
-        }
-      }
-      const bool covered = ic >= 0;
-      const bool use_table = covered && vid[0] != vid[1] && vid[0] != vid[2] && vid[1] != vid[2];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) s_val[wave][(k * 3 + cc) * kRunPad + lane] = g[cc] * B[k];
-        s_vid[wave][k * kRunPad + lane] = vid[k];
-        s_slot[wave][k * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid[k]) : -1;
-      }
-      unsigned long long heads, cov;
-      run_masks(covered ? ic : -1, heads, cov);
-      wave_lds_sync();
-      if (cov != 0) {
-        const T* sv = s_val[wave];
-        scatter_runs<T>(
-            heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals[wave], 4, grad_n, 3, 0,
-            [sv](int k, int cc, int g4, T* x) {
-              const V4 q = *reinterpret_cast<const V4*>(sv + (k * 3 + cc) * kRunPad + 4 * g4);
-              x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
-            });
-      }
-      wave_lds_sync();
-    }
   }
   table_flush<T>(t_keys[wave], t_vals[wave], 4, 3, grad_n, 3, 0);
 }
