@@ -71,8 +71,8 @@ __device__ __forceinline__ Row<T, VEC> load_row(
 // ascending order (edge_grad_kernel.cu:353-380).
 template <typename T, int VEC, int R, int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
-    const T* __restrict__ img, const T* __restrict__ grad_output, int C, int H, int W,
-    int strips_x, T* __restrict__ gdx, T* __restrict__ gdy) {
+    const T* __restrict__ img, const T* __restrict__ grad_output, const int32_t* __restrict__ index_img, int C,
+    int H, int W, int strips_x, T* __restrict__ gdx, T* __restrict__ gdy) {
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
   const int by = blockIdx.x / strips_x, sx = blockIdx.x - by * strips_x;
@@ -80,9 +80,41 @@ __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
   const int y0 = (by * WAVES + threadIdx.x / kWave) * R;
   if (y0 >= H) return;
   const int x = (sx * kWave + lane) * VEC;
-  const bool x_ok = x < W;
   const T* img_n = img + int64_t(n) * C * HW;
   const T* go_n = grad_output + int64_t(n) * C * HW;
+
+  // Pair terms are only ever read where the triangle index changes, and a pair of two background
+  // pixels never does: a lane whose pixels, their left / right neighbours and the halo row are all
+  // background neither loads nor stores anything (its part of the workspace is never read), so the
+  // background of the image costs 4 B/px of index instead of 8C B/px of img + grad_output.
+  bool any_fg = false;
+  {
+    const int32_t* idx_n = index_img + int64_t(n) * HW;
+#pragma unroll
+    for (int r = 0; r <= R; ++r) {
+      const int y = y0 + r;
+      if (y < H) { // wave-uniform
+        bool fg = false;
+        int32_t first = -1, last = -1;
+        if (x < W) {
+          if constexpr (VEC == 4) {
+            const int4 q = *reinterpret_cast<const int4*>(idx_n + int64_t(y) * W + x);
+            fg = (q.x & q.y & q.z & q.w) != -1;
+            first = q.x, last = q.w;
+          } else {
+            first = last = idx_n[int64_t(y) * W + x];
+            fg = first != -1;
+          }
+        }
+        int32_t left = __shfl_up(last, 1), right = __shfl_down(first, 1);
+        if (lane == 0) left = (x >= 1 && x < W) ? idx_n[int64_t(y) * W + x - 1] : -1;
+        if (lane == kWave - 1) right = (x + VEC < W) ? idx_n[int64_t(y) * W + x + VEC] : -1;
+        any_fg = any_fg || fg || left != -1 || right != -1;
+      }
+    }
+  }
+  if (__ballot(any_fg) == 0) return;
+  const bool x_ok = x < W && any_fg;
 
   T ax[R][VEC], ay[R][VEC];
 #pragma unroll
@@ -640,15 +672,16 @@ int edge_grad_backward_impl(
   T* gdy = gdx + N * HW;
   const bool vec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(img) % (4 * sizeof(T)) == 0) &&
       (reinterpret_cast<uintptr_t>(grad_output) % (4 * sizeof(T)) == 0) &&
-      (reinterpret_cast<uintptr_t>(workspace) % (4 * sizeof(T)) == 0);
+      (reinterpret_cast<uintptr_t>(workspace) % (4 * sizeof(T)) == 0) &&
+      (reinterpret_cast<uintptr_t>(index_img) % 16 == 0);
   const int px_per_wave = kWave * (vec ? 4 : 1);
   const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
   if (vec) {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
   } else {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   const bool vec_out = vec && (reinterpret_cast<uintptr_t>(index_img) % 16 == 0) &&
@@ -666,15 +699,15 @@ int edge_grad_backward_impl(
 
 // pass A shared by both routes
 template <typename T>
-int launch_edge_dots(const T* img, const T* grad_output, int64_t N, int64_t C, int64_t H, int64_t W, T* gdx, T* gdy, bool vec, hipStream_t stream) {
+int launch_edge_dots(const T* img, const T* grad_output, const int32_t* index_img, int64_t N, int64_t C, int64_t H, int64_t W, T* gdx, T* gdy, bool vec, hipStream_t stream) {
   const int px_per_wave = kWave * (vec ? 4 : 1);
   const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
   if (vec) {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
   } else {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
@@ -700,7 +733,7 @@ int edge_grad_backward_fused_impl(
   T* gdx = static_cast<T*>(workspace);
   T* gdy = gdx + N * HW;
   if (fused_vec_ok<T>(img, grad_output, index_img, workspace, W)) {
-    const int st = launch_edge_dots<T>(img, grad_output, N, C, H, W, gdx, gdy, true, stream);
+    const int st = launch_edge_dots<T>(img, grad_output, index_img, N, C, H, W, gdx, gdy, true, stream);
     if (st != DRTK_OK) return st;
     const int strips_x = static_cast<int>(ceil_div(W, kWave * 4));
     const int64_t waves = int64_t(strips_x) * ceil_div(H, 4);
