@@ -19,7 +19,7 @@ INC = os.path.join(ROOT, "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-KERNEL_SRCS = ["rasterize.hip", "render.hip", "interpolate.hip", "edge_grad.hip", "transform.hip", "interp_matrix.hip", "mipmap.hip", "uv_derivative.hip", "capi.hip"]
+KERNEL_SRCS = ["rasterize.hip", "rasterize_lines.hip", "render.hip", "interpolate.hip", "edge_grad.hip", "transform.hip", "interp_matrix.hip", "mipmap.hip", "uv_derivative.hip", "capi.hip"]
 HEADERS = ["common.hpp", "segscatter.hpp"]
 LIB = os.path.join(PKG, "libdrtk_amd.so")
 OPS = os.path.join(PKG, "drtk_amd_torch_ops.so")

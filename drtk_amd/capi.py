@@ -39,6 +39,7 @@ EXPORTS = [
     "drtk_amd_status_string",
     "drtk_amd_version",
     "drtk_amd_rasterize_workspace_bytes",
+    "drtk_amd_rasterize_lines_workspace_bytes",
     "drtk_amd_rasterize",
     "drtk_amd_render",
     "drtk_amd_render_backward",
@@ -112,18 +113,25 @@ def rasterize_workspace_bytes(N, F, H, W) -> int:
     return out.value
 
 
-def rasterize(v, vi, height, width, stream=None, workspace=None) -> Tuple[th.Tensor, th.Tensor]:
+def rasterize_lines_workspace_bytes(N, H, W) -> int:
+    out = ctypes.c_size_t(0)
+    _check(lib().drtk_amd_rasterize_lines_workspace_bytes(_i(N), _i(H), _i(W), ctypes.byref(out)), "rasterize")
+    return out.value
+
+
+def rasterize(v, vi, height, width, stream=None, workspace=None, wireframe=False) -> Tuple[th.Tensor, th.Tensor]:
     v = v.contiguous()
     N, V, _ = v.shape
     vi_c, vi_sN, F = _vi(vi, N)
     depth = th.empty(N, height, width, dtype=th.float32, device=v.device)
     index = th.empty(N, height, width, dtype=th.int32, device=v.device)
-    nbytes = rasterize_workspace_bytes(N, F, height, width)
+    nbytes = rasterize_lines_workspace_bytes(N, height, width) if wireframe else rasterize_workspace_bytes(N, F, height, width)
     ws = workspace if workspace is not None else th.empty(nbytes, dtype=th.uint8, device=v.device)
     _check(
         lib().drtk_amd_rasterize(
             ctypes.c_int(_dt(v)), _p(v), _p(vi_c), _i(N), _i(V), _i(F), _i(vi_sN), _i(height), _i(width),
-            ctypes.c_int(0), _p(depth), _p(index), _p(ws), ctypes.c_size_t(ws.numel()), _stream(v, stream)),
+            ctypes.c_int(1 if wireframe else 0), _p(depth), _p(index), _p(ws), ctypes.c_size_t(ws.numel()),
+            _stream(v, stream)),
         "rasterize")
     return depth, index
 

@@ -895,6 +895,11 @@ int rasterize_impl(
 } // namespace
 } // namespace drtk_amd
 
+namespace drtk_amd {
+int rasterize_lines_dispatch( // rasterize_lines.hip
+    drtk_dtype_t dtype, const void* v, const int32_t* vi, int64_t N, int64_t V, int64_t F, int64_t vi_sN, int64_t H,
+    int64_t W, float* depth_img, int32_t* index_img, void* workspace, size_t workspace_bytes, hipStream_t stream);
+}
 using namespace drtk_amd;
 
 extern "C" int drtk_amd_rasterize_workspace_bytes(
@@ -910,7 +915,13 @@ extern "C" int drtk_amd_rasterize(
     void* workspace, size_t workspace_bytes, drtk_stream_t stream) {
   if (N < 0 || V < 0 || F < 0 || H <= 0 || W <= 0) return DRTK_ERR_INVALID_ARGUMENT; // :464-468
   if (V >= 0x10000000LL) return DRTK_ERR_TOO_MANY_VERTICES;                           // :459-462
-  if (wireframe) return DRTK_ERR_UNSUPPORTED;
+  if (wireframe) {
+    if (N > 65535 || N * H * W >= (int64_t(1) << 40) || (dtype != DRTK_F32 && dtype != DRTK_F64)) return DRTK_ERR_INVALID_ARGUMENT;
+    if (N * H * W > 0 && (!depth_img || !index_img)) return DRTK_ERR_INVALID_ARGUMENT;
+    if (N * F > 0 && (!v || !vi)) return DRTK_ERR_INVALID_ARGUMENT;
+    if (vi_sN != 0 && vi_sN != F * 3) return DRTK_ERR_INVALID_ARGUMENT;
+    return rasterize_lines_dispatch(dtype, v, vi, N, V, F, vi_sN, H, W, depth_img, index_img, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  }
   if (N > 65535 || H > 65535LL * 32 || W > 65535LL * 32 || N * F >= (int64_t(1) << 31) / kMaxSmallTiles ||
       N * H * W >= (int64_t(1) << 40))
     return DRTK_ERR_INVALID_ARGUMENT;

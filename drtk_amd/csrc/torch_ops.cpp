@@ -113,7 +113,6 @@ std::vector<Tensor> rasterize_hip(
   TORCH_CHECK(
       height > 0 && width > 0,
       "rasterize(): both height and width must be > 0, but got height: ", height, ", width: ", width);
-  TORCH_CHECK(!wireframe, "rasterize(): wireframe mode is not implemented by drtk_amd yet");
   const drtk_dtype_t dt = dtype_of(v, "rasterize");
 
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
@@ -123,11 +122,14 @@ std::vector<Tensor> rasterize_hip(
   auto depth_img = at::empty({N, height, width}, v.options().dtype(at::kFloat));
   auto index_img = at::empty({N, height, width}, v.options().dtype(at::kInt));
   size_t ws_bytes = 0;
-  check_status(drtk_amd_rasterize_workspace_bytes(N, F, height, width, &ws_bytes), "rasterize");
+  check_status(
+      wireframe ? drtk_amd_rasterize_lines_workspace_bytes(N, height, width, &ws_bytes)
+                : drtk_amd_rasterize_workspace_bytes(N, F, height, width, &ws_bytes),
+      "rasterize");
   auto ws = alloc_workspace(ws_bytes, v);
   check_status(
       drtk_amd_rasterize(
-          dt, v_c.data_ptr(), via.ptr, N, V, F, via.sN, height, width, 0, depth_img.data_ptr<float>(),
+          dt, v_c.data_ptr(), via.ptr, N, V, F, via.sN, height, width, wireframe ? 1 : 0, depth_img.data_ptr<float>(),
           index_img.data_ptr<int32_t>(), ws.data_ptr(), ws_bytes, current_stream(v)),
       "rasterize");
   return {depth_img, index_img};

@@ -28,9 +28,11 @@ def rasterize(
             coordinates, the image spans `[-0.5, width-0.5] x [-0.5, height-0.5]`), z = camera
             space depth.  float32 or float64.
         vi: `[F, 3]` or `[N, F, 3]` int32 triangle list.  The top nibble of `vi[..., 0]` is
-            ignored (it carries edge-visibility bits for wireframe mode in the reference).
+            ignored in triangle mode; in wireframe mode its bits 0..2 switch the edges
+            (v0,v1), (v1,v2), (v0,v2) on (which limits the vertex count to 268435455).
         height, width: image size in pixels.
-        wireframe: not implemented by drtk_amd (raises).
+        wireframe: rasterize the enabled edges (diamond-exit rule) instead of the triangles; the
+            triangles still occlude, with index -1.
 
     Returns:
         `index_img [N, H, W]` int32: id of the nearest triangle covering each pixel centre, `-1`

@@ -44,7 +44,7 @@ typedef enum {
   DRTK_ERR_INVALID_ARGUMENT = -1, /* bad size / null pointer / unknown dtype */
   DRTK_ERR_WORKSPACE_TOO_SMALL = -2,
   DRTK_ERR_LAUNCH = -3,       /* hipGetLastError() after a launch was not hipSuccess */
-  DRTK_ERR_UNSUPPORTED = -4,  /* e.g. wireframe rasterization */
+  DRTK_ERR_UNSUPPORTED = -4,  /* reserved */
   DRTK_ERR_TOO_MANY_VERTICES = -5 /* V >= 2^28, rasterize_kernel.cu:459-462 */
 } drtk_status_t;
 
@@ -60,9 +60,13 @@ const char* drtk_amd_version(void);
  * Z-buffer rasterization of N views.  Writes index_img (triangle id, -1 where empty; lower id
  * wins depth ties) and depth_img (ALWAYS float32, 0 where empty, rasterize_kernel.cu:481) --
  * bit-exact with the reference's arithmetic (rasterize_kernel.cu:69-166).
- * `workspace` holds the tile bins; query its size first.  `wireframe != 0` -> DRTK_ERR_UNSUPPORTED.
+ * `workspace` holds the tile bins; query its size first.
+ * `wireframe != 0` selects the line mode (rasterize_kernel.cu:170-400: edges whose bit is set in the top
+ * nibble of vi[...,0] are drawn by the diamond rule, the triangles themselves only occlude); it needs the
+ * workspace of drtk_amd_rasterize_lines_workspace_bytes (a packed [N,H,W] 64-bit buffer) instead.
  */
 int drtk_amd_rasterize_workspace_bytes(int64_t N, int64_t F, int64_t H, int64_t W, size_t* bytes);
+int drtk_amd_rasterize_lines_workspace_bytes(int64_t N, int64_t H, int64_t W, size_t* bytes);
 int drtk_amd_rasterize(
     drtk_dtype_t dtype, const void* v, const int32_t* vi, int64_t N, int64_t V, int64_t F,
     int64_t vi_sN, int64_t H, int64_t W, int wireframe, float* depth_img, int32_t* index_img,

@@ -3,6 +3,7 @@
  * Build: oracle/build.py  (gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC). */
 #include "drtk_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,7 +31,9 @@ static int drtk_oracle_resolve_threads(int nthreads) {
 #define REAL_EPS 1e-8f /* cuda_math_helper.h:62-64 */
 #define REAL_SQRT sqrtf
 #define REAL_FABS fabsf
+#define REAL_MAX_VALUE FLT_MAX
 #include "drtk_oracle_body.inc"
+#undef REAL_MAX_VALUE
 #define M_SQRT sqrtf
 #define M_FLOOR floorf
 #define M_CEIL ceilf
@@ -57,7 +60,9 @@ static int drtk_oracle_resolve_threads(int nthreads) {
 #define REAL_EPS 1e-16 /* cuda_math_helper.h:67-69 */
 #define REAL_SQRT sqrt
 #define REAL_FABS fabs
+#define REAL_MAX_VALUE DBL_MAX
 #include "drtk_oracle_body.inc"
+#undef REAL_MAX_VALUE
 #define M_SQRT sqrt
 #define M_FLOOR floor
 #define M_CEIL ceil

@@ -32,6 +32,10 @@ extern "C" {
   int drtk_oracle_rasterize_##SFX(                                                                \
       const REAL* v, const int32_t* vi, int64_t N, int64_t V, int64_t F, int64_t vi_sN,           \
       int64_t H, int64_t W, float* depth_img, int32_t* index_img, int nthreads);                  \
+  /* wireframe mode, rasterize_kernel.cu:170-400 (CUDA-only; PARITY UNPINNED, see the body) */        \
+  int drtk_oracle_rasterize_lines_##SFX(                                                          \
+      const REAL* v, const int32_t* vi, int64_t N, int64_t V, int64_t F, int64_t vi_sN,           \
+      int64_t H, int64_t W, float* depth_img, int32_t* index_img);                                \
   /* render_kernel_cpu.cpp:18-121 */                                                              \
   int drtk_oracle_render_##SFX(                                                                   \
       const REAL* v, const int32_t* vi, const int32_t* index_img, int64_t N, int64_t V,           \

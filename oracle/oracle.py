@@ -85,6 +85,18 @@ def rasterize(v, vi, height, width, nthreads=1):
     return depth, index
 
 
+def rasterize_lines(v, vi, height, width):
+    """Wireframe mode (rasterize_kernel.cu:170-400 restated; parity unpinned)."""
+    v = v.contiguous()
+    N, V, _ = v.shape
+    vi_c, vi_sN, F = _prep_vi(vi, N)
+    depth = torch.empty(N, height, width, dtype=torch.float32)
+    index = torch.empty(N, height, width, dtype=torch.int32)
+    _call("rasterize_lines", _sfx(v), _p(v), _p(vi_c), _i64(N), _i64(V), _i64(F), _i64(vi_sN), _i64(height),
+          _i64(width), _p(depth), _p(index))
+    return depth, index
+
+
 def render(v, vi, index_img, nthreads=1):
     v = v.contiguous()
     index_img = index_img.contiguous()

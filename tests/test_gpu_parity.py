@@ -203,8 +203,6 @@ def test_errors_are_loud():
         ops.rasterize(v.half(), vi, 8, 8)
     with pytest.raises(RuntimeError, match="HIP"):
         ops.rasterize(v.cpu(), vi.cpu(), 8, 8)
-    with pytest.raises(RuntimeError, match="wireframe"):
-        ops.rasterize(v, vi, 8, 8, wireframe=True)
     with th.autocast("cuda", dtype=th.float16):  # autocast casts to fp32 like the reference
         idx = ops.rasterize(v.half(), vi, 8, 8)
     assert idx.dtype == th.int32
@@ -446,3 +444,81 @@ def test_rasterize_random_soup_is_bit_exact(seed, ntri, scale):
     got_d, got_i = capi.rasterize(v.to(DEV), vi.to(DEV), H, W)
     assert th.equal(got_i.cpu(), want_i), f"{int((got_i.cpu() != want_i).sum())} index px differ"
     assert th.equal(got_d.cpu(), want_d)
+
+
+# ---- wireframe mode (parity unpinned: HIP vs the restatement of the CUDA source) --------
+
+
+def _wire_scenes():
+    import math
+
+    g = th.Generator().manual_seed(3)
+    scenes = []
+    # two triangles, every combination of edge bits on the first, all on the second
+    v = th.tensor([[[10.0, 5.0, 2.0], [50.0, 8.0, 2.0], [30.0, 40.0, 3.0], [12.0, 44.0, 2.5]]])
+    for bits in range(8):
+        vi = th.tensor([[0, 1, 2], [0, 2, 3]], dtype=th.int32)
+        vi[0, 0] |= bits << 28
+        vi[1, 0] |= 7 << 28
+        scenes.append((f"two_triangles_bits{bits}", v, vi, 48, 64))
+    # sphere views (occlusion between front and back edges), per-view topology with ragged nibbles
+    from drtk_amd import synthetic as S
+
+    v_pix, vi = S.sphere_views(2, 12, 16, 96, 128, second_sphere=True)
+    vi = vi.clone()
+    vi[:, 0] |= (th.randint(0, 8, (vi.shape[0],), generator=g, dtype=th.int32) << 28)
+    scenes.append(("spheres_random_bits", v_pix, vi, 96, 128))
+    # random soup: slivers, axis-aligned and diagonal edges through pixel centres and diamond corners
+    n = 300
+    xy = th.rand(1, n, 3, 2, generator=g) * th.tensor([70.0, 50.0]) - 3.0
+    xy[:, ::3] = xy[:, ::3].round()  # vertices exactly on pixel centres
+    xy[:, 1::3] = (xy[:, 1::3] * 2).round() / 2  # ... and on diamond corners
+    z = 1.0 + th.rand(1, n, 3, 1, generator=g) * 3
+    z[:, ::5] = 2.0
+    v = th.cat([xy, z], -1).reshape(1, n * 3, 3).contiguous()
+    vi = th.arange(n * 3, dtype=th.int32).view(n, 3).clone()
+    vi[:, 0] |= (th.randint(0, 8, (n,), generator=g, dtype=th.int32) << 28)
+    scenes.append(("soup", v, vi, 48, 64))
+    return scenes
+
+
+def test_wireframe_matches_restatement_bit_exact():
+    import oracle as O
+    from drtk_amd import capi
+
+    for name, v, vi, H, W in _wire_scenes():
+        for dt in (th.float32, th.float64):
+            vv = v.to(dt)
+            want_d, want_i = O.rasterize_lines(vv, vi, H, W)
+            got_d, got_i = capi.rasterize(vv.to(DEV), vi.to(DEV), H, W, wireframe=True)
+            assert th.equal(got_i.cpu(), want_i), (name, dt, int((got_i.cpu() != want_i).sum()))
+            assert th.equal(got_d.cpu(), want_d), (name, dt)
+
+
+def test_wireframe_python_api_and_invariants():
+    import drtk_amd
+    from drtk_amd import synthetic as S
+
+    H, W = 256, 256
+    v_pix, vi = S.sphere_views(2, 24, 28, H, W, device=DEV)
+    vi_all = vi.clone()
+    vi_all[:, 0] |= 7 << 28
+    depth_w, index_w = drtk_amd.rasterize_with_depth(v_pix, vi_all, H, W, wireframe=True)
+    assert index_w.dtype == th.int32 and depth_w.dtype == th.float32
+    assert th.equal(drtk_amd.rasterize(v_pix, vi_all, H, W, wireframe=True), index_w)
+    depth_t, index_t = drtk_amd.rasterize_with_depth(v_pix, vi, H, W)
+    inner = th.zeros_like(index_t, dtype=th.bool)
+    inner[:, 1:-1, 1:-1] = True
+    # every pixel a triangle covers is written in wireframe mode too (the border row/column is skipped, :321-325)
+    assert bool(((depth_w > 0) | ~((index_t >= 0) & inner)).all())
+    # drawn pixels carry valid ids, are a minority, and where an edge pixel coincides with a covered pixel its
+    # depth is not behind the surface
+    drawn = index_w >= 0
+    assert 0.02 < float(drawn.float().mean()) < 0.5 and int(index_w.max()) < vi.shape[0]
+    both = drawn & (index_t >= 0)
+    assert bool((depth_w[both] <= depth_t[both] * (1 + 1e-3)).all())
+    # no edge bit set: nothing is drawn but the triangles still write depth
+    depth_0, index_0 = drtk_amd.rasterize_with_depth(v_pix, vi, H, W, wireframe=True)
+    assert int((index_0 >= 0).sum()) == 0 and int((depth_0 > 0).sum()) > 1000
+    sel = (index_t >= 0) & inner
+    assert float((depth_0[sel] - depth_t[sel]).abs().max()) < 1e-4

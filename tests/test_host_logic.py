@@ -36,12 +36,14 @@ def test_c_abi_argument_validation_without_gpu():
     assert 0 < out.value < 64 * 2**20
     assert L.drtk_amd_rasterize_workspace_bytes(ctypes.c_int64(1), ctypes.c_int64(1), ctypes.c_int64(0),
                                                 ctypes.c_int64(4), ctypes.byref(out)) == -1
-    # wireframe is refused before anything touches the device
     z = ctypes.c_void_p(0)
-    rc = L.drtk_amd_rasterize(ctypes.c_int(0), z, z, ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0),
-                              ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(1), z, z, z,
-                              ctypes.c_size_t(0), z)
-    assert rc == -4
+    # wireframe mode needs its own (packed image) workspace
+    rc = L.drtk_amd_rasterize(ctypes.c_int(0), z, z, ctypes.c_int64(1), ctypes.c_int64(0), ctypes.c_int64(0),
+                              ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(1), ctypes.c_void_p(16),
+                              ctypes.c_void_p(16), z, ctypes.c_size_t(0), z)
+    assert rc == -2  # DRTK_ERR_WORKSPACE_TOO_SMALL
+    assert L.drtk_amd_rasterize_lines_workspace_bytes(ctypes.c_int64(2), ctypes.c_int64(8), ctypes.c_int64(8), ctypes.byref(out)) == 0
+    assert out.value == 2 * 8 * 8 * 8
     rc = L.drtk_amd_rasterize(ctypes.c_int(0), z, z, ctypes.c_int64(1), ctypes.c_int64(1 << 28), ctypes.c_int64(0),
                               ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(0), z, z, z,
                               ctypes.c_size_t(0), z)
