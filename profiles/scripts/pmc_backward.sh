@@ -1,8 +1,8 @@
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" "TA_TA_BUSY_sum TA_BUSY_avr TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"; do
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM"; do
   tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_ibwd/$tag -- python3 profiles/kernel_bench.py --only interpolate_backward,render_backward,edge_grad_backward_fused --reps 2 > gpurun_out/pmc_ibwd/$tag.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/${OUTDIR:-pmc_ibwd}/$tag -- python3 profiles/kernel_bench.py --only ${KERNELS:-interpolate_backward,render_backward,edge_grad_backward_fused} --reps 2 > gpurun_out/${OUTDIR:-pmc_ibwd}/$tag.log 2>&1
 done
-python3 profiles/summarize_pmc.py gpurun_out/pmc_ibwd > gpurun_out/pmc_ibwd/summary.txt 2>&1
-tail -5 gpurun_out/pmc_ibwd/*.log
+python3 profiles/summarize_pmc.py gpurun_out/${OUTDIR:-pmc_ibwd} > gpurun_out/${OUTDIR:-pmc_ibwd}/summary.txt 2>&1
+tail -5 gpurun_out/${OUTDIR:-pmc_ibwd}/*.log
