@@ -3,7 +3,12 @@
 facebookresearch/DRTK on PyTorch-ROCm.  Kernels: hand-written HIP for gfx950 in
 `drtk_amd/csrc`, C ABI in `include/drtk_amd.h`."""
 from drtk_amd.edge_grad_estimator import edge_grad_estimator  # noqa: F401
-from drtk_amd.interpolate import interpolate, interpolation_matrix, interpolation_normal_matrix  # noqa: F401
+from drtk_amd.interpolate import (  # noqa: F401
+    interpolate,
+    interpolate_masked,
+    interpolation_matrix,
+    interpolation_normal_matrix,
+)
 from drtk_amd.mipmap_grid_sample import mipmap_grid_sample  # noqa: F401
 from drtk_amd.rasterize import rasterize, rasterize_with_depth  # noqa: F401
 from drtk_amd.render import render  # noqa: F401

@@ -44,6 +44,7 @@ EXPORTS = [
     "drtk_amd_render",
     "drtk_amd_render_backward",
     "drtk_amd_interpolate",
+    "drtk_amd_interpolate_masked",
     "drtk_amd_interpolate_backward",
     "drtk_amd_edge_grad_backward_workspace_bytes",
     "drtk_amd_edge_grad_backward",

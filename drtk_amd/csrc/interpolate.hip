@@ -29,7 +29,7 @@ template <typename T, int VEC, int CV>
 __global__ __launch_bounds__(kBlock) void interpolate_kernel(
     const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
-    int64_t vi_sN, int H, int W, T* __restrict__ out) {
+    int64_t vi_sN, int H, int W, T* __restrict__ out, int zero_background) {
   using V4 = typename Vec4<T>::type;
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
         for (int cc = 0; cc < CV; ++cc) r[cc][j] = u0[cc] * B0[j] + u1[cc] * B1[j] + u2[cc] * B2[j];
       } else {
 #pragma unroll
-        for (int cc = 0; cc < CV; ++cc) r[cc][j] = ((c0 + cc) & 1) ? bgy : bgx[j];
+        for (int cc = 0; cc < CV; ++cc) r[cc][j] = zero_background ? T(0) : (((c0 + cc) & 1) ? bgy : bgx[j]);
       }
     }
 #pragma unroll
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
 template <typename T>
 int interpolate_impl(
     const T* attrs, const int32_t* vi, const int32_t* index_img, const T* bary_img, int64_t N,
-    int64_t V, int64_t C, int64_t vi_sN, int64_t H, int64_t W, T* out, hipStream_t stream) {
+    int64_t V, int64_t C, int64_t vi_sN, int64_t H, int64_t W, T* out, int zero_background, hipStream_t stream) {
   const int64_t HW = H * W;
   if (N * HW * C == 0) return DRTK_OK;
   const bool pvec = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(index_img) % 16 == 0) &&
@@ -449,7 +449,7 @@ int interpolate_impl(
   hipLaunchKernelGGL(                                                                           \
       (interpolate_kernel<T, VEC, CV>),                                                         \
       dim3(static_cast<unsigned>(ceil_div(HW / VEC, kBlock)), static_cast<unsigned>(N)), block, \
-      0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out)
+      0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out, zero_background)
   if (pvec && cvec)
     LAUNCH(4, 4);
   else if (pvec)
@@ -521,22 +521,36 @@ bool bad_common(int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64
 
 using namespace drtk_amd;
 
-extern "C" int drtk_amd_interpolate(
+static int interpolate_entry(
     drtk_dtype_t dtype, const void* attrs, const int32_t* vi, const int32_t* index_img,
     const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H,
-    int64_t W, void* out, drtk_stream_t stream) {
+    int64_t W, void* out, int zero_background, drtk_stream_t stream) {
   if (bad_common(N, V, C, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W * C > 0 && (!index_img || !bary_img || !out)) return DRTK_ERR_INVALID_ARGUMENT;
   if ((N * V * C > 0 && !attrs) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:
-      return interpolate_impl<float>(static_cast<const float*>(attrs), vi, index_img, static_cast<const float*>(bary_img), N, V, C, vi_sN, H, W, static_cast<float*>(out), s);
+      return interpolate_impl<float>(static_cast<const float*>(attrs), vi, index_img, static_cast<const float*>(bary_img), N, V, C, vi_sN, H, W, static_cast<float*>(out), zero_background, s);
     case DRTK_F64:
-      return interpolate_impl<double>(static_cast<const double*>(attrs), vi, index_img, static_cast<const double*>(bary_img), N, V, C, vi_sN, H, W, static_cast<double*>(out), s);
+      return interpolate_impl<double>(static_cast<const double*>(attrs), vi, index_img, static_cast<const double*>(bary_img), N, V, C, vi_sN, H, W, static_cast<double*>(out), zero_background, s);
     default:
       return DRTK_ERR_INVALID_ARGUMENT;
   }
+}
+
+extern "C" int drtk_amd_interpolate(
+    drtk_dtype_t dtype, const void* attrs, const int32_t* vi, const int32_t* index_img,
+    const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H,
+    int64_t W, void* out, drtk_stream_t stream) {
+  return interpolate_entry(dtype, attrs, vi, index_img, bary_img, N, V, C, F, vi_sN, H, W, out, 0, stream);
+}
+
+extern "C" int drtk_amd_interpolate_masked(
+    drtk_dtype_t dtype, const void* attrs, const int32_t* vi, const int32_t* index_img,
+    const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H,
+    int64_t W, void* out, drtk_stream_t stream) {
+  return interpolate_entry(dtype, attrs, vi, index_img, bary_img, N, V, C, F, vi_sN, H, W, out, 1, stream);
 }
 
 extern "C" int drtk_amd_interpolate_backward(

@@ -329,7 +329,7 @@ void interpolate_checks(const Tensor& a, const Tensor& vi, const Tensor& index_i
       "interpolate(): expected H and W dims of index_img and bary_img to match");
 }
 
-Tensor interpolate_hip(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+Tensor interpolate_launch(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img, bool masked) {
   interpolate_checks(a, vi, index_img, bary_img);
   const drtk_dtype_t dt = dtype_of(a, "interpolate");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(a.device());
@@ -340,11 +340,19 @@ Tensor interpolate_hip(const Tensor& a, const Tensor& vi, const Tensor& index_im
   const int64_t N = a.size(0), V = a.size(1), C = a.size(2), F = vi.size(1), H = bary_img.size(2), W = bary_img.size(3);
   auto out = at::empty({N, C, H, W}, a.options());
   check_status(
-      drtk_amd_interpolate(
+      (masked ? drtk_amd_interpolate_masked : drtk_amd_interpolate)(
           dt, a_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), N, V, C, F, via.sN,
           H, W, out.data_ptr(), current_stream(a)),
       "interpolate");
   return out;
+}
+
+Tensor interpolate_hip(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  return interpolate_launch(a, vi, index_img, bary_img, false);
+}
+// extension: background written as 0 (= interpolate(...) * (index_img != -1)[:, None] in one pass)
+Tensor interpolate_masked_hip(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  return interpolate_launch(a, vi, index_img, bary_img, true);
 }
 
 std::tuple<Tensor, Tensor> interpolate_backward_hip(
@@ -403,6 +411,34 @@ class InterpolateFunction : public torch::autograd::Function<InterpolateFunction
 
 Tensor interpolate_autograd(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
   return InterpolateFunction::apply(a, vi, index_img, bary_img)[0];
+}
+
+Tensor interpolate_masked_op(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("drtk_amd_ext::interpolate_masked", "")
+                       .typed<decltype(interpolate_masked_op)>();
+  return op.call(a, vi, index_img, bary_img);
+}
+// Same VJP as interpolate: the backward ignores the upstream gradient of background pixels, which is
+// exactly what multiplying the output by the mask would do to it.
+class InterpolateMaskedFunction : public torch::autograd::Function<InterpolateMaskedFunction> {
+ public:
+  static tensor_list forward(
+      AutogradContext* ctx, const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+    ctx->set_materialize_grads(false);
+    ctx->save_for_backward({a, vi, index_img, bary_img});
+    at::AutoDispatchBelowADInplaceOrView g;
+    return {interpolate_masked_op(a, vi, index_img, bary_img)};
+  }
+  static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+    return InterpolateFunction::backward(ctx, grad_outputs);
+  }
+};
+Tensor interpolate_masked_autograd(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
+  return InterpolateMaskedFunction::apply(a, vi, index_img, bary_img)[0];
+}
+Tensor interpolate_masked_cpu(const Tensor&, const Tensor&, const Tensor&, const Tensor&) {
+  no_cpu("interpolate_masked");
 }
 
 Tensor interpolate_autocast(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
@@ -1580,6 +1616,7 @@ TORCH_LIBRARY_IMPL(mipmap_grid_sampler_ext, CPU, m) { // the reference registers
 // drtk_amd's own namespace (extensions with no reference counterpart)
 TORCH_LIBRARY(drtk_amd_ext, m) {
   m.def("transform_pinhole(Tensor v, Tensor campos, Tensor camrot, Tensor focal, Tensor princpt) -> Tensor");
+  m.def("interpolate_masked(Tensor vert_attributes, Tensor vi, Tensor index_img, Tensor bary_img) -> Tensor");
   m.def(
       "screen_space_uv_derivative(Tensor v, Tensor vt, Tensor vi, Tensor vti, Tensor index_img, Tensor bary_img, Tensor mask, Tensor campos, Tensor camrot, Tensor focal) -> Tensor",
       &screen_space_uv_derivative_hip);
@@ -1590,10 +1627,13 @@ TORCH_LIBRARY(drtk_amd_ext, m) {
 }
 TORCH_LIBRARY_IMPL(drtk_amd_ext, Autograd, m) {
   m.impl("transform_pinhole", &transform_pinhole_autograd);
+  m.impl("interpolate_masked", &interpolate_masked_autograd);
 }
 TORCH_LIBRARY_IMPL(drtk_amd_ext, CUDA, m) {
   m.impl("transform_pinhole", &transform_pinhole_hip);
+  m.impl("interpolate_masked", &interpolate_masked_hip);
 }
 TORCH_LIBRARY_IMPL(drtk_amd_ext, CPU, m) {
   m.impl("transform_pinhole", &transform_pinhole_cpu);
+  m.impl("interpolate_masked", &interpolate_masked_cpu);
 }

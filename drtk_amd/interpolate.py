@@ -31,6 +31,26 @@ def interpolate(
     return th.ops.interpolate_ext.interpolate(vert_attributes, vi, index_img, bary_img)
 
 
+@th.compiler.disable
+def interpolate_masked(
+    vert_attributes: th.Tensor,
+    vi: th.Tensor,
+    index_img: th.Tensor,
+    bary_img: th.Tensor,
+) -> th.Tensor:
+    """drtk_amd extension: `interpolate(...) * (index_img != -1)[:, None]` in one pass.
+
+    Every DRTK pipeline masks the background of `interpolate`'s output (the reference fills it with
+    a coordinate sweep).  Done with torch ops that costs a full read+write of the image forward and
+    another one backward; here the kernel writes 0 there itself and the backward is `interpolate`'s
+    own (which never reads the upstream gradient of a background pixel).  Values and gradients are
+    identical to the two-op form.
+    """
+    if vi.ndim == 2:
+        vi = vi[None].expand(vert_attributes.shape[0], -1, -1)
+    return th.ops.drtk_amd_ext.interpolate_masked(vert_attributes, vi, index_img, bary_img)
+
+
 def _broadcast_vi(vi: th.Tensor, n: int) -> th.Tensor:
     # drtk/interpolate.py:107-110 : [F,3] and [1,F,3] broadcast to the batch with a stride-0 expand
     if vi.ndim == 2:

@@ -99,6 +99,15 @@ int drtk_amd_interpolate(
     const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H,
     int64_t W, void* out, drtk_stream_t stream);
 
+/* Extension (no reference counterpart): interpolate with the background written as 0 instead of the
+ * +-1 coordinate sweep -- the fused form of `interpolate(...) * (index_img != -1)[:, None]`, the way every
+ * DRTK pipeline uses the op (test/two_triangles.py:52-58).  Same gradient as drtk_amd_interpolate: the
+ * backward never reads the upstream gradient of a background pixel. */
+int drtk_amd_interpolate_masked(
+    drtk_dtype_t dtype, const void* attrs, const int32_t* vi, const int32_t* index_img,
+    const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H,
+    int64_t W, void* out, drtk_stream_t stream);
+
 /* interpolate_backward  replaces interpolate_cuda_backward (interpolate_kernel.cu:642-697)
  * attr_grad [N,V,C] (NULL = not wanted) is zero-filled then accumulated; bary_grad [N,3,H,W]
  * (NULL = not wanted) is fully written.  At least one must be non-NULL.

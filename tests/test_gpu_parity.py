@@ -522,3 +522,24 @@ def test_wireframe_python_api_and_invariants():
     assert int((index_0 >= 0).sum()) == 0 and int((depth_0 > 0).sum()) > 1000
     sel = (index_t >= 0) & inner
     assert float((depth_0[sel] - depth_t[sel]).abs().max()) < 1e-4
+
+
+def test_interpolate_masked_extension_equals_interpolate_times_mask():
+    import drtk_amd
+
+    i, o = load_golden("spheres_c16_f32")
+    vi, index, bary = dev(i["vi"]), dev(o["index_img"]), dev(o["render_bary"])
+    mask = (index != -1)[:, None]
+    a1 = dev(i["attr"]).clone().requires_grad_(True)
+    b1 = bary.clone().requires_grad_(True)
+    ref = drtk_amd.interpolate(a1, vi, index, b1) * mask
+    a2 = dev(i["attr"]).clone().requires_grad_(True)
+    b2 = bary.clone().requires_grad_(True)
+    got = drtk_amd.interpolate_masked(a2, vi, index, b2)
+    assert th.equal(got, ref)
+    go = dev(i["go"])
+    ref.backward(go)
+    got.backward(go)
+    close(a2.grad, a1.grad, "attr grad (masked extension)")
+    close(b2.grad, b1.grad, "bary grad (masked extension)")
+    assert float(b2.grad[~mask.expand_as(b2.grad)[:, :3]].abs().sum()) == 0.0
