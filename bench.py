@@ -69,7 +69,7 @@ OP_KERNELS = {
     "render": ["render_kernel<"],
     "interpolate": ["interpolate_kernel<float, 4, 4>"],
     "edge_grad_backward": ["edge_dots_kernel", "edge_gather"],
-    "edge_grad_backward_fused": ["edge_dots_kernel", "edge_scatter4_kernel"],
+    "edge_grad_backward_fused": ["edge_dots_kernel", "edge_scatter_pairs_kernel"],
     "interpolate_backward_vpix": ["interpolate_backward_kernel<float, true, false"],
     "interpolate_backward": ["interpolate_backward_wide_kernel<float>", "interpolate_backward_kernel<float, true, true, 4, 16>"],
     "render_backward": ["render_backward_kernel"],

@@ -513,23 +513,30 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 
 // Fused pass B for the default route of drtk.edge_grad_estimator (no v_pix_img hook): instead of
 // materialising grad_v_pix_img [N,3,H,W] (80 % exact zeros) for a separate C=3 interpolate backward to
-// scatter, the edge pixels are compacted as in edge_gather4_kernel and their three gradient components
-// are multiplied by the pixel's barycentrics and scattered to the triangle's vertices right away,
-// through the run reduction + wave-private vertex table of segscatter.hpp.  A wave owns a
-// 256 x 4 pixel tile.  (edge_grad_estimator.py:168-176 + interpolate_kernel.cu:271-279 fused.)
+// scatter, the contributions are multiplied by the pixel's barycentrics and scattered to the triangle's
+// vertices right away (edge_grad_estimator.py:168-176 + interpolate_kernel.cu:271-279 fused).
+// A per-pixel formulation (as in edge_gather4_kernel, which must own its output pixel) evaluates every
+// differing pixel pair twice -- once from each end -- inside four divergent branches; that arithmetic was
+// 60 % of such a kernel, which is instruction-issue bound (1.27 ms fused; this kernel: 0.96 ms).
+// Here the unit of work is the PAIR: a wave compacts the horizontal pairs (x,y)-(x+1,y) and the vertical
+// pairs (x,y)-(x,y+1) of its 256 x 4 tile whose indices differ (same stencil domain, edge_grad_kernel.cu:270),
+// one pair per lane, evaluates it ONCE with the axis as a compile-time constant, and scatters both ends'
+// contributions (pixel A: -gA on the axis, -zA on z; pixel B: -gB, -zB; each times its own pixel's
+// barycentrics) through the run reduction of segscatter.hpp with six corner slots (A0..A2, B0..B2) and
+// two components each.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void edge_scatter4_kernel(
-    const T* __restrict__ v_pix, const int32_t* __restrict__ vi,
-    const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, const T* __restrict__ gdx,
-    const T* __restrict__ gdy, int64_t V, int64_t vi_sN, int H, int W, int strips_x, T M,
-    T* __restrict__ grad_v_pix) {
+__global__ __launch_bounds__(kBlock) void edge_scatter_pairs_kernel(
+    const T* __restrict__ v_pix, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
+    const T* __restrict__ bary_img, const T* __restrict__ gdx, const T* __restrict__ gdy, int64_t V, int64_t vi_sN,
+    int H, int W, int strips_x, T M, T* __restrict__ grad_v_pix) {
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kRows = 4;
-  __shared__ uint16_t s_list[kWaves][kWave * 4 * 4]; // kRows rows of 256 pixels
-  __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
-  __shared__ int32_t s_vid[kWaves][3 * kRunPad];
-  __shared__ int32_t s_slot[kWaves][3 * kRunPad];
+  constexpr int kCap = kWave * 4 * 2 * 2; // pairs of two rows, both axes: the most one list build can hold
+  __shared__ uint16_t s_list[kWaves][kCap];
+  __shared__ __attribute__((aligned(16))) T s_val[kWaves][12 * kRunPad];
+  __shared__ int32_t s_vid[kWaves][6 * kRunPad];
+  __shared__ int32_t s_slot[kWaves][6 * kRunPad];
   __shared__ int32_t t_keys[kWaves][kTableSlots];
   __shared__ T t_vals[kWaves][kTableSlots * 4];
 
@@ -552,16 +559,13 @@ __global__ __launch_bounds__(kBlock) void edge_scatter4_kernel(
 
   table_init(t_keys[wave]);
   for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = T(0);
-  wave_lds_sync();
 
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  // index rows y_base-1 .. y_base+kRows of this lane's 4 pixels, fetched in one batch (each row serves
-  // as centre, as "up" of the row below and as "down" of the row above)
-  int32_t row[kRows + 2][4];
+  // index rows y_base .. y_base+kRows of this lane's 4 pixels, one batch
+  int32_t row[kRows + 1][4];
 #pragma unroll
-  for (int r = 0; r < kRows + 2; ++r) {
-    const int y = y_base - 1 + r;
-    if (in_x && y >= 0 && y < H) {
+  for (int r = 0; r <= kRows; ++r) {
+    const int y = y_base + r;
+    if (in_x && y < H) {
       const int4 q = *reinterpret_cast<const int4*>(idx_n + int64_t(y) * W + x0);
       row[r][0] = q.x, row[r][1] = q.y, row[r][2] = q.z, row[r][3] = q.w;
     } else {
@@ -569,91 +573,135 @@ __global__ __launch_bounds__(kBlock) void edge_scatter4_kernel(
       for (int j = 0; j < 4; ++j) row[r][j] = -1;
     }
   }
-  // edge flags (same stencil domain as edge_gather4_kernel) and pixel-ordered compaction of the whole
-  // 256 x 4 tile: entry = row << 8 | local x, ordered by row then x, so runs of one triangle stay
-  // contiguous and the compacted lanes are ~97 % full instead of ~72 % with one list per row
-  int total = 0;
+  // pair flags of the lane's pixels: bit j of hf[r] / vf[r] = horizontal / vertical pair starting at pixel j of row r
+  uint32_t hf[kRows], vf[kRows];
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
     const int y = y_base + r;
-    const bool y_ok = y < H; // wave-uniform
-    const int32_t* c = row[r + 1];
-    int32_t lprev = __shfl_up(c[3], 1), rnext = __shfl_down(c[0], 1);
-    if (y_ok && in_x && lane == 0 && x0 >= 1) lprev = idx_n[int64_t(y) * W + x0 - 1];
-    if (y_ok && in_x && lane == kWave - 1 && x0 + 4 < W) rnext = idx_n[int64_t(y) * W + x0 + 4];
-    bool e[4];
-    int cnt = 0;
+    int32_t rnext = __shfl_down(row[r][0], 1);
+    if (in_x && y < H && lane == kWave - 1 && x0 + 4 < W) rnext = idx_n[int64_t(y) * W + x0 + 4];
+    hf[r] = vf[r] = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int x = x0 + j;
-      const bool own = y_ok && in_x && (x < W - 1) && (y < H - 1);
-      const bool left = y_ok && in_x && (x >= 1) && (y < H - 1);
-      const bool up = y_ok && in_x && (y >= 1) && (x < W - 1);
-      const int32_t nr = own ? (j < 3 ? c[(j + 1) & 3] : rnext) : c[j];
-      const int32_t nd = own ? row[r + 2][j] : c[j];
-      const int32_t nl = left ? (j > 0 ? c[(j + 3) & 3] : lprev) : c[j];
-      const int32_t nu = up ? row[r][j] : c[j];
-      e[j] = y_ok && (c[j] != nr || c[j] != nd || c[j] != nl || c[j] != nu);
-      cnt += e[j] ? 1 : 0;
-    }
-    // exclusive prefix of cnt (0..4) over the lanes from three ballots
-    const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
-    int pos = total + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-    total += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (e[j]) s_list[wave][pos++] = static_cast<uint16_t>((r << 8) | (lane * 4 + j));
+      const bool own = in_x && (x0 + j < W - 1) && (y < H - 1); // stencil domain of the reference
+      const int32_t nr = j < 3 ? row[r][(j + 1) & 3] : rnext;
+      if (own && row[r][j] != nr) hf[r] |= 1u << j;
+      if (own && row[r][j] != row[r + 1][j]) vf[r] |= 1u << j;
     }
   }
-  wave_lds_sync();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // exclusive prefix over the lanes of a 0..4 count, and its wave total, from three ballots
+  auto prefix4 = [&](int cnt, int& total) -> int {
+    const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+    total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    return __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+  };
 
-  for (int t0 = 0; t0 < total; t0 += kWave) {
-    const int t = t0 + lane;
-    const bool act = t < total;
-    int32_t ic = -1;
-    T g[3] = {T(0), T(0), T(0)};
-    T B[3] = {T(0), T(0), T(0)};
-    int32_t vid[3] = {0, 0, 0};
-    if (act) {
-      const int entry = s_list[wave][t];
-      const int y = y_base + (entry >> 8);
-      const int px = sx * (kWave * 4) + (entry & 255);
-      const int64_t pix = int64_t(y) * W + px;
-      ic = idx_n[pix];
-      if (ic >= 0) { // background pixels never receive a gradient
-        const bool own = (px < W - 1) && (y < H - 1);
-        const bool left = (px >= 1) && (y < H - 1);
-        const bool up = (y >= 1) && (px < W - 1);
-        const int32_t ir = own ? idx_n[pix + 1] : ic;
-        const int32_t id = own ? idx_n[pix + W] : ic;
-        const int32_t il = left ? idx_n[pix - 1] : ic;
-        const int32_t iu = up ? idx_n[pix - W] : ic;
-        edge_pixel<T>(v_n, vi_n, gdx_n, gdy_n, pix, px, y, W, ic, ir, id, il, iu, M, g[0], g[1], g[2], vid);
-        B[0] = bary_n[pix], B[1] = bary_n[HW + pix], B[2] = bary_n[2 * HW + pix];
+  // rows are processed in groups whose pair lists fit the LDS list: all four rows normally, two and two
+  // when the tile is so dense that they would not
+  int grand = 0;
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    int t;
+    prefix4(__popc(hf[r]) + 0, t);
+    grand += t;
+    prefix4(__popc(vf[r]) + 0, t);
+    grand += t;
+  }
+  const int rows_per_group = grand <= kCap ? kRows : 2;
+  for (int r0 = 0; r0 < kRows; r0 += rows_per_group) {
+    // list layout: [horizontal pairs of the group, row-major][vertical pairs, row-major]
+    int n_h = 0, n_all = 0;
+    wave_lds_sync(); // the previous group's list and staging are no longer read
+#pragma unroll
+    for (int axis = 0; axis < 2; ++axis) {
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        if (r < r0 || r >= r0 + rows_per_group) continue;
+        const uint32_t f = axis == 0 ? hf[r] : vf[r];
+        int t;
+        int pos = n_all + prefix4(__popc(f), t);
+        n_all += t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (f & (1u << j)) s_list[wave][pos++] = static_cast<uint16_t>((r << 8) | (lane * 4 + j));
+        }
+      }
+      if (axis == 0) n_h = n_all;
+    }
+    wave_lds_sync();
+
+    // one pair per lane; a chunk of 64 lanes never mixes the two axes
+    for (int axis = 0; axis < 2; ++axis) {
+      const int l_begin = axis == 0 ? 0 : n_h, l_end = axis == 0 ? n_h : n_all;
+      for (int t0 = l_begin; t0 < l_end; t0 += kWave) {
+        const int t = t0 + lane;
+        const bool act = t < l_end;
+        int32_t ia = -1, ib = -1;
+        T ga = T(0), za = T(0), gb = T(0), zb = T(0); // -(in-plane), -(z) contributions to pixel A / pixel B
+        T Ba[3] = {T(0), T(0), T(0)}, Bb[3] = {T(0), T(0), T(0)};
+        int32_t va[3] = {0, 0, 0}, vb[3] = {0, 0, 0};
+        if (act) {
+          const int entry = s_list[wave][t];
+          const int y = y_base + (entry >> 8);
+          const int px = sx * (kWave * 4) + (entry & 255);
+          const int64_t pa = int64_t(y) * W + px;
+          const int64_t pb = axis == 0 ? pa + 1 : pa + W;
+          ia = idx_n[pa];
+          ib = idx_n[pb];
+          TriInfo<T> ta, tb;
+          load_tri<T>(v_n, vi_n, ia, ta);
+          load_tri<T>(v_n, vi_n, ib, tb);
+          T gA, zA, gB, zB;
+          if (axis == 0) {
+            eval_pair<T, 0>(v_n, ta, tb, ia, ib, px, y, gdx_n[pa], M, gA, zA, gB, zB);
+          } else {
+            eval_pair<T, 1>(v_n, ta, tb, ia, ib, px, y, gdy_n[pa], M, gA, zA, gB, zB);
+          }
+          ga = -gA, za = -zA, gb = -gB, zb = -zB; // edge_grad_kernel.cu:427-445 negates
+          va[0] = ta.i0, va[1] = ta.i1, va[2] = ta.i2;
+          vb[0] = tb.i0, vb[1] = tb.i1, vb[2] = tb.i2;
+          if (ia >= 0) Ba[0] = bary_n[pa], Ba[1] = bary_n[HW + pa], Ba[2] = bary_n[2 * HW + pa];
+          if (ib >= 0) Bb[0] = bary_n[pb], Bb[1] = bary_n[HW + pb], Bb[2] = bary_n[2 * HW + pb];
+        }
+        // a side takes part if its pixel is foreground and it received something
+        const bool a_on = ia >= 0 && (ga != T(0) || za != T(0));
+        const bool b_on = ib >= 0 && (gb != T(0) || zb != T(0));
+        const bool a_tab = a_on && va[0] != va[1] && va[0] != va[2] && va[1] != va[2];
+        const bool b_tab = b_on && vb[0] != vb[1] && vb[0] != vb[2] && vb[1] != vb[2];
+        // staging rows: corner slot ks = 0..2 (A's vertices), 3..5 (B's); two components per corner:
+        // c = 0 the pair's axis (x or y), c = 1 z
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          s_val[wave][(k * 2 + 0) * kRunPad + lane] = a_on ? ga * Ba[k] : T(0);
+          s_val[wave][(k * 2 + 1) * kRunPad + lane] = a_on ? za * Ba[k] : T(0);
+          s_val[wave][((3 + k) * 2 + 0) * kRunPad + lane] = b_on ? gb * Bb[k] : T(0);
+          s_val[wave][((3 + k) * 2 + 1) * kRunPad + lane] = b_on ? zb * Bb[k] : T(0);
+          s_vid[wave][k * kRunPad + lane] = va[k];
+          s_vid[wave][(3 + k) * kRunPad + lane] = vb[k];
+          s_slot[wave][k * kRunPad + lane] = a_on ? (a_tab ? table_slot(t_keys[wave], va[k]) : -1) : -2;
+          s_slot[wave][(3 + k) * kRunPad + lane] = b_on ? (b_tab ? table_slot(t_keys[wave], vb[k]) : -1) : -2;
+        }
+        // a run = consecutive lanes with the same two triangles and the same participation
+        const int32_t key_a = a_on ? ia : -1, key_b = b_on ? ib : -1;
+        const int32_t prev_a = __shfl_up(key_a, 1), prev_b = __shfl_up(key_b, 1);
+        const unsigned long long heads = __ballot(lane == 0 || key_a != prev_a || key_b != prev_b);
+        const unsigned long long cov = __ballot(a_on || b_on);
+        wave_lds_sync();
+        if (cov != 0) {
+          const T* sv = s_val[wave];
+          // components {axis, z}: x,z = 0 + c*2 ; y,z = 1 + c*1
+          scatter_runs<T>(
+              heads, cov, s_slot[wave], s_vid[wave], 12, 2, t_vals[wave], 4, grad_n, 3, 0,
+              [sv](int k, int cc, int g4, T* x) {
+                const V4 q = *reinterpret_cast<const V4*>(sv + (k * 2 + cc) * kRunPad + 4 * g4);
+                x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
+              },
+              0, axis == 0 ? 0 : 1, axis == 0 ? 2 : 1);
+        }
+        wave_lds_sync();
       }
     }
-    const bool covered = ic >= 0;
-    const bool use_table = covered && vid[0] != vid[1] && vid[0] != vid[2] && vid[1] != vid[2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) s_val[wave][(k * 3 + cc) * kRunPad + lane] = g[cc] * B[k];
-      s_vid[wave][k * kRunPad + lane] = vid[k];
-      s_slot[wave][k * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid[k]) : -1;
-    }
-    unsigned long long heads, cov;
-    run_masks(covered ? ic : -1, heads, cov);
-    wave_lds_sync();
-    if (cov != 0) {
-      const T* sv = s_val[wave];
-      scatter_runs<T>(
-          heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals[wave], 4, grad_n, 3, 0,
-          [sv](int k, int cc, int g4, T* x) {
-            const V4 q = *reinterpret_cast<const V4*>(sv + (k * 3 + cc) * kRunPad + 4 * g4);
-            x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
-          });
-    }
-    wave_lds_sync();
   }
   table_flush<T>(t_keys[wave], t_vals[wave], 4, 3, grad_n, 3, 0);
 }
@@ -738,7 +786,7 @@ int edge_grad_backward_fused_impl(
     const int strips_x = static_cast<int>(ceil_div(W, kWave * 4));
     const int64_t waves = int64_t(strips_x) * ceil_div(H, 4);
     const dim3 grid(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((edge_scatter4_kernel<T>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix);
+    hipLaunchKernelGGL((edge_scatter_pairs_kernel<T>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix);
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;
   }

@@ -77,15 +77,20 @@ __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
 template <typename T, typename Val4Fn>
 __device__ __forceinline__ void scatter_runs(
     unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
-    int CC, T* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0) {
+    int CC, T* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0,
+    int c_off = 0, int c_step = 1) {
   const int lane = lane_id();
   using LdsPtr = __attribute__((address_space(3))) T*;
   // `exclusive`: no two lanes of one call target the same table entry (one run at a time, and the
   // three corners of a triangle are distinct vertices -- phase 1 sends triangles with repeated
   // vertex ids to the global fallback), so a plain read-modify-write is race free.
-  auto flush = [&](int k, int c, int start, T acc, bool exclusive) {
+  // lane channel c addresses component c_off + c * c_step of the table entry / destination row
+  // (default: c itself), so callers can scatter a strided subset of the components
+  auto flush = [&](int k, int c_lane, int start, T acc, bool exclusive) {
     if (dbg & 32) return;
+    const int c = c_off + c_lane * c_step;
     const int s = slot ? slot[k * kRunPad + start] : -1; // slot == nullptr: no table, always direct
+    if (s < -1) return;                                   // -2: this corner receives nothing in this run
     if (s >= 0) {
       if (exclusive) {
         LdsPtr q = (LdsPtr)(vals + s * stride + c);
