@@ -284,6 +284,13 @@ __device__ __forceinline__ void atomic_add_g1(GlobalPtr<T> p, T v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// float/double add on an explicitly LDS-typed pointer (ds_add_f32 / ds_add_f64, no return)
+template <typename T>
+__device__ __forceinline__ void lds_add(T* p, T v) {
+  using LdsPtr = __attribute__((address_space(3))) T*;
+  __hip_atomic_fetch_add((LdsPtr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // two horizontally adjacent texels, loaded with one element-aligned 8/16-byte access
 template <typename T>
 struct PairOf;
@@ -490,6 +497,162 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
   grad_grid[index * 2 + 1] = acc_y;
 }
 
+// Backward, bilinear, C <= 4: LDS-windowed accumulation of the texture gradient.
+// The direct kernel above is bound by the float-atomic REQUEST rate (~20 G/s): every (tap, level, corner,
+// channel) is one atomic instruction touching ~5 64-byte segments.  Here a workgroup owns a 16 x 16 PIXEL
+// tile, whose taps land in a compact texel window on the two or three mip levels its pixels select; the
+// window (32 x 32 texels per level, 3 levels from the tile's finest level) is accumulated in LDS with
+// ds_add_f32 and flushed once, row-major, so the global atomics are coalesced and each touched texel costs
+// one request per tile instead of one per tap.  Corners outside the window, or on other levels, go to
+// global memory directly, so any uv field is handled.
+constexpr int kTileW = 16;  // pixel tile
+constexpr int kWin = 32;    // texel window side
+constexpr int kWinLevels = 3;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
+    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid,
+    const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso, int padding, bool align_corners,
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid) {
+  __shared__ const void* s_ptr[kMaxLevels];
+  __shared__ void* s_grad[kMaxLevels];
+  __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels];
+  __shared__ T s_win[kWinLevels][4][kWin * kWin];
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
+  const int tid = threadIdx.x;
+  if (tid == 0) s_ref = kMaxLevels;
+  if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
+  for (int i = tid; i < kWinLevels * 4 * kWin * kWin; i += kBlock) (&s_win[0][0][0])[i] = T(0);
+  __syncthreads();
+
+  const int n = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileW + tid / kTileW;
+  const bool valid = px < W && py < H;
+  const int64_t HW = int64_t(H) * W;
+  const int64_t index = int64_t(n) * HW + int64_t(py) * W + px;
+  Taps<T> t = {};
+  if (valid) t = setup_taps<T>(grid, vt, index, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+  const int n_lv = mipmaps > 1 ? 2 : 1;
+  if (valid) atomicMin(&s_ref, t.d1);
+  __syncthreads();
+  const int ref = s_ref;
+  auto tap_xy = [&](int i, T& x, T& y) {
+    const double f = (i + 1.0) / (t.n + 1.0) * 2.0 - 1.0;
+    x = t.u + static_cast<T>(t.du * f);
+    y = t.v + static_cast<T>(t.dv * f);
+  };
+  // window origins: the taps of a pixel are collinear, so their extreme texels are those of the first and
+  // the last tap
+  if (valid) {
+    for (int e = 0; e < 2; ++e) {
+      T x, y;
+      tap_xy(e == 0 ? 0 : t.n - 1, x, y);
+      for (int s = 0; s < n_lv; ++s) {
+        const int l = t.d1 + s - ref;
+        if (l < kWinLevels) {
+          const Quad<T> q = bilinear_quad<T>(x, y, s_h[t.d1 + s], s_w[t.d1 + s], padding, align_corners);
+          atomicMin(&s_ox[l], q.ix_nw);
+          atomicMin(&s_oy[l], q.iy_nw);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  if (valid) {
+    const T* gout_px = grad_out + int64_t(n) * C * HW + (int64_t(py) * W + px);
+    const T alpha_1 = t.a / t.n;
+    const T alpha_2 = static_cast<T>((1.0 - t.a) / t.n);
+    T acc_x = T(0), acc_y = T(0);
+    for (int i = 0; i < t.n; ++i) {
+      T x, y;
+      tap_xy(i, x, y);
+      for (int s = 0; s < n_lv; ++s) {
+        const int d = t.d1 + s;
+        const int h = s_h[d], w = s_w[d];
+        const int64_t plane = int64_t(h) * w;
+        const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * C * plane);
+        const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+        const T alpha = s == 0 ? alpha_2 : alpha_1;
+        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
+        const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
+        // window cell of the north-west corner (the other three are +1 in x / y), or -1 if not windowed
+        const int l = d - ref;
+        int cell = -1;
+        if (l < kWinLevels) {
+          const int wx = q.ix_nw - s_ox[l], wy = q.iy_nw - s_oy[l];
+          if (wx >= 0 && wx < kWin - 1 && wy >= 0 && wy < kWin - 1) cell = wy * kWin + wx;
+        }
+        T gix = T(0), giy = T(0);
+        for (int c = 0; c < C; ++c) {
+          const GlobalPtr<const T> p = inp + c * plane;
+          const T gOut = gout_px[int64_t(c) * HW] * alpha;
+          if (gOut != T(0)) { // a zero upstream gradient (masked background) adds nothing
+            if (cell >= 0) {
+              T* wp = &s_win[l][c][cell];
+              if (q.o_nw >= 0) lds_add(wp, q.nw * gOut);
+              if (q.o_ne >= 0) lds_add(wp + 1, q.ne * gOut);
+              if (q.o_sw >= 0) lds_add(wp + kWin, q.sw * gOut);
+              if (q.o_se >= 0) lds_add(wp + kWin + 1, q.se * gOut);
+            } else {
+              const GlobalPtr<T> gp = ginp + c * plane;
+              if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * gOut);
+              if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * gOut);
+              if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * gOut);
+              if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gOut);
+            }
+          }
+          if (q.o_nw >= 0) {
+            const T val = p[q.o_nw];
+            gix -= val * (iy_se - q.iy) * gOut;
+            giy -= val * (ix_se - q.ix) * gOut;
+          }
+          if (q.o_ne >= 0) {
+            const T val = p[q.o_ne];
+            gix += val * (iy_se - q.iy) * gOut;
+            giy -= val * (q.ix - q.ix_nw) * gOut;
+          }
+          if (q.o_sw >= 0) {
+            const T val = p[q.o_sw];
+            gix -= val * (q.iy - q.iy_nw) * gOut;
+            giy += val * (ix_se - q.ix) * gOut;
+          }
+          if (q.o_se >= 0) {
+            const T val = p[q.o_se];
+            gix += val * (q.iy - q.iy_nw) * gOut;
+            giy += val * (q.ix - q.ix_nw) * gOut;
+          }
+        }
+        acc_x += q.mx * gix;
+        acc_y += q.my * giy;
+      }
+    }
+    grad_grid[index * 2 + 0] = acc_x;
+    grad_grid[index * 2 + 1] = acc_y;
+  }
+  __syncthreads();
+  // flush the windows: consecutive threads = consecutive texels of a row; cells that stayed 0 cost nothing,
+  // cells outside the level were never written (only in-bounds corners are accumulated)
+  for (int l = 0; l < kWinLevels; ++l) {
+    const int d = ref + l;
+    if (d >= mipmaps || s_ox[l] == INT32_MAX) continue;
+    const int h = s_h[d], w = s_w[d];
+    const int64_t plane = int64_t(h) * w;
+    const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+    for (int c = 0; c < C; ++c) {
+      for (int i = tid; i < kWin * kWin; i += kBlock) {
+        const T val = s_win[l][c][i];
+        if (val != T(0)) {
+          const int gx = s_ox[l] + (i & (kWin - 1)), gy = s_oy[l] + i / kWin;
+          atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx, val);
+        }
+      }
+    }
+  }
+}
+
 int fill_table(
     LevelTable& lv, const void* const* levels, void* const* grad_levels, const int64_t* level_h,
     const int64_t* level_w, int mipmaps, int64_t N, int64_t C) {
@@ -566,6 +729,16 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   const int64_t count = N * H * W;
   if (count == 0) return DRTK_OK;
   if (!grid || !vt_dxdy_img || !grad_grid || (C > 0 && !grad_out)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !(debug_flags() & 512)) {
+    const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileW));
+    hipLaunchKernelGGL(
+        (mipmap_backward_tiled_kernel<float>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)),
+        dim3(kBlock), 0, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid),
+        static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, padding_mode, align_corners != 0,
+        force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid));
+    DRTK_RETURN_IF_LAUNCH_FAILED();
+    return DRTK_OK;
+  }
   const dim3 grid_dim(static_cast<unsigned>(ceil_div(count, kBlock)));
 #define LAUNCH(T, MODE)                                                                                       \
   hipLaunchKernelGGL(                                                                                         \
