@@ -603,9 +603,9 @@ __global__ __launch_bounds__(kBlock) void edge_scatter_pairs_kernel(
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
     int t;
-    prefix4(__popc(hf[r]) + 0, t);
+    prefix4(__popc(hf[r]), t);
     grand += t;
-    prefix4(__popc(vf[r]) + 0, t);
+    prefix4(__popc(vf[r]), t);
     grand += t;
   }
   const int rows_per_group = grand <= kCap ? kRows : 2;
