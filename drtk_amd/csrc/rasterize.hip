@@ -382,9 +382,9 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(
     ntiles = tw * (ty1 - ty0 + 1);
   }
   // per-view mean depth of either orientation (decides which group the raster pass draws first); a
-  // 1-in-8 sample of the workgroups is plenty for that decision and keeps the four same-address
+  // 1-in-64 sample of the workgroups is plenty for that decision and keeps the four same-address
   // atomics per view off the critical path
-  if ((blockIdx.x & 7) == 0) {
+  if ((blockIdx.x & 63) == 0) {
     const bool live = ntiles >= 1;
     float zp = (live && positive) ? z_mean : 0.0f, zn = (live && !positive) ? z_mean : 0.0f;
 #pragma unroll
@@ -506,13 +506,50 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(
   }
   const bool small = ntiles >= 1 && ntiles <= kMaxSmallTiles;
   const int base = n * tiles_per_view;
+  // Slots come from returning atomics, whose latency would be paid once per distinct tile and wave if
+  // they were issued inside the grouping loop.  So: group first (no memory traffic), then let every
+  // group's first lane issue its atomic -- all groups of all four tile slots in flight together -- and
+  // only then hand the results to the group members.
+  const int lane = lane_id();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int t_[kMaxSmallTiles], leader_[kMaxSmallTiles], rank_[kMaxSmallTiles];
+  bool on_[kMaxSmallTiles];
+  unsigned long long base_[kMaxSmallTiles];
+#pragma unroll
   for (int s = 0; s < kMaxSmallTiles; ++s) {
     const bool on = small && s < ntiles;
     const int dy = on ? s / tw : 0;
     const int dx = on ? s - dy * tw : 0;
     const int t = base + (ty0 + dy) * tiles_x + tx0 + dx;
-    const int pos = wave_agg_inc2<false, true>(tile_cursor, t, on, !positive); // low: positive, high: negative
-    if (on) pairs[positive ? tile_offset[t] + pos : tile_offset[t + 1] - 1 - pos] = f;
+    int leader = lane, rank = 0;
+    unsigned long long add = 0;
+    unsigned long long todo = __ballot(on);
+    while (todo) {
+      const int ld = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+      const int k = __builtin_amdgcn_readlane(t, ld);
+      const bool mine = on && t == k;
+      const unsigned long long same = __ballot(mine);
+      const unsigned long long same_neg = __ballot(mine && !positive);
+      const unsigned long long same_pos = same & ~same_neg;
+      if (mine) {
+        leader = ld;
+        rank = positive ? __popcll(same_pos & below) : __popcll(same_neg & below);
+        add = static_cast<unsigned long long>(__popcll(same_pos)) | (static_cast<unsigned long long>(__popcll(same_neg)) << 32);
+      }
+      todo &= ~same;
+    }
+    on_[s] = on, t_[s] = t, leader_[s] = leader, rank_[s] = rank;
+    base_[s] = 0;
+    if (on && lane == leader) base_[s] = atomicAdd(tile_cursor + t, add); // low word: positive cursor, high: negative
+  }
+#pragma unroll
+  for (int s = 0; s < kMaxSmallTiles; ++s) {
+    const unsigned lo = __shfl(static_cast<unsigned>(base_[s] & 0xFFFFFFFFull), leader_[s]);
+    const unsigned hi = __shfl(static_cast<unsigned>(base_[s] >> 32), leader_[s]);
+    if (on_[s]) {
+      const int pos = static_cast<int>(positive ? lo : hi) + rank_[s];
+      pairs[positive ? tile_offset[t_[s]] + pos : tile_offset[t_[s] + 1] - 1 - pos] = f;
+    }
   }
 }
 
