@@ -333,6 +333,26 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
     }
   };
 
+  // A wave whose 64 x 4 pixels are all background (43 % of them at the benchmark's coverage) has nothing to
+  // scatter: it zeroes its part of bary_grad and leaves.
+  {
+    int32_t t4[kPasses];
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) t4[ps] = load_tr(ps);
+    const bool any_fg = (t4[0] & t4[1] & t4[2] & t4[3]) != -1;
+    if (__ballot(any_fg) == 0) {
+#pragma unroll
+      for (int ps = 0; ps < kPasses; ++ps) {
+        const int y = y0 + ps;
+        if (x < W && y < H) {
+          T* bgp = bgrad_n + int64_t(y) * W + x;
+          bgp[0] = T(0), bgp[HW] = T(0), bgp[2 * HW] = T(0);
+        }
+      }
+      return;
+    }
+  }
+
   for (int c0 = 0; c0 < C; c0 += CH) {
     T G[CH], B[3];
     auto load_row = [&](int ps, bool cov) { // grad_out + bary of row ps; zeros where uncovered
