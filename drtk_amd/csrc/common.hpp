@@ -71,9 +71,44 @@ __device__ __forceinline__ void atomic_add_global(T* p, T v) {
   unsafeAtomicAdd(p, v);
 }
 
+// XCD-aware workgroup -> tile order.  The dispatcher deals workgroups round-robin to the 8 XCDs (block b
+// runs on XCD b % 8), each with its own L2.  If block b simply takes tile b of an image whose channel
+// planes are a power of two apart, every XCD only ever sees one residue class of 4 KB pieces, and all C
+// planes of that piece alias onto the same slice of its L2 / fabric: measured with
+// profiles/micro/plane_remap.hip, 16-plane stores run at 4.1 TB/s and loads at 4.7 TB/s that way, against
+// 6.3 / 6.1 TB/s when each XCD owns strips of consecutive tiles (this mapping), with no change to the data
+// layout; neighbouring tiles on one XCD also keep the shared vertices' gathers and atomics in one L2.
+// `strip` = tiles per strip; bijective on [0, n) for any n and strip >= 1 (the last partial group is split
+// evenly, leftovers map to themselves).
+__device__ __forceinline__ int xcd_tile(int b, int n, int strip) {
+  constexpr int kXcds = 8;
+  const int group = kXcds * strip;
+  const int base = b / group * group;
+  const int r = b - base;
+  const int left = n - base;
+  if (left >= group) return base + (r % kXcds) * strip + r / kXcds;
+  const int s = left / kXcds;
+  if (r < s * kXcds) return base + (r % kXcds) * s + r / kXcds;
+  return b;
+}
+// blockIdx.x of a 1-D-per-image grid mapped through xcd_tile.  `strip` comes from xcd_strip() on the host;
+// 1 keeps the linear order.
+__device__ __forceinline__ int tile_index(int strip) {
+  const int b = static_cast<int>(blockIdx.x);
+  return strip <= 1 ? b : xcd_tile(b, static_cast<int>(gridDim.x), strip);
+}
+
 // Diagnostics only (profiles/*.py): bit mask that lets single phases of a kernel be switched off to
 // attribute time.  0 in normal operation.
 int debug_flags();
+// Strip length for tile_index(): the tiles of 16 consecutive image rows (128 KB of every float plane at
+// W = 2048 -- strips of 64 to 256 KB measured best for every planar kernel, profiles/kernel_bench.py
+// --flags).  Diagnostics: debug flags >> 10 override it (1 = linear order).
+inline int xcd_strip(int64_t tiles_per_16_rows) {
+  const int forced = debug_flags() >> 10;
+  if (forced) return forced;
+  return tiles_per_16_rows < 2 ? 2 : static_cast<int>(tiles_per_16_rows);
+}
 
 // Compute units of the current device (cached per device id).
 int num_compute_units();

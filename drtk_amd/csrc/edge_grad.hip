@@ -72,10 +72,11 @@ __device__ __forceinline__ Row<T, VEC> load_row(
 template <typename T, int VEC, int R, int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
     const T* __restrict__ img, const T* __restrict__ grad_output, const int32_t* __restrict__ index_img, int C,
-    int H, int W, int strips_x, T* __restrict__ gdx, T* __restrict__ gdy) {
+    int H, int W, int strips_x, T* __restrict__ gdx, T* __restrict__ gdy, int strip) {
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
-  const int by = blockIdx.x / strips_x, sx = blockIdx.x - by * strips_x;
+  const int tile = tile_index(strip);
+  const int by = tile / strips_x, sx = tile - by * strips_x;
   const int lane = threadIdx.x & (kWave - 1);
   const int y0 = (by * WAVES + threadIdx.x / kWave) * R;
   if (y0 >= H) return;
@@ -405,7 +406,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
     const T* __restrict__ v_pix, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ gdx, const T* __restrict__ gdy,
-    int64_t V, int64_t vi_sN, int H, int W, T M, T* __restrict__ out) {
+    int64_t V, int64_t vi_sN, int H, int W, T M, T* __restrict__ out, int strip) {
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPix = kWave * 4;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-  const int64_t wave_pix0 = (int64_t(blockIdx.x) * kWaves + wave) * kPix;
+  const int64_t wave_pix0 = (int64_t(tile_index(strip)) * kWaves + wave) * kPix;
   if (wave_pix0 >= HW) return;
   const int64_t pix0 = wave_pix0 + lane * 4;
   const bool in_range = pix0 < HW;
@@ -528,7 +529,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void edge_scatter_pairs_kernel(
     const T* __restrict__ v_pix, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ bary_img, const T* __restrict__ gdx, const T* __restrict__ gdy, int64_t V, int64_t vi_sN,
-    int H, int W, int strips_x, T M, T* __restrict__ grad_v_pix) {
+    int H, int W, int strips_x, T M, T* __restrict__ grad_v_pix, int strip) {
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kRows = 4;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void edge_scatter_pairs_kernel(
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-  const int wg = blockIdx.x * kWaves + wave;
+  const int wg = tile_index(strip) * kWaves + wave;
   const int ry = wg / strips_x, sx = wg - ry * strips_x;
   const int y_base = ry * kRows;
   if (y_base >= H) return;
@@ -727,16 +728,16 @@ int edge_grad_backward_impl(
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
   if (vec) {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
   } else {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   const bool vec_out = vec && (reinterpret_cast<uintptr_t>(index_img) % 16 == 0) &&
       (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0);
   if (vec_out) {
     const dim3 gridB(static_cast<unsigned>(ceil_div(HW, kBlock * 4)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((edge_gather4_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out);
+    hipLaunchKernelGGL((edge_gather4_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out, xcd_strip(ceil_div(16 * W, kBlock * 4)));
   } else {
     const dim3 gridB(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
     hipLaunchKernelGGL((edge_gather_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out);
@@ -753,9 +754,9 @@ int launch_edge_dots(const T* img, const T* grad_output, const int32_t* index_im
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
   if (vec) {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
   } else {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy);
+    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
@@ -786,7 +787,7 @@ int edge_grad_backward_fused_impl(
     const int strips_x = static_cast<int>(ceil_div(W, kWave * 4));
     const int64_t waves = int64_t(strips_x) * ceil_div(H, 4);
     const dim3 grid(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((edge_scatter_pairs_kernel<T>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix);
+    hipLaunchKernelGGL((edge_scatter_pairs_kernel<T>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, xcd_strip(ceil_div(int64_t(strips_x) * 4, kBlock / kWave)));
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;
   }

@@ -29,11 +29,11 @@ template <typename T, int VEC, int CV>
 __global__ __launch_bounds__(kBlock) void interpolate_kernel(
     const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
-    int64_t vi_sN, int H, int W, T* __restrict__ out, int zero_background) {
+    int64_t vi_sN, int H, int W, T* __restrict__ out, int zero_background, int strip) {
   using V4 = typename Vec4<T>::type;
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
-  const int64_t pix0 = (int64_t(blockIdx.x) * kBlock + threadIdx.x) * VEC;
+  const int64_t pix0 = (int64_t(tile_index(strip)) * kBlock + threadIdx.x) * VEC;
   if (pix0 >= HW) return;
   const T* attrs_n = attrs + int64_t(n) * V * C;
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
-    int dbg) {
+    int dbg, int strip) {
   using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPasses = kTileRows / kWaves;
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
-  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int tile = tile_index(strip);
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int wave = threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   const int x = txi * kWave + lane;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
-    int dbg) {
+    int dbg, int strip) {
   using V4 = typename Vec4<T>::type;
   constexpr int CH = 16;
   constexpr int kWaves = kBlock / kWave;
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
-  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int tile = tile_index(strip);
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int wave = threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   const int x = txi * kWave + lane;
@@ -469,7 +471,8 @@ int interpolate_impl(
   hipLaunchKernelGGL(                                                                           \
       (interpolate_kernel<T, VEC, CV>),                                                         \
       dim3(static_cast<unsigned>(ceil_div(HW / VEC, kBlock)), static_cast<unsigned>(N)), block, \
-      0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out, zero_background)
+      0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out, zero_background, \
+      xcd_strip(ceil_div(16 * W, int64_t(kBlock) * VEC)))
   if (pvec && cvec)
     LAUNCH(4, 4);
   else if (pvec)
@@ -501,11 +504,12 @@ int interpolate_backward_impl(
   const int tiles_x = static_cast<int>(ceil_div(W, kWave)), tiles_y = static_cast<int>(ceil_div(H, kTileRows));
   const dim3 grid(static_cast<unsigned>(int64_t(tiles_x) * tiles_y), static_cast<unsigned>(N));
   const dim3 block(kBlock);
+  const int strip = xcd_strip(int64_t(tiles_x) * (16 / kTileRows));
 #define LAUNCH(HV, HB, CV, CH)                                                                  \
   hipLaunchKernelGGL(                                                                           \
       (interpolate_backward_kernel<T, HV, HB, CV, CH>), grid, block, 0, stream, grad_out, attrs, \
       vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad,  \
-      debug_flags())
+      debug_flags(), strip)
   const bool small_c = C <= 4;
   // float only: the double instantiation would need > 256 VGPRs for the same pipeline
   const bool wide = sizeof(T) == 4 && attr_grad && bary_grad && cvec && (C % 16 == 0) && !(debug_flags() & 128);
@@ -513,7 +517,7 @@ int interpolate_backward_impl(
     if constexpr (sizeof(T) == 4) {
       hipLaunchKernelGGL(
           (interpolate_backward_wide_kernel<T>), grid, block, 0, stream, grad_out, attrs, vi, index_img, bary_img,
-          V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags());
+          V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip);
     }
   } else if (attr_grad && bary_grad) {
     if (small_c) {

@@ -80,10 +80,10 @@ struct Vec4<double> {
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void render_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
-    int64_t V, int64_t vi_sN, int H, int W, T* __restrict__ depth_img, T* __restrict__ bary_img) {
+    int64_t V, int64_t vi_sN, int H, int W, T* __restrict__ depth_img, T* __restrict__ bary_img, int strip) {
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
-  const int64_t pix0 = (int64_t(blockIdx.x) * kBlock + threadIdx.x) * VEC; // pixel within the view
+  const int64_t pix0 = (int64_t(tile_index(strip)) * kBlock + threadIdx.x) * VEC; // pixel within the view
   if (pix0 >= HW) return;
   const T* v_n = v + int64_t(n) * V * 3;
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
@@ -138,7 +138,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock, 6) void render_backward_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ grad_depth_img, const T* __restrict__ grad_bary_img, int64_t V,
-    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ grad_v) {
+    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ grad_v, int strip) {
   constexpr int kWaves = kBlock / kWave;
   __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
   __shared__ int32_t s_vid[kWaves][3 * kRunPad];
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(kBlock, 6) void render_backward_kernel(
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
-  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int tile = tile_index(strip);
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int wave = threadIdx.x / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   const int x = txi * kWave + lane;
@@ -286,10 +287,10 @@ int render_impl(
       (reinterpret_cast<uintptr_t>(bary_img) % (4 * sizeof(T)) == 0);
   if (vec) {
     dim3 grid(static_cast<unsigned>(ceil_div(HW / 4, kBlock)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((render_kernel<T, 4>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img);
+    hipLaunchKernelGGL((render_kernel<T, 4>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img, xcd_strip(ceil_div(16 * W, kBlock * 4)));
   } else {
     dim3 grid(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((render_kernel<T, 1>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img);
+    hipLaunchKernelGGL((render_kernel<T, 1>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img, xcd_strip(ceil_div(16 * W, kBlock)));
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
@@ -307,7 +308,7 @@ int render_backward_impl(
   if (N * HW == 0) return DRTK_OK;
   const int tiles_x = static_cast<int>(ceil_div(W, kWave)), tiles_y = static_cast<int>(ceil_div(H, kTileRows));
   dim3 grid(static_cast<unsigned>(int64_t(tiles_x) * tiles_y), static_cast<unsigned>(N));
-  hipLaunchKernelGGL((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, tiles_x, grad_v);
+  hipLaunchKernelGGL((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, tiles_x, grad_v, xcd_strip(int64_t(tiles_x) * (16 / kTileRows)));
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }

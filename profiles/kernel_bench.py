@@ -21,6 +21,7 @@ ap.add_argument("--res", type=int, default=2048)
 ap.add_argument("--channels", type=int, default=16)
 ap.add_argument("--tex", type=int, default=4096)
 ap.add_argument("--uvscale", type=float, default=1.0)
+ap.add_argument("--flags", default="0", help="comma list of drtk_amd_debug_set_flags values to time every kernel under")
 a = ap.parse_args()
 dev = "cuda:0"
 nl, no = S.MESH_SIZES[a.mesh]
@@ -71,17 +72,20 @@ if "mipmap" in a.only:
     kernels["mipmap_bwd_bicubic"] = lambda: capi.mipmap_grid_sampler_2d_backward(gmo, tex, uvn, jac, 8, 1, 2)
     kernels["torch_grid_sample_fwd"] = lambda: th.nn.functional.grid_sample(tex[0], uvn, mode="bilinear", padding_mode="border", align_corners=False)
 th.cuda.synchronize()
-for name, fn in kernels.items():
-    if a.only and name not in a.only.split(","):
-        continue
-    ev0, ev1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-    fn()
-    ev0.record()
-    for _ in range(a.reps):
+for flags in [int(x) for x in a.flags.split(",")]:
+    capi.lib().drtk_amd_debug_set_flags(flags)
+    for name, fn in kernels.items():
+        if a.only and name not in a.only.split(","):
+            continue
+        ev0, ev1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         fn()
-    ev1.record()
-    th.cuda.synchronize()
-    print(f"{name}: {ev0.elapsed_time(ev1) / a.reps:.3f} ms")
+        ev0.record()
+        for _ in range(a.reps):
+            fn()
+        ev1.record()
+        th.cuda.synchronize()
+        print(f"{name}{'' if flags == 0 else f' [flags={flags}]'}: {ev0.elapsed_time(ev1) / a.reps:.3f} ms")
+capi.lib().drtk_amd_debug_set_flags(0)
 
 if os.environ.get("DRTK_ABLATE"):
     L = capi.lib()
