@@ -310,12 +310,12 @@ constexpr int kChBlock = 4; // channels accumulated in registers per sweep over 
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grid, const T* __restrict__ vt, int64_t count, int C,
-    int64_t HW, int max_aniso, int padding, bool force_max_aniso, bool clip_grad, T* __restrict__ out) {
+    int64_t HW, int max_aniso, int padding, bool force_max_aniso, bool clip_grad, T* __restrict__ out, int strip) {
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
   stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
-  const int64_t index = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t index = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
   if (index >= count) return;
   const int64_t n = index / HW;
   const bool align_corners = false; // mipmap_grid_sampler_kernel.cu:423
@@ -402,12 +402,12 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid,
     const T* __restrict__ vt, int64_t count, int C, int64_t HW, int max_aniso, int padding, bool align_corners,
-    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid) {
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, int strip) {
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
   stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
-  const int64_t index = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t index = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
   if (index >= count) return;
   const int64_t n = index / HW;
   const Taps<T> t = setup_taps<T>(grid, vt, index, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
@@ -513,7 +513,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid,
     const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso, int padding, bool align_corners,
-    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid) {
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, int strip) {
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
@@ -527,7 +527,8 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   __syncthreads();
 
   const int n = blockIdx.y;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int tile = tile_index(strip);
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileW + tid / kTileW;
   const bool valid = px < W && py < H;
   const int64_t HW = int64_t(H) * W;
@@ -695,7 +696,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
   hipLaunchKernelGGL(                                                                                     \
       (mipmap_forward_kernel<T, MODE>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grid), \
       static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, force_max_aniso != 0,  \
-      clip_grad != 0, static_cast<T*>(out))
+      clip_grad != 0, static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
   if (dtype == DRTK_F32) {
     if (interpolation_mode == 0) LAUNCH(float, 0); else LAUNCH(float, 2);
   } else {
@@ -735,7 +736,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
         (mipmap_backward_tiled_kernel<float>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)),
         dim3(kBlock), 0, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid),
         static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, padding_mode, align_corners != 0,
-        force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid));
+        force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), xcd_strip(tiles_x));
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;
   }
@@ -744,7 +745,8 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   hipLaunchKernelGGL(                                                                                         \
       (mipmap_backward_kernel<T, MODE>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grad_out), \
       static_cast<const T*>(grid), static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, \
-      align_corners != 0, force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid))
+      align_corners != 0, force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid),                       \
+      xcd_strip(ceil_div(16 * W, kBlock)))
   if (dtype == DRTK_F32) {
     if (interpolation_mode == 0) LAUNCH(float, 0); else LAUNCH(float, 2);
   } else {

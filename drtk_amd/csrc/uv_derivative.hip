@@ -21,9 +21,9 @@ __global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
     const T* __restrict__ v, int64_t v_sN, const T* __restrict__ vt, int64_t vt_sN,
     const int32_t* __restrict__ vi, const int32_t* __restrict__ vti, const int32_t* __restrict__ index_img,
     const T* __restrict__ bary_img, const uint8_t* __restrict__ mask, const T* __restrict__ campos,
-    const T* __restrict__ camrot, const T* __restrict__ focal, int64_t HW, T* __restrict__ out) {
+    const T* __restrict__ camrot, const T* __restrict__ focal, int64_t HW, T* __restrict__ out, int strip) {
   const int n = blockIdx.y;
-  const int64_t pix = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t pix = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
   if (pix >= HW) return;
   const int32_t tr = index_img[int64_t(n) * HW + pix];
   T o00 = T(0), o01 = T(0), o10 = T(0), o11 = T(0);
@@ -123,13 +123,13 @@ extern "C" int drtk_amd_screen_space_uv_derivative(
         (uv_derivative_kernel<float>), grid, dim3(kBlock), 0, s, static_cast<const float*>(v), v_sN,
         static_cast<const float*>(vt), vt_sN, vi, vti, index_img, static_cast<const float*>(bary_img), mask,
         static_cast<const float*>(campos), static_cast<const float*>(camrot), static_cast<const float*>(focal), H * W,
-        static_cast<float*>(out));
+        static_cast<float*>(out), xcd_strip(ceil_div(16 * W, kBlock)));
   } else {
     hipLaunchKernelGGL(
         (uv_derivative_kernel<double>), grid, dim3(kBlock), 0, s, static_cast<const double*>(v), v_sN,
         static_cast<const double*>(vt), vt_sN, vi, vti, index_img, static_cast<const double*>(bary_img), mask,
         static_cast<const double*>(campos), static_cast<const double*>(camrot), static_cast<const double*>(focal),
-        H * W, static_cast<double*>(out));
+        H * W, static_cast<double*>(out), xcd_strip(ceil_div(16 * W, kBlock)));
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
