@@ -26,7 +26,20 @@ struct RenderPix {
   T depth_inverse, depth_inverse_eps, depth;
 };
 
-template <typename T>
+// EXACT = true: IEEE divisions (the forward's outputs are compared bit for bit).  EXACT = false (backward,
+// float): a * rcp(b), 1-2 ulp -- the gradients are sums of thousands of such terms accumulated in
+// arbitrary order and are compared at 1e-5, and the backward kernel is bound by instruction issue
+// (an IEEE float division is a 10-instruction sequence, 12 of them per pixel).
+template <bool EXACT, typename T>
+__device__ __forceinline__ T quotient(T a, T b) {
+  if constexpr (!EXACT && sizeof(T) == 4) {
+    return a * __builtin_amdgcn_rcpf(b);
+  } else {
+    return a / b;
+  }
+}
+
+template <typename T, bool EXACT = true>
 __device__ __forceinline__ void render_pix(
     const T* __restrict__ v_n, int32_t vi0, int32_t vi1, int32_t vi2, int x, int y, RenderPix<T>& r) {
   r.vi0 = vi0;
@@ -48,8 +61,8 @@ __device__ __forceinline__ void render_pix(
   r.vp0y = static_cast<T>(y) - p0y;
   const T b1_pre = r.vp0x * r.v02y - r.vp0y * r.v02x;
   const T b2_pre = r.vp0y * r.v01x - r.vp0x * r.v01y;
-  r.b1 = b1_pre / r.den;
-  r.b2 = b2_pre / r.den;
+  r.b1 = quotient<EXACT>(b1_pre, r.den);
+  r.b2 = quotient<EXACT>(b2_pre, r.den);
   r.b0 = T(1.0) - r.b1 - r.b2;
   r.z0e = epsclamp(p0z);
   r.z1e = epsclamp(p1z);
@@ -57,12 +70,12 @@ __device__ __forceinline__ void render_pix(
   r.z0c = r.z0e != p0z;
   r.z1c = r.z1e != p1z;
   r.z2c = r.z2e != p2z;
-  r.dinv0 = T(1.0) / r.z0e;
-  r.dinv1 = T(1.0) / r.z1e;
-  r.dinv2 = T(1.0) / r.z2e;
+  r.dinv0 = quotient<EXACT>(T(1.0), r.z0e);
+  r.dinv1 = quotient<EXACT>(T(1.0), r.z1e);
+  r.dinv2 = quotient<EXACT>(T(1.0), r.z2e);
   r.depth_inverse = r.dinv0 * r.b0 + r.dinv1 * r.b1 + r.dinv2 * r.b2;
   r.depth_inverse_eps = epsclamp(r.depth_inverse);
-  r.depth = T(1.0) / r.depth_inverse_eps;
+  r.depth = quotient<EXACT>(T(1.0), r.depth_inverse_eps);
 }
 
 template <typename T>
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(kBlock, 6) void render_backward_kernel(
 
     if (tr != -1) {
       RenderPix<T> r;
-      render_pix<T>(v_n, cur[0], cur[1], cur[2], x, y, r);
+      render_pix<T, false>(v_n, cur[0], cur[1], cur[2], x, y, r);
       vid[0] = r.vi0;
       vid[1] = r.vi1;
       vid[2] = r.vi2;
@@ -210,22 +223,22 @@ __global__ __launch_bounds__(kBlock, 6) void render_backward_kernel(
       const T dL_depth = grad_depth_img[int64_t(n) * HW + pix] + dL_B0 * r.dinv0 * r.b0 +
           dL_B1 * r.dinv1 * r.b1 + dL_B2 * r.dinv2 * r.b2;
       const T dL_dinv_s =
-          dinv_clamped ? T(0) : (-dL_depth / (r.depth_inverse * r.depth_inverse));
+          dinv_clamped ? T(0) : quotient<false>(-dL_depth, r.depth_inverse * r.depth_inverse);
 
       const T dL_dinv0 = dL_B0 * r.b0 * r.depth + dL_dinv_s * r.b0;
       const T dL_dinv1 = dL_B1 * r.b1 * r.depth + dL_dinv_s * r.b1;
       const T dL_dinv2 = dL_B2 * r.b2 * r.depth + dL_dinv_s * r.b2;
-      g[2] = r.z0c ? T(0) : (-dL_dinv0 / (r.z0e * r.z0e));
-      g[5] = r.z1c ? T(0) : (-dL_dinv1 / (r.z1e * r.z1e));
-      g[8] = r.z2c ? T(0) : (-dL_dinv2 / (r.z2e * r.z2e));
+      g[2] = r.z0c ? T(0) : quotient<false>(-dL_dinv0, r.z0e * r.z0e);
+      g[5] = r.z1c ? T(0) : quotient<false>(-dL_dinv1, r.z1e * r.z1e);
+      g[8] = r.z2c ? T(0) : quotient<false>(-dL_dinv2, r.z2e * r.z2e);
 
       const T dL_b0 = dL_B0 * r.dinv0 * r.depth + dL_dinv_s * r.dinv0;
       const T dL_b1 = dL_B1 * r.dinv1 * r.depth + dL_dinv_s * r.dinv1;
       const T dL_b2 = dL_B2 * r.dinv2 * r.depth + dL_dinv_s * r.dinv2;
       const T dL_b12x = -dL_b0 + dL_b1;
       const T dL_b12y = -dL_b0 + dL_b2;
-      const T prex = dL_b12x / r.den;
-      const T prey = dL_b12y / r.den;
+      const T prex = quotient<false>(dL_b12x, r.den);
+      const T prey = quotient<false>(dL_b12y, r.den);
       const T dL_den = den_clamped ? T(0) : -(prex * r.b1 + prey * r.b2);
 
       const T dL_vp0x = prex * r.v02y - prey * r.v01y;
