@@ -265,6 +265,48 @@ def test_full_size_properties(cfg):
     assert th.isfinite(gv).all()
 
 
+@pytest.mark.parametrize("cfg", [("100k", 2048, 16), ("250k", 2048, 16), ("1M", 4096, 4)])
+def test_full_size_view_matches_oracle(cfg):
+    """One view of BASELINE.json configs[2], [3] and [4] at FULL resolution against the CPU oracle (all host
+    threads; it finishes in seconds for one view): index_img and rasterize depth bit-exact, render /
+    interpolate forward and all four backward passes at the 1e-5 bar."""
+    import oracle as O
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    mesh, res, C = cfg
+    nl, no = S.MESH_SIZES[mesh]
+    v, vi = S.sphere_views(1, nl, no, res, res, lobes=0.05)
+    g = th.Generator().manual_seed(11)
+    attr = th.rand(1, v.shape[1], C, generator=g)
+    go = th.rand(1, C, res, res, generator=g) * 2 - 1
+    gd = th.rand(1, res, res, generator=g) * 2 - 1
+    gbar = th.rand(1, 3, res, res, generator=g) * 2 - 1
+
+    d_o, i_o = O.rasterize(v, vi, res, res, nthreads=0)
+    d_g, i_g = capi.rasterize(dev(v), dev(vi), res, res)
+    assert th.equal(i_g.cpu(), i_o) and th.equal(d_g.cpu(), d_o)
+    assert int((i_o >= 0).sum()) > 0.4 * res * res
+    rd_o, rb_o = O.render(v, vi, i_o, nthreads=0)
+    rd_g, rb_g = capi.render(dev(v), dev(vi), i_g)
+    close(rd_g, rd_o, "render depth")
+    close(rb_g, rb_o, "render bary")
+    img_o = O.interpolate(attr, vi, i_o, rb_o, nthreads=0)
+    close(capi.interpolate(dev(attr), dev(vi), i_g, dev(rb_o)), img_o, "interpolate")
+    close(capi.render_backward(dev(v), dev(vi), i_g, dev(gd), dev(gbar)),
+          O.render_backward(v, vi, i_o, gd, gbar, nthreads=0), "render backward", atol=1e-4)
+    ag_o, bg_o = O.interpolate_backward(go, attr, vi, i_o, rb_o, nthreads=0)
+    ag_g, bg_g = capi.interpolate_backward(dev(go), dev(attr), dev(vi), i_g, dev(rb_o))
+    close(ag_g, ag_o, "attr grad", atol=1e-4)
+    close(bg_g, bg_o, "bary grad")
+    img = img_o * (i_o != -1)[:, None]
+    eg_o = O.edge_grad_backward(v, img, i_o, vi, go, nthreads=0)
+    close(capi.edge_grad_backward(dev(v), dev(img), i_g, dev(vi), dev(go)), eg_o, "edge grad")
+    vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False, nthreads=0)
+    close(capi.edge_grad_backward_fused(dev(v), dev(img), i_g, dev(vi), dev(rb_o), dev(go)), vg_o,
+          "fused edge grad", atol=1e-4)
+
+
 @pytest.mark.parametrize("dtype", [th.float32, th.float64])
 def test_exact_division_matches_ieee(dtype):
     """The rasterizer divides by |denominator| through a precomputed reciprocal + two fused
