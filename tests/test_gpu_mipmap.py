@@ -192,3 +192,60 @@ def test_uv_derivative_equals_finite_differences_of_the_uv_image():
     err = (jac[:, 1:-1, :, 1, :] - fdy).abs()[same_y]
     assert float(err.max()) < 2e-2 * scale and float(err.mean()) < 1e-3 * scale
     assert float(jac[~mask].abs().sum()) == 0.0
+
+
+def test_textured_shading_with_fp16_attributes_under_autocast():
+    """BASELINE.json configs[4] in small: rasterize -> render -> interpolate(uv) -> uv Jacobian ->
+    mipmap_grid_sample -> edge_grad_estimator with the uv attributes and the texture pyramid stored in
+    fp16, run under autocast.  Like the reference (Autocast keys: cached_cast to float32 at every op,
+    interpolate_module.cpp:584-600, mipmap_grid_sampler_module.cpp autocast wrapper) the ops compute in f32:
+    outputs equal the f32 pipeline on the same (fp16-representable) values bit for bit, and the leaves
+    receive fp16 gradients equal to the rounded f32 ones."""
+    import drtk_amd
+    from drtk_amd import synthetic as S
+
+    N, H, W = 2, 192, 256
+    nl, no = 24, 28
+    v, vi = S.uv_sphere(nl, no, device=DEV)
+    campos, camrot, focal, princpt = S.ring_cameras(N, W, H, device=DEV)
+    vN = v[None].expand(N, -1, -1).contiguous()
+    vid = th.arange(v.shape[0], device=DEV)
+    vt16 = th.stack([(vid % no).float() / no * 0.8 + 0.1, (vid // no).float() / nl * 0.8 + 0.1], -1)[None].expand(N, -1, -1).half()
+    g = th.Generator(device=DEV).manual_seed(2)
+    tex16 = [th.rand(N, 3, 64, 64, device=DEV, generator=g).half()]
+    while tex16[-1].shape[-1] > 4:
+        tex16.append(th.nn.functional.avg_pool2d(tex16[-1].float(), 2).half())
+
+    def pipeline(vt, tex, v_in, autocast):
+        with th.autocast("cuda", dtype=th.float16, enabled=autocast):
+            v_pix = drtk_amd.transform(v_in, campos, camrot, focal, princpt)
+            index = drtk_amd.rasterize(v_pix, vi, H, W)
+            _, bary = drtk_amd.render(v_pix, vi, index)
+            uv = drtk_amd.interpolate(vt, vi, index, bary)
+            mask = index != -1
+            jac = drtk_amd.screen_space_uv_derivative(v_in, vt.float(), vi, vi, index, bary, mask, campos, camrot, focal)
+            grid = (uv.permute(0, 2, 3, 1) * 2 - 1) * mask[..., None]
+            img = drtk_amd.mipmap_grid_sample(tex, grid, jac, 4, padding_mode="border") * mask[:, None]
+            img = drtk_amd.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary, img=img, index_img=index)
+            return index, uv, img
+
+    vt_h = vt16.clone().requires_grad_(True)
+    tex_h = [t.clone().requires_grad_(True) for t in tex16]
+    v_h = vN.clone().requires_grad_(True)
+    index_h, uv_h, img_h = pipeline(vt_h, tex_h, v_h, True)
+    assert uv_h.dtype == th.float32 and img_h.dtype == th.float32
+    (img_h.square().mean()).backward()
+
+    vt_f = vt16.float().requires_grad_(True)
+    tex_f = [t.float().requires_grad_(True) for t in tex16]
+    v_f = vN.clone().requires_grad_(True)
+    index_f, uv_f, img_f = pipeline(vt_f, tex_f, v_f, False)
+    (img_f.square().mean()).backward()
+
+    assert th.equal(index_h, index_f) and th.equal(uv_h, uv_f) and th.equal(img_h, img_f)
+    assert int((index_f != -1).sum()) > 0.3 * index_f.numel() and float(img_f.detach().abs().max()) > 0.1
+    assert vt_h.grad.dtype == th.float16 and all(t.grad.dtype == th.float16 for t in tex_h)
+    close(vt_h.grad, vt_f.grad, "uv attribute gradient", atol=1e-6, rtol=2e-3)  # fp16 rounding of the f32 gradient
+    for a, b in zip(tex_h, tex_f):
+        close(a.grad, b.grad, "texture gradient", atol=1e-7, rtol=2e-3)
+    close(v_h.grad, v_f.grad, "vertex gradient", atol=1e-7, rtol=1e-4)
