@@ -169,7 +169,7 @@ def render_backward(v, vi, index_img, grad_depth_img, grad_bary_img, stream=None
     return grad_v
 
 
-def interpolate(attrs, vi, index_img, bary_img, stream=None):
+def interpolate(attrs, vi, index_img, bary_img, stream=None, masked=False):
     attrs = attrs.contiguous()
     index_img = index_img.contiguous()
     bary_img = bary_img.contiguous()
@@ -177,12 +177,17 @@ def interpolate(attrs, vi, index_img, bary_img, stream=None):
     H, W = index_img.shape[1:]
     vi_c, vi_sN, F = _vi(vi, N)
     out = th.empty(N, C, H, W, dtype=attrs.dtype, device=attrs.device)
+    fn = lib().drtk_amd_interpolate_masked if masked else lib().drtk_amd_interpolate
     _check(
-        lib().drtk_amd_interpolate(
-            ctypes.c_int(_dt(attrs)), _p(attrs), _p(vi_c), _p(index_img), _p(bary_img), _i(N), _i(V), _i(C), _i(F),
-            _i(vi_sN), _i(H), _i(W), _p(out), _stream(attrs, stream)),
-        "interpolate")
+        fn(ctypes.c_int(_dt(attrs)), _p(attrs), _p(vi_c), _p(index_img), _p(bary_img), _i(N), _i(V), _i(C), _i(F),
+           _i(vi_sN), _i(H), _i(W), _p(out), _stream(attrs, stream)),
+        "interpolate_masked" if masked else "interpolate")
     return out
+
+
+def interpolate_masked(attrs, vi, index_img, bary_img, stream=None):
+    """drtk_amd extension: `interpolate` with the background pixels written as 0 (include/drtk_amd.h)."""
+    return interpolate(attrs, vi, index_img, bary_img, stream, masked=True)
 
 
 def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires_grad=True,

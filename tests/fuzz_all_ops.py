@@ -1,0 +1,122 @@
+"""Randomised sweep of every hot-path op through the C ABI against the CPU oracle (not collected by
+pytest -- run on a GPU box: `python tests/fuzz_all_ops.py --cases 200`; a small fixed subset runs as
+tests/test_gpu_parity.py::test_randomised_shapes).  Shapes are deliberately awkward: widths that are not
+multiples of 4 or 64, heights that are not multiples of the tile rows, single rows/columns, channel
+counts around the kernels' specialisations (1..5, 15..17, 32, 33), f32/f64, shared or per-view topology,
+triangle soups with overdraw as well as meshes."""
+import argparse
+import os
+import sys
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+DEV = "cuda:0"
+
+
+def _close(a, ref, what, atol=1e-5, rtol=1e-5):
+    a = a.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    tol = atol + rtol * float(ref.abs().max()) if ref.numel() else atol
+    err = float((a - ref).abs().max()) if ref.numel() else 0.0
+    assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
+
+
+def make_case(seed):
+    g = th.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(th.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    N = r(1, 3)
+    H = [1, 2, 7, 16, 17, 33, 64, 65, 100, 129, 200][r(0, 10)]
+    W = [1, 3, 4, 5, 8, 63, 64, 66, 100, 127, 130, 256, 258, 323][r(0, 13)]
+    C = [1, 2, 3, 4, 5, 8, 15, 16, 17, 32, 33][r(0, 10)]
+    dtype = th.float64 if r(0, 3) == 0 else th.float32
+    kind = r(0, 2)
+    if kind == 0:  # triangle soup with overdraw, slivers, ties
+        ntri = r(1, 400)
+        ctr = th.rand(N, ntri, 1, 2, generator=g) * th.tensor([W + 10.0, H + 10.0]) - 5.0
+        xy = ctr + (th.rand(N, ntri, 3, 2, generator=g) - 0.5) * float(r(2, max(3, max(H, W))))
+        z = 1.5 + th.randint(0, 3, (N, ntri, 1, 1), generator=g).float() + th.rand(N, ntri, 3, 1, generator=g) * 0.3
+        z[:, ::5] = 2.25
+        v = th.cat([xy, z], -1).reshape(N, ntri * 3, 3)
+        vi = th.arange(ntri * 3, dtype=th.int32).view(ntri, 3)
+    else:  # projected sphere(s): shared vertices -> vertex-gradient merging paths
+        from drtk_amd import synthetic as S
+
+        v, vi = S.sphere_views(N, r(3, 24), r(3, 30), H, W, lobes=0.1 * r(0, 2), second_sphere=(kind == 2))
+    batched_vi = r(0, 3) == 0
+    if batched_vi:
+        vi = vi[None].repeat(N, 1, 1)
+        if N > 1:  # different topology per view: reverse the winding of view 1
+            vi[1] = vi[1].flip(-1)
+    v = v.to(dtype).contiguous()
+    attr = th.rand(N, v.shape[1], C, generator=g).to(dtype)
+    go = (th.rand(N, C, H, W, generator=g) * 2 - 1).to(dtype)
+    gd = (th.rand(N, H, W, generator=g) * 2 - 1).to(dtype)
+    gb = (th.rand(N, 3, H, W, generator=g) * 2 - 1).to(dtype)
+    return dict(N=N, H=H, W=W, C=C, dtype=dtype, kind=kind, batched_vi=batched_vi, v=v, vi=vi.contiguous(), attr=attr,
+                go=go, gd=gd, gb=gb)
+
+
+def run_case(c):
+    import oracle as O
+    from drtk_amd import capi
+
+    d = lambda x: x.to(DEV)  # noqa: E731
+    v, vi, H, W = c["v"], c["vi"], c["H"], c["W"]
+    tight = c["dtype"] == th.float64
+    d_o, i_o = O.rasterize(v, vi, H, W, nthreads=0)
+    d_g, i_g = capi.rasterize(d(v), d(vi), H, W)
+    assert th.equal(i_g.cpu(), i_o), "index_img"
+    assert th.equal(d_g.cpu(), d_o), "rasterize depth"
+    rd_o, rb_o = O.render(v, vi, i_o, nthreads=0)
+    rd_g, rb_g = capi.render(d(v), d(vi), i_g)
+    assert th.equal(rd_g.cpu(), rd_o) and th.equal(rb_g.cpu(), rb_o), "render forward bits"
+    img_o = O.interpolate(c["attr"], vi, i_o, rb_o, nthreads=0)
+    assert th.equal(capi.interpolate(d(c["attr"]), d(vi), i_g, d(rb_o)).cpu(), img_o), "interpolate forward bits"
+    masked = capi.interpolate_masked(d(c["attr"]), d(vi), i_g, d(rb_o)).cpu()
+    assert th.equal(masked, img_o * (i_o != -1)[:, None]), "interpolate_masked"
+    tol = dict(atol=1e-12, rtol=1e-10) if tight else dict(atol=1e-5, rtol=1e-5)
+    _close(capi.render_backward(d(v), d(vi), i_g, d(c["gd"]), d(c["gb"])), O.render_backward(v, vi, i_o, c["gd"], c["gb"]),
+           "render backward", **tol)
+    ag_o, bg_o = O.interpolate_backward(c["go"], c["attr"], vi, i_o, rb_o)
+    ag_g, bg_g = capi.interpolate_backward(d(c["go"]), d(c["attr"]), d(vi), i_g, d(rb_o))
+    _close(ag_g, ag_o, "attr grad", **tol)
+    _close(bg_g, bg_o, "bary grad", **tol)
+    ag_g1, none = capi.interpolate_backward(d(c["go"]), d(c["attr"]), d(vi), i_g, d(rb_o), True, False)
+    assert none is None
+    _close(ag_g1, ag_o, "attr grad (vertex only)", **tol)
+    none, bg_g1 = capi.interpolate_backward(d(c["go"]), d(c["attr"]), d(vi), i_g, d(rb_o), False, True)
+    assert none is None
+    _close(bg_g1, bg_o, "bary grad (bary only)", **tol)
+    img = img_o * (i_o != -1)[:, None]
+    for M in (1e4, 0.5):
+        eg_o = O.edge_grad_backward(v, img, i_o, vi, c["go"], M)
+        _close(capi.edge_grad_backward(d(v), d(img), i_g, d(vi), d(c["go"]), M), eg_o, f"edge grad M={M}", **tol)
+        vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False)
+        _close(capi.edge_grad_backward_fused(d(v), d(img), i_g, d(vi), d(rb_o), d(c["go"]), M), vg_o, f"fused edge grad M={M}",
+               **tol)
+
+
+def describe(c):
+    return (f"N={c['N']} H={c['H']} W={c['W']} C={c['C']} {str(c['dtype']).split('.')[-1]} kind={c['kind']} "
+            f"F={c['vi'].shape[-2]} V={c['v'].shape[1]} batched_vi={c['batched_vi']}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--first", type=int, default=0)
+    a = ap.parse_args()
+    bad = 0
+    for seed in range(a.first, a.first + a.cases):
+        c = make_case(seed)
+        try:
+            run_case(c)
+        except AssertionError as e:
+            bad += 1
+            print(f"FAIL seed {seed}: {describe(c)}: {e}", flush=True)
+    print(f"{a.cases - bad}/{a.cases} cases passed")
+    sys.exit(1 if bad else 0)

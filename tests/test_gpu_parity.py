@@ -586,3 +586,19 @@ def test_interpolate_masked_extension_equals_interpolate_times_mask():
     close(a2.grad, a1.grad, "attr grad (masked extension)")
     close(b2.grad, b1.grad, "bary grad (masked extension)")
     assert float(b2.grad[~mask.expand_as(b2.grad)[:, :3]].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_randomised_shapes(block):
+    """16 seeded cases per block from tests/fuzz_all_ops.py: awkward image sizes (1-pixel rows and columns,
+    widths off every vector / tile multiple), channel counts around the kernels' specialisations, f32 and
+    f64, shared and per-view topology, soups and meshes -- every op against the oracle: forward bits
+    identical, gradients at the 1e-5 bar (1e-10 relative in f64)."""
+    import fuzz_all_ops as F
+
+    for seed in range(16 * block, 16 * block + 16):
+        c = F.make_case(seed)
+        try:
+            F.run_case(c)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
