@@ -249,3 +249,17 @@ def test_textured_shading_with_fp16_attributes_under_autocast():
     for a, b in zip(tex_h, tex_f):
         close(a.grad, b.grad, "texture gradient", atol=1e-7, rtol=2e-3)
     close(v_h.grad, v_f.grad, "vertex gradient", atol=1e-7, rtol=1e-4)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_randomised_mipmap_cases(block):
+    """20 seeded cases per block from tests/fuzz_mipmap.py (odd / non-square textures and outputs, 1..11
+    levels, 1..6 channels, smooth and incoherent uv fields, every mode flag) against the oracle."""
+    import fuzz_mipmap as F
+
+    for seed in range(20 * block, 20 * block + 20):
+        c = F.make_case(seed)
+        try:
+            F.run_case(c)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
