@@ -313,6 +313,9 @@ def main():
             "traffic": measured_traffic(dom) if (args.mesh, H, n_local, C) == ("100k", 2048, 8, 16) else None,
             "algorithmic_bytes": bpp[dom] * P,
             "bytes_per_px": bpp[dom], "ms_per_launch": round(kt[dom], 4),
+            # the op is one C-ABI call = these HIP kernels back to back (names as rocprofv3 prints them in
+            # profiles/rNN/bench_step_kernel_stats.txt; their average durations add up to ms_per_launch)
+            "hip_kernels": OP_KERNELS[dom],
         }
         path = {
             "bytes_per_px": unfused_bpp, "bytes_per_px_fused_route": fused_bpp, "t_ops_ms": round(t_ops, 4),
