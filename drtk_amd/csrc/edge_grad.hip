@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 // barycentrics) through the run reduction of segscatter.hpp with six corner slots (A0..A2, B0..B2) and
 // two components each.
 template <typename T>
-__global__ __launch_bounds__(kBlock, 4) void edge_scatter_pairs_kernel(
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_pairs_kernel(
     const T* __restrict__ v_pix, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ bary_img, const T* __restrict__ gdx, const T* __restrict__ gdy, int64_t V, int64_t vi_sN,
     int H, int W, int strips_x, T M, T* __restrict__ grad_v_pix, int strip) {

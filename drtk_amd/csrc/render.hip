@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
 
 // Backward: a workgroup owns a 64 x 16 pixel tile; each of its 4 waves walks 4 adjacent rows of 64 pixels.
 template <typename T>
-__global__ __launch_bounds__(kBlock, 6) void render_backward_kernel(
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backward_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ grad_depth_img, const T* __restrict__ grad_bary_img, int64_t V,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ grad_v, int strip) {
