@@ -31,6 +31,44 @@ __global__ __launch_bounds__(256) void k(float* buf, long HW, int n, float* sink
   if (!STORE && acc.x + acc.y + acc.z + acc.w == 12345.f) *sink = 1.f;
 }
 
+// interpolate-forward-like mix: read 4 planes (index + 3 bary) of `src`, write 16 planes of `buf`
+template <int R>
+__global__ __launch_bounds__(256) void kmix(float* buf, const float* src, long HW, int n) {
+  float* o = buf + long(blockIdx.y) * 16 * HW;
+  const float* q = src + long(blockIdx.y) * 4 * HW;
+  const int b = blockIdx.x;
+  int c = b;
+  if (R == 4) c = (b % 8) * 64 + (b / 8) % 64 + (b / 512) * 512;
+  const long off = (long(c) * 256 + threadIdx.x) * 4;
+  float4 a = *reinterpret_cast<const float4*>(q + off);
+#pragma unroll
+  for (int p = 1; p < 4; ++p) {
+    const float4 t = *reinterpret_cast<const float4*>(q + long(p) * HW + off);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) *reinterpret_cast<float4*>(o + long(p) * HW + off) = a;
+}
+
+template <int R>
+void runmix(float* buf, const float* src, long N, long HW) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int n = int(HW / 1024);
+  const dim3 grid((unsigned)n, (unsigned)N);
+  hipLaunchKernelGGL((kmix<R>), grid, dim3(256), 0, 0, buf, src, HW, n);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((kmix<R>), grid, dim3(256), 0, 0, buf, src, HW, n);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= 10;
+  printf("mix   load 4 + store 16 planes R%d : %.3f ms  %.2f TB/s\n", R, ms, double(N) * 20 * HW * 4 / ms * 1e-9);
+}
+
 template <bool STORE, int P, int R>
 void run(float* buf, long N, long HW) {
   hipEvent_t e0, e1;
@@ -64,5 +102,10 @@ int main() {
   CK(hipMemset(buf, 0, N * 16 * HW * 4));
   all<true>(buf, N, HW);
   all<false>(buf, N, HW);
+  float* src;
+  CK(hipMalloc(&src, N * 4 * HW * 4));
+  CK(hipMemset(src, 0, N * 4 * HW * 4));
+  runmix<0>(buf, src, N, HW);
+  runmix<4>(buf, src, N, HW);
   return 0;
 }
