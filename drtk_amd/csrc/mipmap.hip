@@ -505,6 +505,17 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
 // ds_add_f32 and flushed once, row-major, so the global atomics are coalesced and each touched texel costs
 // one request per tile instead of one per tap.  Corners outside the window, or on other levels, go to
 // global memory directly, so any uv field is handled.
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
 constexpr int kTileW = 16;  // pixel tile
 constexpr int kWin = 32;    // texel window side
 constexpr int kWinLevels = 3;
@@ -536,7 +547,11 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   Taps<T> t = {};
   if (valid) t = setup_taps<T>(grid, vt, index, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
   const int n_lv = mipmaps > 1 ? 2 : 1;
-  if (valid) atomicMin(&s_ref, t.d1);
+  {
+    // one LDS atomic per wave, not per lane: same-address LDS atomics are served one lane at a time
+    const int d_min = wave_min_i32(valid ? t.d1 : kMaxLevels);
+    if ((tid & (kWave - 1)) == 0) atomicMin(&s_ref, d_min);
+  }
   __syncthreads();
   const int ref = s_ref;
   auto tap_xy = [&](int i, T& x, T& y) {
@@ -546,17 +561,32 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   };
   // window origins: the taps of a pixel are collinear, so their extreme texels are those of the first and
   // the last tap
-  if (valid) {
-    for (int e = 0; e < 2; ++e) {
-      T x, y;
-      tap_xy(e == 0 ? 0 : t.n - 1, x, y);
-      for (int s = 0; s < n_lv; ++s) {
-        const int l = t.d1 + s - ref;
-        if (l < kWinLevels) {
-          const Quad<T> q = bilinear_quad<T>(x, y, s_h[t.d1 + s], s_w[t.d1 + s], padding, align_corners);
-          atomicMin(&s_ox[l], q.ix_nw);
-          atomicMin(&s_oy[l], q.iy_nw);
+  {
+    int lo_x[kWinLevels], lo_y[kWinLevels];
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX;
+    if (valid) {
+      for (int e = 0; e < 2; ++e) {
+        T x, y;
+        tap_xy(e == 0 ? 0 : t.n - 1, x, y);
+        for (int s = 0; s < n_lv; ++s) {
+          const int l = t.d1 + s - ref;
+          if (l < kWinLevels) {
+            const Quad<T> q = bilinear_quad<T>(x, y, s_h[t.d1 + s], s_w[t.d1 + s], padding, align_corners);
+#pragma unroll
+            for (int k = 0; k < kWinLevels; ++k) {
+              if (k == l) lo_x[k] = min(lo_x[k], q.ix_nw), lo_y[k] = min(lo_y[k], q.iy_nw);
+            }
+          }
         }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l) {
+      const int a = wave_min_i32(lo_x[l]), b = wave_min_i32(lo_y[l]);
+      if ((tid & (kWave - 1)) == 0 && a != INT32_MAX) {
+        atomicMin(&s_ox[l], a);
+        atomicMin(&s_oy[l], b);
       }
     }
   }
