@@ -441,25 +441,39 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
             if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * gOut);
             if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gOut);
           }
+          // texel values for the grid gradient: the two texels of a row in one 8-byte load when both exist
+          T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
+          if (gOut != T(0)) { // with a zero upstream gradient every term below is +-0 * finite
+            if (q.o_nw >= 0 && q.o_ne >= 0) {
+              const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_nw);
+              v_nw = t2.x, v_ne = t2.y;
+            } else {
+              if (q.o_nw >= 0) v_nw = p[q.o_nw];
+              if (q.o_ne >= 0) v_ne = p[q.o_ne];
+            }
+            if (q.o_sw >= 0 && q.o_se >= 0) {
+              const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_sw);
+              v_sw = t2.x, v_se = t2.y;
+            } else {
+              if (q.o_sw >= 0) v_sw = p[q.o_sw];
+              if (q.o_se >= 0) v_se = p[q.o_se];
+            }
+          }
           if (q.o_nw >= 0) {
-            const T val = p[q.o_nw];
-            gix -= val * (iy_se - q.iy) * gOut;
-            giy -= val * (ix_se - q.ix) * gOut;
+            gix -= v_nw * (iy_se - q.iy) * gOut;
+            giy -= v_nw * (ix_se - q.ix) * gOut;
           }
           if (q.o_ne >= 0) {
-            const T val = p[q.o_ne];
-            gix += val * (iy_se - q.iy) * gOut;
-            giy -= val * (q.ix - q.ix_nw) * gOut;
+            gix += v_ne * (iy_se - q.iy) * gOut;
+            giy -= v_ne * (q.ix - q.ix_nw) * gOut;
           }
           if (q.o_sw >= 0) {
-            const T val = p[q.o_sw];
-            gix -= val * (q.iy - q.iy_nw) * gOut;
-            giy += val * (ix_se - q.ix) * gOut;
+            gix -= v_sw * (q.iy - q.iy_nw) * gOut;
+            giy += v_sw * (ix_se - q.ix) * gOut;
           }
           if (q.o_se >= 0) {
-            const T val = p[q.o_se];
-            gix += val * (q.iy - q.iy_nw) * gOut;
-            giy += val * (q.ix - q.ix_nw) * gOut;
+            gix += v_se * (q.iy - q.iy_nw) * gOut;
+            giy += v_se * (q.ix - q.ix_nw) * gOut;
           }
         }
         acc_x += q.mx * gix;
@@ -635,25 +649,39 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
               if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gOut);
             }
           }
+          // texel values for the grid gradient: the two texels of a row in one 8-byte load when both exist
+          T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
+          if (gOut != T(0)) { // with a zero upstream gradient every term below is +-0 * finite
+            if (q.o_nw >= 0 && q.o_ne >= 0) {
+              const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_nw);
+              v_nw = t2.x, v_ne = t2.y;
+            } else {
+              if (q.o_nw >= 0) v_nw = p[q.o_nw];
+              if (q.o_ne >= 0) v_ne = p[q.o_ne];
+            }
+            if (q.o_sw >= 0 && q.o_se >= 0) {
+              const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_sw);
+              v_sw = t2.x, v_se = t2.y;
+            } else {
+              if (q.o_sw >= 0) v_sw = p[q.o_sw];
+              if (q.o_se >= 0) v_se = p[q.o_se];
+            }
+          }
           if (q.o_nw >= 0) {
-            const T val = p[q.o_nw];
-            gix -= val * (iy_se - q.iy) * gOut;
-            giy -= val * (ix_se - q.ix) * gOut;
+            gix -= v_nw * (iy_se - q.iy) * gOut;
+            giy -= v_nw * (ix_se - q.ix) * gOut;
           }
           if (q.o_ne >= 0) {
-            const T val = p[q.o_ne];
-            gix += val * (iy_se - q.iy) * gOut;
-            giy -= val * (q.ix - q.ix_nw) * gOut;
+            gix += v_ne * (iy_se - q.iy) * gOut;
+            giy -= v_ne * (q.ix - q.ix_nw) * gOut;
           }
           if (q.o_sw >= 0) {
-            const T val = p[q.o_sw];
-            gix -= val * (q.iy - q.iy_nw) * gOut;
-            giy += val * (ix_se - q.ix) * gOut;
+            gix -= v_sw * (q.iy - q.iy_nw) * gOut;
+            giy += v_sw * (ix_se - q.ix) * gOut;
           }
           if (q.o_se >= 0) {
-            const T val = p[q.o_se];
-            gix += val * (q.iy - q.iy_nw) * gOut;
-            giy += val * (q.ix - q.ix_nw) * gOut;
+            gix += v_se * (q.iy - q.iy_nw) * gOut;
+            giy += v_se * (q.ix - q.ix_nw) * gOut;
           }
         }
         acc_x += q.mx * gix;
