@@ -19,6 +19,8 @@
 // corners), so results match the CPU restatement to rounding of the transcendental log2 only.
 // The forward pass ignores align_corners exactly like the reference (:423 forces it to false);
 // the backward pass honours it (:641 ff).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace drtk_amd {
@@ -533,22 +535,33 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 constexpr int kTileW = 16;  // pixel tile
 constexpr int kWin = 32;    // texel window side
 constexpr int kWinLevels = 3;
+// `dbg` (diagnostics, profiles/kernel_bench.py --flags): 1 = no texture-gradient accumulation, 2 = no texel reads,
+// 4 = no flush.  Ablation at the bench shape: 6.0 ms total, 2.2 without the accumulation, 1.7 without all three --
+// the LDS float atomics (4 per tap, level and channel, neighbouring pixels on the same cells) are the bound.
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid,
     const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso, int padding, bool align_corners,
-    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, int strip) {
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, int strip, int dbg) {
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
   __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels];
-  __shared__ T s_win[kWinLevels][4][kWin * kWin];
+  // windows [level][channel][kWin * kWin], C channels: dynamic LDS sized by the launch (C = 3: 36 KB -> 4 workgroups/CU)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_win_raw[];
+  T* const s_win = reinterpret_cast<T*>(s_win_raw);
+  const int win_lstride = C * kWin * kWin;
   stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
   const int tid = threadIdx.x;
   if (tid == 0) s_ref = kMaxLevels;
   if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
-  for (int i = tid; i < kWinLevels * 4 * kWin * kWin; i += kBlock) (&s_win[0][0][0])[i] = T(0);
+  {
+    using V4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
+    V4* w4 = reinterpret_cast<V4*>(s_win);
+    const V4 z = {T(0), T(0), T(0), T(0)};
+    for (int i = tid; i < kWinLevels * win_lstride / 4; i += kBlock) w4[i] = z;
+  }
   __syncthreads();
 
   const int n = blockIdx.y;
@@ -607,7 +620,15 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   __syncthreads();
 
   if (valid) {
-    const T* gout_px = grad_out + int64_t(n) * C * HW + (int64_t(py) * W + px);
+    // the pixel's upstream gradient, all channels in one batch of loads (C <= 4 here)
+    T go[4] = {T(0), T(0), T(0), T(0)};
+    {
+      const T* gout_px = grad_out + int64_t(n) * C * HW + (int64_t(py) * W + px);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < C) go[c] = gout_px[int64_t(c) * HW];
+      }
+    }
     const T alpha_1 = t.a / t.n;
     const T alpha_2 = static_cast<T>((1.0 - t.a) / t.n);
     T acc_x = T(0), acc_y = T(0);
@@ -631,12 +652,15 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
           if (wx >= 0 && wx < kWin - 1 && wy >= 0 && wy < kWin - 1) cell = wy * kWin + wx;
         }
         T gix = T(0), giy = T(0);
-        for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c >= C) break;
           const GlobalPtr<const T> p = inp + c * plane;
-          const T gOut = gout_px[int64_t(c) * HW] * alpha;
+          const T gOut = go[c] * alpha;
           if (gOut != T(0)) { // a zero upstream gradient (masked background) adds nothing
-            if (cell >= 0) {
-              T* wp = &s_win[l][c][cell];
+            if (dbg & 1) {
+            } else if (cell >= 0) {
+              T* wp = s_win + l * win_lstride + c * (kWin * kWin) + cell;
               if (q.o_nw >= 0) lds_add(wp, q.nw * gOut);
               if (q.o_ne >= 0) lds_add(wp + 1, q.ne * gOut);
               if (q.o_sw >= 0) lds_add(wp + kWin, q.sw * gOut);
@@ -651,7 +675,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
           }
           // texel values for the grid gradient: the two texels of a row in one 8-byte load when both exist
           T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
-          if (gOut != T(0)) { // with a zero upstream gradient every term below is +-0 * finite
+          if (gOut != T(0) && !(dbg & 2)) { // with a zero upstream gradient every term below is +-0 * finite
             if (q.o_nw >= 0 && q.o_ne >= 0) {
               const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_nw);
               v_nw = t2.x, v_ne = t2.y;
@@ -696,16 +720,22 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   // cells outside the level were never written (only in-bounds corners are accumulated)
   for (int l = 0; l < kWinLevels; ++l) {
     const int d = ref + l;
-    if (d >= mipmaps || s_ox[l] == INT32_MAX) continue;
+    if (d >= mipmaps || s_ox[l] == INT32_MAX || (dbg & 4)) continue;
     const int h = s_h[d], w = s_w[d];
     const int64_t plane = int64_t(h) * w;
     const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
     for (int c = 0; c < C; ++c) {
-      for (int i = tid; i < kWin * kWin; i += kBlock) {
-        const T val = s_win[l][c][i];
-        if (val != T(0)) {
-          const int gx = s_ox[l] + (i & (kWin - 1)), gy = s_oy[l] + i / kWin;
-          atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx, val);
+      // four cells per lane and step (one 16-byte LDS read); a row of 32 cells = 8 consecutive lanes
+      using V4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
+      const V4* win4 = reinterpret_cast<const V4*>(s_win + l * win_lstride + c * (kWin * kWin));
+      for (int i4 = tid; i4 < kWin * kWin / 4; i4 += kBlock) {
+        const V4 q = win4[i4];
+        const T vals[4] = {q.x, q.y, q.z, q.w};
+        const int i = i4 * 4;
+        const int gx = s_ox[l] + (i & (kWin - 1)), gy = s_oy[l] + i / kWin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
         }
       }
     }
@@ -792,9 +822,9 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileW));
     hipLaunchKernelGGL(
         (mipmap_backward_tiled_kernel<float>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)),
-        dim3(kBlock), 0, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid),
+        dim3(kBlock), sizeof(float) * kWinLevels * C * kWin * kWin, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid),
         static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, padding_mode, align_corners != 0,
-        force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), xcd_strip(tiles_x));
+        force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), xcd_strip(tiles_x), debug_flags());
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;
   }
