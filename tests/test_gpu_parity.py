@@ -602,3 +602,67 @@ def test_randomised_shapes(block):
             F.run_case(c)
         except AssertionError as e:
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
+
+
+def test_non_contiguous_inputs_and_concurrent_streams():
+    """Boundary conventions of the reference: arbitrary input strides are accepted (the ops make
+    their own contiguous copies where they need them), and the ops are re-entrant -- two Python threads on two
+    streams with different scenes get the results of the sequential calls."""
+    import threading
+
+    import drtk_amd
+    from drtk_amd import synthetic as S
+
+    H, W, C = 96, 128, 5
+    v, vi = S.sphere_views(3, 10, 12, H, W, second_sphere=True, device=DEV)
+    attr = th.rand(3, v.shape[1], C, device=DEV)
+    index = drtk_amd.rasterize(v, vi, H, W)
+    depth, bary = drtk_amd.render(v, vi, index)
+    img = drtk_amd.interpolate(attr, vi, index, bary)
+    # strided views of the same values
+    v_nc = th.empty(3, 3, v.shape[1], device=DEV).copy_(v.permute(0, 2, 1)).permute(0, 2, 1)
+    attr_nc = th.empty(3, C, v.shape[1], device=DEV).copy_(attr.permute(0, 2, 1)).permute(0, 2, 1)
+    bary_nc = th.empty(3, H, W, 3, device=DEV).copy_(bary.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    index_nc = th.empty(3, H, 2 * W, dtype=th.int32, device=DEV)[:, :, ::2].copy_(index)
+    vi_nc = th.empty(3, vi.shape[0], dtype=th.int32, device=DEV).copy_(vi.t()).t()
+    assert not (v_nc.is_contiguous() or attr_nc.is_contiguous() or bary_nc.is_contiguous() or index_nc.is_contiguous()
+                or vi_nc.is_contiguous())
+    assert th.equal(drtk_amd.rasterize(v_nc, vi_nc, H, W), index)
+    d2, b2 = drtk_amd.render(v_nc, vi_nc, index_nc)
+    assert th.equal(d2, depth) and th.equal(b2, bary)
+    assert th.equal(drtk_amd.interpolate(attr_nc, vi_nc, index_nc, bary_nc), img)
+    g = th.rand_like(img)
+    a1 = attr.clone().requires_grad_(True)
+    b1 = bary.clone().requires_grad_(True)
+    (drtk_amd.interpolate(a1, vi, index, b1) * g).sum().backward()
+    a2 = attr_nc.detach().requires_grad_(True)
+    b2 = bary_nc.detach().requires_grad_(True)
+    (drtk_amd.interpolate(a2, vi_nc, index_nc, b2) * g.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)).sum().backward()
+    close(a2.grad, a1.grad, "attr grad through strided inputs")
+    close(b2.grad, b1.grad, "bary grad through strided inputs")
+
+    # two threads, two streams, two scenes
+    scenes = [S.sphere_views(2, 12 + 4 * k, 14 + 3 * k, 160, 192, lobes=0.1 * k, device=DEV) for k in range(2)]
+    want = []
+    for sv, svi in scenes:
+        i0 = drtk_amd.rasterize(sv, svi, 160, 192)
+        want.append((i0, *drtk_amd.render(sv, svi, i0)))
+    th.cuda.synchronize()
+    got = [None, None]
+
+    def work(k):
+        st = th.cuda.Stream()
+        with th.cuda.stream(st):
+            for _ in range(20):
+                i0 = drtk_amd.rasterize(scenes[k][0], scenes[k][1], 160, 192)
+                got[k] = (i0, *drtk_amd.render(scenes[k][0], scenes[k][1], i0))
+        st.synchronize()
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(2):
+        for a, b in zip(got[k], want[k]):
+            assert th.equal(a, b)
