@@ -39,6 +39,38 @@ int num_compute_units() {
   return cached[dev];
 }
 
+namespace {
+// 16-byte words in a grid-stride loop; the (< 16) bytes before the first and after the last aligned word are
+// written by the first threads of the grid.
+__global__ __launch_bounds__(kBlock) void fill_bytes_kernel(
+    unsigned char* __restrict__ p, size_t head, size_t n16, size_t tail, uint32_t word) {
+  const size_t gid = size_t(blockIdx.x) * kBlock + threadIdx.x;
+  const size_t stride = size_t(gridDim.x) * kBlock;
+  uint4* mid = reinterpret_cast<uint4*>(p + head);
+  const uint4 w = make_uint4(word, word, word, word);
+  for (size_t i = gid; i < n16; i += stride) mid[i] = w;
+  if (gid < head) p[gid] = static_cast<unsigned char>(word);
+  if (gid < tail) p[head + 16 * n16 + gid] = static_cast<unsigned char>(word);
+}
+} // namespace
+
+int fill_bytes_async(void* p, int value, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return DRTK_OK;
+  if (!p) return DRTK_ERR_LAUNCH;
+  size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;
+  if (head > bytes) head = bytes;
+  const size_t n16 = (bytes - head) / 16;
+  const size_t tail = bytes - head - 16 * n16;
+  const uint32_t b = static_cast<uint32_t>(value) & 0xFFu;
+  const size_t want = (n16 + kBlock - 1) / kBlock;
+  const size_t cap = size_t(num_compute_units()) * 16;
+  const unsigned blocks = static_cast<unsigned>(want < 1 ? 1 : (want > cap ? cap : want));
+  hipLaunchKernelGGL(fill_bytes_kernel, dim3(blocks), dim3(kBlock), 0, stream, static_cast<unsigned char*>(p), head, n16, tail,
+                     b * 0x01010101u);
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
+}
+
 static int g_debug_flags = 0;
 int debug_flags() {
   return g_debug_flags;

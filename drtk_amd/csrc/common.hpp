@@ -113,6 +113,14 @@ inline int xcd_strip(int64_t tiles_per_16_rows) {
 // Compute units of the current device (cached per device id).
 int num_compute_units();
 
+// memset(p, value, bytes) in stream order, as an ordinary KERNEL launch (any alignment, any size; DRTK_OK or
+// DRTK_ERR_LAUNCH).  The library does not use hipMemsetAsync: captured into a graph (torch.cuda.graph around a
+// training step) its memset node stops doing its job on replays that follow other work on the device -- measured
+// on MI355X / ROCm 7.2 with profiles-style probes: replay 1 of rasterize found pointer-like garbage instead of
+// zeros in its counter block and scattered bins out of bounds (GPU memory fault), while every kernel node of the
+// same graph replayed correctly.  A fill kernel is a kernel node like all the others.
+int fill_bytes_async(void* p, int value, size_t bytes, hipStream_t stream);
+
 inline int64_t ceil_div(int64_t a, int64_t b) {
   return (a + b - 1) / b;
 }

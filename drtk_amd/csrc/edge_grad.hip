@@ -777,7 +777,7 @@ int edge_grad_backward_fused_impl(
     int64_t H, int64_t W, double max_dp_dr, T* grad_v_pix, void* workspace, size_t workspace_bytes,
     hipStream_t stream) {
   const int64_t HW = H * W;
-  if (N * V > 0 && hipMemsetAsync(grad_v_pix, 0, sizeof(T) * N * V * 3, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+  if (N * V > 0 && fill_bytes_async(grad_v_pix, 0, sizeof(T) * N * V * 3, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
   if (N * HW == 0) return DRTK_OK;
   T* gdx = static_cast<T*>(workspace);
   T* gdy = gdx + N * HW;

@@ -194,7 +194,7 @@ extern "C" int drtk_amd_interpolation_matrix_backward(
   const size_t es = dtype == DRTK_F32 ? 4 : 8;
   if (N * H * W > 0) {
     if (!bary_grad) return DRTK_ERR_INVALID_ARGUMENT;
-    if (hipMemsetAsync(bary_grad, 0, es * 3 * N * H * W, s) != hipSuccess) return DRTK_ERR_LAUNCH; // cpu :512
+    if (fill_bytes_async(bary_grad, 0, es * 3 * N * H * W, s) != DRTK_OK) return DRTK_ERR_LAUNCH; // cpu :512
   }
   if (R == 0) return DRTK_OK;
   if (!grad_values || !vi || !index_img || !row_pixels) return DRTK_ERR_INVALID_ARGUMENT;
@@ -216,7 +216,7 @@ extern "C" int drtk_amd_interpolation_normal_matrix_values(
   const size_t es = dtype == DRTK_F32 ? 4 : 8;
   if (nnz > 0) {
     if (!values) return DRTK_ERR_INVALID_ARGUMENT;
-    if (hipMemsetAsync(values, 0, es * nnz, s) != hipSuccess) return DRTK_ERR_LAUNCH; // cpu :586
+    if (fill_bytes_async(values, 0, es * nnz, s) != DRTK_OK) return DRTK_ERR_LAUNCH; // cpu :586
   }
   if (N * H * W == 0 || nnz == 0) return DRTK_OK;
   if (!pair_indices || !index_img || !bary_img) return DRTK_ERR_INVALID_ARGUMENT;

@@ -492,12 +492,12 @@ int interpolate_backward_impl(
     const T* bary_img, int64_t N, int64_t V, int64_t C, int64_t vi_sN, int64_t H, int64_t W,
     T* attr_grad, T* bary_grad, hipStream_t stream) {
   if (attr_grad && N * V * C > 0) {
-    if (hipMemsetAsync(attr_grad, 0, sizeof(T) * N * V * C, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+    if (fill_bytes_async(attr_grad, 0, sizeof(T) * N * V * C, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
   }
   const int64_t HW = H * W;
   if (N * HW == 0) return DRTK_OK;
   if (C == 0) {
-    if (bary_grad && hipMemsetAsync(bary_grad, 0, sizeof(T) * N * 3 * HW, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+    if (bary_grad && fill_bytes_async(bary_grad, 0, sizeof(T) * N * 3 * HW, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
     return DRTK_OK;
   }
   const bool cvec = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(attrs) % (4 * sizeof(T)) == 0);

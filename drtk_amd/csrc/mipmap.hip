@@ -812,7 +812,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
     const size_t bytes = es * N * C * level_h[i] * level_w[i];
     if (bytes > 0) {
       if (!grad_levels[i]) return DRTK_ERR_INVALID_ARGUMENT;
-      if (hipMemsetAsync(grad_levels[i], 0, bytes, s) != hipSuccess) return DRTK_ERR_LAUNCH;
+      if (fill_bytes_async(grad_levels[i], 0, bytes, s) != DRTK_OK) return DRTK_ERR_LAUNCH;
     }
   }
   const int64_t count = N * H * W;

@@ -891,7 +891,7 @@ int rasterize_impl(
   auto* items = reinterpret_cast<uint32_t*>(ws + L.off_items);
   auto* queue = reinterpret_cast<int32_t*>(ws + L.off_queue);
 
-  if (hipMemsetAsync(ws, 0, L.zero_bytes, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+  if (fill_bytes_async(ws, 0, L.zero_bytes, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
   const int64_t total = N * F;
   const dim3 tri_grid(static_cast<unsigned>(ceil_div(F > 0 ? F : 1, kBlock)), static_cast<unsigned>(N));
   if (total > 0) {
@@ -980,7 +980,7 @@ extern "C" int drtk_amd_selftest_exact_div(
     drtk_dtype_t dtype, uint64_t seed, int64_t count, uint64_t* d_mismatches, drtk_stream_t stream) {
   if (!d_mismatches || count < 0) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(d_mismatches, 0, sizeof(uint64_t), s) != hipSuccess) return DRTK_ERR_LAUNCH;
+  if (fill_bytes_async(d_mismatches, 0, sizeof(uint64_t), s) != DRTK_OK) return DRTK_ERR_LAUNCH;
   const unsigned blocks = 4096;
   if (dtype == DRTK_F32) {
     hipLaunchKernelGGL((exact_div_selftest_kernel<float>), dim3(blocks), dim3(kBlock), 0, s, seed, (long long)count, (unsigned long long*)d_mismatches);

@@ -161,7 +161,7 @@ int rasterize_lines_dispatch(
   if (workspace_bytes < sizeof(unsigned long long) * static_cast<size_t>(count) || !workspace) return DRTK_ERR_WORKSPACE_TOO_SMALL;
   if (F >= (int64_t(1) << 31)) return DRTK_ERR_INVALID_ARGUMENT;
   auto* packed = static_cast<unsigned long long*>(workspace);
-  if (hipMemsetAsync(packed, 0xFF, sizeof(unsigned long long) * count, stream) != hipSuccess) return DRTK_ERR_LAUNCH; // :484-488
+  if (fill_bytes_async(packed, 0xFF, sizeof(unsigned long long) * count, stream) != DRTK_OK) return DRTK_ERR_LAUNCH; // :484-488
   if (N * F > 0) {
     const dim3 grid(static_cast<unsigned>(ceil_div(F, kBlock / kWave)), static_cast<unsigned>(N));
     if (dtype == DRTK_F32) {

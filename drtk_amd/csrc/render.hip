@@ -315,7 +315,7 @@ int render_backward_impl(
     const T* grad_bary_img, int64_t N, int64_t V, int64_t vi_sN, int64_t H, int64_t W, T* grad_v,
     hipStream_t stream) {
   if (N * V > 0) {
-    if (hipMemsetAsync(grad_v, 0, sizeof(T) * N * V * 3, stream) != hipSuccess) return DRTK_ERR_LAUNCH;
+    if (fill_bytes_async(grad_v, 0, sizeof(T) * N * V * 3, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
   }
   const int64_t HW = H * W;
   if (N * HW == 0) return DRTK_OK;

@@ -666,3 +666,61 @@ def test_non_contiguous_inputs_and_concurrent_streams():
     for k in range(2):
         for a, b in zip(got[k], want[k]):
             assert th.equal(a, b)
+
+
+def test_graph_capture_and_replay_with_other_work_between_replays():
+    """The ops are capture-safe (no syncs, no host reads of device data, outputs and workspaces from the
+    caller's allocator) -- and stay correct when the captured graph is REPLAYED between ordinary torch work,
+    which is what a captured training step does.  Regression test: with hipMemsetAsync for the zero-initialised
+    counters / gradients, the memset node of the captured graph stopped zeroing on such replays (MI355X,
+    ROCm 7.2): replay 1 of rasterize binned into garbage counters and faulted.  The library now fills with a
+    kernel (csrc/common.hpp: fill_bytes_async)."""
+    import drtk_amd
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    H, W, C, N = 192, 256, 5, 3
+    v0, vi = S.sphere_views(N, 18, 22, H, W, second_sphere=True, device=DEV)
+    g = th.Generator(device=DEV).manual_seed(4)
+    attr = th.rand(N, v0.shape[1], C, device=DEV, generator=g)
+    go = th.rand(N, C, H, W, device=DEV, generator=g) * 2 - 1
+    gd = th.rand(N, H, W, device=DEV, generator=g) * 2 - 1
+    gb = th.rand(N, 3, H, W, device=DEV, generator=g) * 2 - 1
+    v = v0.clone()  # updated in place between replays
+
+    def step():
+        index = drtk_amd.rasterize(v, vi, H, W)                      # torch op: workspace allocated inside
+        wire = drtk_amd.rasterize(v, vi, H, W, wireframe=True)        # 0xFF-initialised z-buffer
+        depth, bary = drtk_amd.render(v, vi, index)
+        img = drtk_amd.interpolate(attr, vi, index, bary)
+        d2, i2 = capi.rasterize(v, vi, H, W)                          # C ABI
+        gv = capi.render_backward(v, vi, index, gd, gb)               # zero-initialised outputs
+        ag, bg = capi.interpolate_backward(go, attr, vi, index, bary)
+        eg = capi.edge_grad_backward_fused(v, img * (index != -1)[:, None], index, vi, bary, go)
+        return dict(index=index, wire=wire, depth=depth, bary=bary, img=img, d2=d2, i2=i2, gv=gv, ag=ag, bg=bg, eg=eg)
+
+    side = th.cuda.Stream()
+    side.wait_stream(th.cuda.current_stream())
+    with th.cuda.stream(side):
+        for _ in range(2):
+            step()
+    th.cuda.current_stream().wait_stream(side)
+    th.cuda.synchronize()
+    graph = th.cuda.CUDAGraph()
+    with th.cuda.graph(graph):
+        out = step()
+
+    exact = ("index", "wire", "depth", "bary", "img", "d2", "i2")
+    for k, shift in enumerate((0.0, 0.0, 2.75, -6.5, 2.75)):
+        v.copy_(v0 + th.tensor([shift, -0.5 * shift, 0.0], device=DEV))  # a temporary + an eager kernel
+        graph.replay()
+        th.cuda.synchronize()
+        got = {n: t.clone() for n, t in out.items()}
+        want = step()                                                      # eager, same data
+        th.cuda.synchronize()
+        assert int((want["index"] != -1).sum()) > 0.2 * N * H * W
+        for n in exact:
+            assert th.equal(got[n], want[n]), f"replay {k} (shift {shift}): {n} differs from the eager result"
+        for n in ("gv", "ag", "bg", "eg"):
+            close(got[n], want[n], f"replay {k} (shift {shift}): {n}", atol=1e-4)
+        _ = float((got["img"] * 2).sum())                                  # more eager work + a D2H copy

@@ -116,6 +116,23 @@ def test_product_never_touches_the_oracle():
                     assert not re.search(pat, src), f"{f} reaches into the oracle ({pat})"
 
 
+def test_library_fills_with_a_kernel_not_with_hipMemset():
+    """Zero-initialised counters and gradients are filled by fill_bytes_async (a kernel launch), never by
+    hipMemset*: a captured memset node stops zeroing on graph replays that follow other device work (MI355X,
+    ROCm 7.2), which turns rasterize into an out-of-bounds scatter and every backward op into silent
+    accumulation.  The behaviour itself is pinned on the GPU by
+    tests/test_gpu_parity.py::test_graph_capture_and_replay_with_other_work_between_replays."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "drtk_amd", "csrc")):
+        for f in files:
+            if not f.endswith((".hip", ".hpp", ".cpp", ".h")):
+                continue
+            for no, line in enumerate(open(os.path.join(dirpath, f), errors="ignore"), 1):
+                if "hipMemset" in line.split("//")[0]:
+                    bad.append(f"{f}:{no}: {line.strip()}")
+    assert not bad, "\n".join(bad)
+
+
 def test_synthetic_mesh_sizes():
     from drtk_amd import synthetic as S
 
