@@ -724,3 +724,65 @@ def test_graph_capture_and_replay_with_other_work_between_replays():
         for n in ("gv", "ag", "bg", "eg"):
             close(got[n], want[n], f"replay {k} (shift {shift}): {n}", atol=1e-4)
         _ = float((got["img"] * 2).sum())                                  # more eager work + a D2H copy
+
+
+def test_whole_training_step_captured_through_autograd():
+    """torch's whole-network capture recipe around transform -> rasterize -> render -> interpolate -> mask ->
+    edge_grad_estimator -> loss -> backward(): the captured step replays with the eager loss and gradients, also
+    after the shared vertices were moved in place (what an optimizer does between replays)."""
+    import drtk_amd
+    from drtk_amd import synthetic as S
+    from drtk_amd.transform import transform
+
+    H, W, n, C = 160, 224, 3, 4
+    v0, vi = S.uv_sphere(16, 20, lobes=0.05, device=DEV)
+    cams = S.ring_cameras(n, W, H, device=DEV)
+    v_world = v0.clone().requires_grad_(True)
+    attr = th.rand(1, v0.shape[0], C, device=DEV).requires_grad_(True)
+
+    def step():
+        v_pix = transform(v_world[None], *cams)
+        index = drtk_amd.rasterize(v_pix, vi, H, W)
+        depth, bary = drtk_amd.render(v_pix, vi, index)
+        img = drtk_amd.interpolate(attr.expand(n, -1, -1), vi, index, bary)
+        img = th.where((index != -1)[:, None], img, 0.0)
+        img = drtk_amd.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary, img=img, index_img=index)
+        loss = img.square().mean() + depth.mean()
+        loss.backward()
+        return loss
+
+    def eager():
+        v_world.grad = None
+        attr.grad = None
+        loss = step()
+        th.cuda.synchronize()
+        return float(loss.detach()), v_world.grad.clone(), attr.grad.clone()
+
+    side = th.cuda.Stream()
+    side.wait_stream(th.cuda.current_stream())
+    with th.cuda.stream(side):
+        for _ in range(3):
+            v_world.grad = None
+            attr.grad = None
+            step()
+    th.cuda.current_stream().wait_stream(side)
+    th.cuda.synchronize()
+    v_world.grad = None
+    attr.grad = None
+    graph = th.cuda.CUDAGraph()
+    with th.cuda.graph(graph):
+        loss = step()
+    gv_static, ga_static = v_world.grad, attr.grad  # filled by every replay
+
+    for k, move in enumerate((0.0, 0.0, 0.01, -0.02)):
+        with th.no_grad():
+            v_world.copy_(v0 * (1.0 + move))
+        graph.replay()
+        th.cuda.synchronize()
+        got = (float(loss.detach()), gv_static.clone(), ga_static.clone())
+        v_world.grad, attr.grad = None, None
+        want = eager()
+        v_world.grad, attr.grad = gv_static, ga_static
+        assert abs(got[0] - want[0]) <= 1e-6 * abs(want[0]), f"replay {k}: loss {got[0]} vs {want[0]}"
+        close(got[1], want[1], f"replay {k}: grad of the shared vertices", atol=1e-7, rtol=1e-4)
+        close(got[2], want[2], f"replay {k}: grad of the shared attributes", atol=1e-7, rtol=1e-4)
