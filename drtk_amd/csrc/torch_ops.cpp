@@ -50,10 +50,6 @@ drtk_stream_t current_stream(const Tensor& t) {
   return static_cast<drtk_stream_t>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
 }
 
-// Kernels and workspace allocations go to the device of the op's tensors, whatever the caller's current
-// device is (the reference: at::cuda::OptionalCUDAGuard device_guard(device_of(v)), rasterize_kernel.cu:470).
-#define DRTK_DEVICE_GUARD(t) const c10::hip::OptionalHIPGuardMasqueradingAsCUDA device_guard(at::device_of(t))
-
 void check_status(int status, const char* op) {
   TORCH_CHECK(status == DRTK_OK, op, "(): ", drtk_amd_status_string(status), " [drtk_amd status ", status, "]");
 }
@@ -91,7 +87,6 @@ Tensor alloc_workspace(size_t bytes, const Tensor& like) {
 // ---------------------------------------------------------------------------------------------
 std::vector<Tensor> rasterize_hip(
     const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {
-  DRTK_DEVICE_GUARD(v);
   // checks and messages follow rasterize_kernel.cu:423-468
   TORCH_CHECK(v.defined() && vi.defined(), "rasterize(): expected all inputs to be defined");
   TORCH_CHECK(
@@ -210,7 +205,6 @@ void render_checks(const Tensor& v, const Tensor& vi, const Tensor& index_img) {
 }
 
 std::vector<Tensor> render_hip(const Tensor& v, const Tensor& vi, const Tensor& index_img) {
-  DRTK_DEVICE_GUARD(v);
   render_checks(v, vi, index_img);
   const drtk_dtype_t dt = dtype_of(v, "render");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
@@ -231,7 +225,6 @@ std::vector<Tensor> render_hip(const Tensor& v, const Tensor& vi, const Tensor& 
 Tensor render_backward_hip(
     const Tensor& v, const Tensor& vi, const Tensor& index_img, const Tensor& grad_depth_img,
     const Tensor& grad_bary_img) {
-  DRTK_DEVICE_GUARD(v);
   const drtk_dtype_t dt = dtype_of(v, "render_backward");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
   const auto v_c = v.contiguous();
@@ -337,7 +330,6 @@ void interpolate_checks(const Tensor& a, const Tensor& vi, const Tensor& index_i
 }
 
 Tensor interpolate_launch(const Tensor& a, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img, bool masked) {
-  DRTK_DEVICE_GUARD(a);
   interpolate_checks(a, vi, index_img, bary_img);
   const drtk_dtype_t dt = dtype_of(a, "interpolate");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(a.device());
@@ -366,7 +358,6 @@ Tensor interpolate_masked_hip(const Tensor& a, const Tensor& vi, const Tensor& i
 std::tuple<Tensor, Tensor> interpolate_backward_hip(
     const Tensor& grad_out, const Tensor& a, const Tensor& vi, const Tensor& index_img,
     const Tensor& bary_img, bool vert_requires_grad, bool bary_requires_grad) {
-  DRTK_DEVICE_GUARD(grad_out);
   const drtk_dtype_t dt = dtype_of(a, "interpolate_backward");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(a.device());
   const auto a_c = a.contiguous();
@@ -477,7 +468,6 @@ ViArg prep_pairs(const Tensor& pair_indices) {
 }
 
 Tensor4 interpolation_matrix_hip(const Tensor& vi, const Tensor& index_img, const Tensor& bary_img) {
-  DRTK_DEVICE_GUARD(vi);
   // interpolate_kernel.cu:703-729
   TORCH_CHECK(
       vi.defined() && index_img.defined() && bary_img.defined(),
@@ -524,7 +514,6 @@ Tensor4 interpolation_matrix_hip(const Tensor& vi, const Tensor& index_img, cons
 Tensor interpolation_matrix_backward_hip(
     const Tensor& grad_values, const Tensor& vi, const Tensor& index_img, const Tensor& bary_img,
     const Tensor& row_pixels) {
-  DRTK_DEVICE_GUARD(grad_values);
   const drtk_dtype_t dt = dtype_of(bary_img, "interpolation_matrix_backward");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(bary_img.device());
   const auto idx_c = index_img.contiguous();
@@ -543,7 +532,6 @@ Tensor interpolation_matrix_backward_hip(
 
 Tensor normal_matrix_values_hip(
     const Tensor& pair_indices, const Tensor& index_img, const Tensor& bary_img, int64_t nnz) {
-  DRTK_DEVICE_GUARD(pair_indices);
   // interpolate_kernel.cu:813-836
   TORCH_CHECK(
       pair_indices.defined() && index_img.defined() && bary_img.defined(),
@@ -583,7 +571,6 @@ Tensor normal_matrix_values_hip(
 
 Tensor normal_matrix_values_backward_hip(
     const Tensor& grad_values, const Tensor& pair_indices, const Tensor& index_img, const Tensor& bary_img) {
-  DRTK_DEVICE_GUARD(grad_values);
   const drtk_dtype_t dt = dtype_of(bary_img, "interpolation_normal_matrix_values_backward");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(bary_img.device());
   const auto idx_c = index_img.contiguous();
@@ -960,7 +947,6 @@ LevelArgs prep_levels(at::TensorList input) {
 Tensor mipmap_grid_sampler_2d_hip(
     at::TensorList input, const Tensor& grid, const Tensor& vt_dxdy_img, int64_t max_aniso, int64_t padding_mode,
     int64_t interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) {
-  DRTK_DEVICE_GUARD(grid);
   // mipmap_grid_sampler_kernel.cu:909-1000
   const int64_t mipmaps = static_cast<int64_t>(input.size());
   TORCH_CHECK(mipmaps >= 1, "mipmap_aniso_grid_sampler_2d(): expected input to have at least one mipmap level");
@@ -1044,7 +1030,6 @@ std::tuple<std::vector<Tensor>, Tensor> mipmap_grid_sampler_2d_backward_hip(
     const Tensor& grad_output, const std::vector<Tensor>& input, const Tensor& grid, const Tensor& vt_dxdy_img,
     int64_t max_aniso, int64_t padding_mode, int64_t interpolation_mode, bool align_corners, bool force_max_ansio,
     bool clip_grad) {
-  DRTK_DEVICE_GUARD(grad_output);
   const drtk_dtype_t dt = dtype_of(input[0], "mipmap_aniso_grid_sampler_2d_backward_kernel");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input[0].device());
   const LevelArgs lv = prep_levels(input);
@@ -1154,7 +1139,6 @@ Tensor mipmap_grid_sampler_2d_autocast(
 Tensor screen_space_uv_derivative_hip(
     const Tensor& v, const Tensor& vt, const Tensor& vi, const Tensor& vti, const Tensor& index_img,
     const Tensor& bary_img, const Tensor& mask, const Tensor& campos, const Tensor& camrot, const Tensor& focal) {
-  DRTK_DEVICE_GUARD(v);
   const char* op = "screen_space_uv_derivative";
   TORCH_CHECK(v.dim() == 3 && v.size(2) == 3, op, "(): expected v to be [N,V,3], got ", v.sizes()); // geometry.py:60-61
   TORCH_CHECK(vt.dim() == 3 && vt.size(2) == 2, op, "(): expected vt to be [N,T,2], got ", vt.sizes());
@@ -1247,7 +1231,6 @@ Tensor edge_grad_fwd_hip(
 Tensor edge_grad_backward_hip(
     const Tensor& v_pix, const Tensor& img, const Tensor& index_img, const Tensor& vi,
     const Tensor& grad_outputs, double max_dp_dr) {
-  DRTK_DEVICE_GUARD(v_pix);
   const drtk_dtype_t dt = dtype_of(v_pix, "edge_grad_estimator_backward");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v_pix.device());
   const auto v_c = v_pix.contiguous();
@@ -1345,7 +1328,6 @@ Tensor edge_grad_fused_fwd_hip(
 Tensor edge_grad_fused_backward_hip(
     const Tensor& v_pix, const Tensor& img, const Tensor& index_img, const Tensor& vi,
     const Tensor& bary_img, const Tensor& grad_outputs, double max_dp_dr) {
-  DRTK_DEVICE_GUARD(v_pix);
   const drtk_dtype_t dt = dtype_of(v_pix, "edge_grad_estimator_backward");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v_pix.device());
   const auto v_c = v_pix.contiguous();
@@ -1459,7 +1441,6 @@ TransformArgs transform_prep(
 
 Tensor transform_pinhole_hip(
     const Tensor& v, const Tensor& campos, const Tensor& camrot, const Tensor& focal, const Tensor& princpt) {
-  DRTK_DEVICE_GUARD(v);
   const drtk_dtype_t dt = dtype_of(v, "transform");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
   const TransformArgs a = transform_prep(v, campos, camrot, focal, princpt);
@@ -1475,7 +1456,6 @@ Tensor transform_pinhole_hip(
 Tensor transform_pinhole_backward_hip(
     const Tensor& v, const Tensor& campos, const Tensor& camrot, const Tensor& focal, const Tensor& princpt,
     const Tensor& grad_v_pix) {
-  DRTK_DEVICE_GUARD(v);
   const drtk_dtype_t dt = dtype_of(v, "transform_backward");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
   const TransformArgs a = transform_prep(v, campos, camrot, focal, princpt);
