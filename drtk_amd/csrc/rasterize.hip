@@ -431,11 +431,14 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(
 __global__ __launch_bounds__(1024) void bin_scan_kernel(
     const unsigned long long* __restrict__ tile_count64, int32_t* __restrict__ tile_offset, int num_tiles,
     int tile_shift, uint32_t* __restrict__ items, int32_t* __restrict__ queue) {
-  __shared__ int32_t part[1024];
-  __shared__ int32_t cls_count[4], cls_base[4];
-  const int tid = threadIdx.x;
-  auto tile_count = [&](int i) { return static_cast<int32_t>(tile_count64[i] & 0xFFFFFFFFull); };
-  const int chunk = (num_tiles + 1023) / 1024;
+  // One block-wide scan of FIVE running sums per thread -- list entries, and work items of each of the four
+  // classes -- gives every thread the list offset of its first tile and its first slot in every class of the
+  // work list: no atomics (1024 threads bumping four LDS counters are served one lane at a time), two
+  // barriers, and the work list comes out ordered by tile within a class.
+  constexpr int kThreads = 1024, kWaves = kThreads / kWave, kVals = 5, kReg = 8;
+  __shared__ int32_t s_wave[kWaves][kVals];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int chunk = (num_tiles + kThreads - 1) / kThreads;
   const int begin = tid * chunk;
   const int end = min(begin + chunk, num_tiles);
   const int max_split_log = max(0, min(2, tile_shift - 4)); // sub-rectangles are at least 16 px
@@ -443,45 +446,88 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
     int sl = c > kSplit16Threshold ? 2 : (c > kSplit4Threshold ? 1 : 0);
     return min(sl, max_split_log);
   };
-  if (tid < 4) cls_count[tid] = 0;
-  int32_t sum = 0;
-  for (int i = begin; i < end; ++i) sum += tile_count(i);
-  part[tid] = sum;
-  __syncthreads();
-  // Hillis-Steele inclusive scan over the 1024 partial sums
-  for (int off = 1; off < 1024; off <<= 1) {
-    int32_t add = (tid >= off) ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += add;
-    __syncthreads();
+  auto class_of = [&](int c, int sl) { return c == 0 ? 3 : 2 - sl; }; // 0: 4x4 split, 1: 2x2, 2: whole tile, 3: empty list
+  // the thread's counters: in registers when they fit (one batch of independent loads), re-read otherwise
+  const bool in_regs = chunk <= kReg;
+  int32_t cnt[kReg];
+#pragma unroll
+  for (int j = 0; j < kReg; ++j) {
+    cnt[j] = (in_regs && begin + j < end) ? static_cast<int32_t>(tile_count64[begin + j] & 0xFFFFFFFFull) : 0;
   }
-  int32_t run = part[tid] - sum; // exclusive prefix of this thread's chunk
-  for (int i = begin; i < end; ++i) {
-    const int c = tile_count(i);
+  auto count_at = [&](int j) -> int32_t { // j-th tile of this thread's chunk
+    return static_cast<int32_t>(tile_count64[begin + j] & 0xFFFFFFFFull);
+  };
+  int32_t v[kVals] = {0, 0, 0, 0, 0};
+  auto tally = [&](int c) {
+    const int sl = split_log_of(c);
+    v[0] += c;
+    v[1 + class_of(c, sl)] += 1 << (2 * sl);
+  };
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < kReg; ++j) {
+      if (begin + j < end) tally(cnt[j]);
+    }
+  } else {
+    for (int j = 0; begin + j < end; ++j) tally(count_at(j));
+  }
+  // inclusive scan within the wave, wave totals through LDS
+  int32_t inc[kVals];
+#pragma unroll
+  for (int k = 0; k < kVals; ++k) {
+    int32_t x = v[k];
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int32_t up = __shfl_up(x, o);
+      if (lane >= o) x += up;
+    }
+    inc[k] = x;
+    if (lane == kWave - 1) s_wave[wave][k] = x;
+  }
+  __syncthreads();
+  int32_t before[kVals], total[kVals];
+#pragma unroll
+  for (int k = 0; k < kVals; ++k) {
+    int32_t lo = 0, all = 0;
+    for (int w = 0; w < kWaves; ++w) {
+      const int32_t t = s_wave[w][k];
+      all += t;
+      if (w < wave) lo += t;
+    }
+    before[k] = lo + inc[k] - v[k]; // exclusive prefix of this thread
+    total[k] = all;
+  }
+  // class k's slots start after the classes before it
+  int32_t slot[4];
+  {
+    int32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      slot[k] = acc + before[1 + k];
+      acc += total[1 + k];
+    }
+    if (tid == 0) {
+      queue[1] = acc; // number of work items
+      tile_offset[num_tiles] = total[0];
+    }
+  }
+  int32_t run = before[0];
+  auto emit = [&](int i, int c) {
     tile_offset[i] = run;
     run += c;
     const int sl = split_log_of(c);
-    const int cls = c == 0 ? 3 : 2 - sl; // 0: 4x4 split, 1: 2x2 split, 2: whole tile, 3: empty list
-    atomicAdd(&cls_count[cls], 1 << (2 * sl));
-  }
-  if (tid == 1023) tile_offset[num_tiles] = part[1023];
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int k = 0; k < 4; ++k) {
-      cls_base[k] = acc;
-      acc += cls_count[k];
-    }
-    queue[1] = acc; // number of work items
-  }
-  __syncthreads();
-  for (int i = begin; i < end; ++i) {
-    const int c = tile_count(i);
-    const int sl = split_log_of(c);
-    const int cls = c == 0 ? 3 : 2 - sl;
+    const int cls = class_of(c, sl);
     const int n_sub = 1 << (2 * sl);
-    const int base = atomicAdd(&cls_base[cls], n_sub);
-    for (int j = 0; j < n_sub; ++j) items[base + j] = make_item(static_cast<uint32_t>(i), j, sl);
+    for (int j = 0; j < n_sub; ++j) items[slot[cls] + j] = make_item(static_cast<uint32_t>(i), j, sl);
+    slot[cls] += n_sub;
+  };
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < kReg; ++j) {
+      if (begin + j < end) emit(begin + j, cnt[j]);
+    }
+  } else {
+    for (int j = 0; begin + j < end; ++j) emit(begin + j, count_at(j));
   }
 }
 
