@@ -582,7 +582,12 @@ extern "C" int drtk_amd_interpolate_backward(
     const int32_t* index_img, const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F,
     int64_t vi_sN, int64_t H, int64_t W, void* attr_grad, void* bary_grad, drtk_stream_t stream) {
   if (bad_common(N, V, C, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
-  if (!attr_grad && !bary_grad) return DRTK_ERR_INVALID_ARGUMENT;
+  if (!attr_grad && !bary_grad) {
+    // A null output is one that was not requested OR is empty (N*V*C == 0 / N*H*W == 0; an empty tensor has no
+    // storage): either way there is nothing to write.  Requesting nothing is an error only when both gradients
+    // would have had elements.
+    return (N * V * C > 0 && N * H * W > 0) ? DRTK_ERR_INVALID_ARGUMENT : DRTK_OK;
+  }
   if (N * H * W * C > 0 && (!grad_out || !index_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
   if ((N * V * C > 0 && !attrs) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);

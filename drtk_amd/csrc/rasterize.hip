@@ -1001,7 +1001,9 @@ extern "C" int drtk_amd_rasterize(
   if (wireframe) {
     if (N > 65535 || N * H * W >= (int64_t(1) << 40) || (dtype != DRTK_F32 && dtype != DRTK_F64)) return DRTK_ERR_INVALID_ARGUMENT;
     if (N * H * W > 0 && (!depth_img || !index_img)) return DRTK_ERR_INVALID_ARGUMENT;
-    if (N * F > 0 && (!v || !vi)) return DRTK_ERR_INVALID_ARGUMENT;
+    // Triangles need vertices: with F > 0 an empty `v` (V == 0, no storage) is rejected here on purpose -- every
+  // non-degenerate index would be read off a null base (like the reference, the kernels do not bounds-check vi).
+  if (N * F > 0 && (!v || !vi)) return DRTK_ERR_INVALID_ARGUMENT;
     if (vi_sN != 0 && vi_sN != F * 3) return DRTK_ERR_INVALID_ARGUMENT;
     return rasterize_lines_dispatch(dtype, v, vi, N, V, F, vi_sN, H, W, depth_img, index_img, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   }
@@ -1009,6 +1011,8 @@ extern "C" int drtk_amd_rasterize(
       N * H * W >= (int64_t(1) << 40))
     return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W > 0 && (!depth_img || !index_img || !workspace)) return DRTK_ERR_INVALID_ARGUMENT;
+  // Triangles need vertices: with F > 0 an empty `v` (V == 0, no storage) is rejected here on purpose -- every
+  // non-degenerate index would be read off a null base (like the reference, the kernels do not bounds-check vi).
   if (N * F > 0 && (!v || !vi)) return DRTK_ERR_INVALID_ARGUMENT;
   if (vi_sN != 0 && vi_sN != F * 3) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -786,3 +786,108 @@ def test_whole_training_step_captured_through_autograd():
         assert abs(got[0] - want[0]) <= 1e-6 * abs(want[0]), f"replay {k}: loss {got[0]} vs {want[0]}"
         close(got[1], want[1], f"replay {k}: grad of the shared vertices", atol=1e-7, rtol=1e-4)
         close(got[2], want[2], f"replay {k}: grad of the shared attributes", atol=1e-7, rtol=1e-4)
+
+
+def test_zero_sized_dimensions():
+    """Every op with every dimension in turn set to zero (a batch of zero views, no vertices, no triangles, no
+    channels, an empty image), through the C-ABI wrappers and through autograd: no error, empty or finite
+    outputs.  An empty tensor has no storage, so its pointer is null -- which the C ABI must not mistake for a
+    missing argument (interpolate_backward did, for N = 0).  One combination is rejected on purpose: rasterize
+    with triangles but no vertices, where every index would be out of range."""
+    import drtk_amd
+    from drtk_amd import capi
+
+    base = dict(N=2, V=7, F=5, C=3, H=6, W=8)
+    for zero in "NVFCHW":
+        d = dict(base)
+        d[zero] = 0
+        N, V, F, C, H, W = (d[k] for k in "NVFCHW")
+        g = th.Generator(device=DEV).manual_seed(0)
+        v = th.rand(N, V, 3, device=DEV, generator=g) * th.tensor([W, H, 1.0], device=DEV) + th.tensor([0, 0, 2.0], device=DEV)
+        vi = th.randint(0, max(V, 1), (F, 3), device=DEV, generator=g).int()
+        index = th.full((N, H, W), -1, dtype=th.int32, device=DEV)
+        if F > 0 and V > 0 and index.numel():
+            index.view(-1)[::3] = 0
+        bary = th.rand(N, 3, H, W, device=DEV, generator=g)
+        attr = th.rand(N, V, C, device=DEV, generator=g)
+        img = th.rand(N, C, H, W, device=DEV, generator=g)
+        go = th.rand(N, C, H, W, device=DEV, generator=g)
+        gd = th.rand(N, H, W, device=DEV, generator=g)
+
+        def autograd_step():
+            vv, aa = v.clone().requires_grad_(True), attr.clone().requires_grad_(True)
+            depth, b = drtk_amd.render(vv, vi, index)
+            im = drtk_amd.interpolate(aa, vi, index, b)
+            im = drtk_amd.edge_grad_estimator(v_pix=vv, vi=vi, bary_img=b, img=im, index_img=index)
+            (im.sum() + depth.sum()).backward()
+            return vv.grad, aa.grad
+
+        calls = [
+            ("render", lambda: capi.render(v, vi, index), [(N, H, W), (N, 3, H, W)]),
+            ("render_backward", lambda: capi.render_backward(v, vi, index, gd, bary), [(N, V, 3)]),
+            ("interpolate", lambda: capi.interpolate(attr, vi, index, bary), [(N, C, H, W)]),
+            ("interpolate_masked", lambda: capi.interpolate_masked(attr, vi, index, bary), [(N, C, H, W)]),
+            ("interpolate_backward both", lambda: capi.interpolate_backward(go, attr, vi, index, bary, True, True), [(N, V, C), (N, 3, H, W)]),
+            ("interpolate_backward vertex only", lambda: capi.interpolate_backward(go, attr, vi, index, bary, True, False), [(N, V, C)]),
+            ("interpolate_backward bary only", lambda: capi.interpolate_backward(go, attr, vi, index, bary, False, True), [(N, 3, H, W)]),
+            ("edge_grad_backward", lambda: capi.edge_grad_backward(v, img, index, vi, go), [(N, 3, H, W)]),
+            ("edge_grad_backward_fused", lambda: capi.edge_grad_backward_fused(v, img, index, vi, bary, go), [(N, V, 3)]),
+            ("autograd render+interpolate+edge_grad", autograd_step, [(N, V, 3), (N, V, C)]),
+        ]
+        if H > 0 and W > 0:  # the reference requires height, width > 0 (rasterize_kernel.cu:464-468)
+            if V == 0 and F > 0:
+                for wf in (False, True):
+                    with pytest.raises(capi.DrtkAmdError, match="invalid argument"):
+                        capi.rasterize(v, vi, H, W, wireframe=wf)
+                with pytest.raises(RuntimeError, match="invalid argument"):
+                    drtk_amd.rasterize(v, vi, H, W)
+            else:
+                calls += [
+                    ("rasterize", lambda: capi.rasterize(v, vi, H, W), [(N, H, W), (N, H, W)]),
+                    ("rasterize wireframe", lambda: capi.rasterize(v, vi, H, W, wireframe=True), [(N, H, W), (N, H, W)]),
+                    ("torch rasterize", lambda: drtk_amd.rasterize(v, vi, H, W), [(N, H, W)]),
+                ]
+        for name, fn, shapes in calls:
+            r = fn()
+            th.cuda.synchronize()
+            outs = [t for t in (r if isinstance(r, (tuple, list)) else [r]) if t is not None]
+            assert [tuple(t.shape) for t in outs] == shapes, f"{zero}=0 {name}: {[tuple(t.shape) for t in outs]} != {shapes}"
+            for t in outs:
+                assert t.numel() == 0 or bool(th.isfinite(t.float()).all()), f"{zero}=0 {name}: non-finite output"
+
+
+def test_non_finite_and_huge_vertex_coordinates():
+    """What a diverging optimisation feeds the rasterizer: NaN, +-Inf, 1e30, -3e38 coordinates, depths below
+    the near plane, negative and zero.  No fault; index_img and the depth bits equal the oracle's (such triangles
+    never win a pixel on either side); render on a VISIBLE triangle whose edge products overflow goes non-finite
+    at exactly the oracle's pixels and is bit-identical everywhere else.  NaN bit patterns are not compared:
+    they are a property of the hardware (x86's default NaN has the sign bit set, the GPU's does not)."""
+    import oracle as O
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    H, W = 96, 128
+    v0, vi = S.sphere_views(2, 12, 16, H, W, second_sphere=True)
+    poison = {"nan x": (5, 0, float("nan")), "nan z": (40, 2, float("nan")), "+inf x": (77, 0, float("inf")),
+              "-inf y": (101, 1, float("-inf")), "1e30 x": (130, 0, 1e30), "-3e38 y": (150, 1, -3e38),
+              "z below the near plane": (160, 2, 1e-9), "negative z": (180, 2, -1.0), "zero z": (200, 2, 0.0)}
+    for case in list(poison) + ["all of them"]:
+        v = v0.clone()
+        for nm in (poison if case == "all of them" else [case]):
+            i, c, val = poison[nm]
+            v[:, i, c] = val
+        d_o, i_o = O.rasterize(v, vi, H, W)
+        d_g, i_g = capi.rasterize(dev(v), dev(vi), H, W)
+        assert th.equal(i_g.cpu(), i_o), f"{case}: index_img"
+        assert bool(th.isfinite(d_o).all()) and th.equal(d_g.cpu().view(th.int32), d_o.view(th.int32)), f"{case}: depth bits"
+        assert int((i_o != -1).sum()) > 0.2 * i_o.numel()
+        rd_o, rb_o = O.render(v, vi, i_o)
+        rd_g, rb_g = capi.render(dev(v), dev(vi), i_g)
+        rd_g, rb_g = rd_g.cpu(), rb_g.cpu()
+        fin_o = th.isfinite(rb_o).all(1) & th.isfinite(rd_o)
+        fin_g = th.isfinite(rb_g).all(1) & th.isfinite(rd_g)
+        assert th.equal(fin_o, fin_g), f"{case}: render goes non-finite at other pixels than the oracle"
+        assert th.equal(rb_g.permute(0, 2, 3, 1)[fin_o], rb_o.permute(0, 2, 3, 1)[fin_o]), f"{case}: bary"
+        assert th.equal(rd_g[fin_o], rd_o[fin_o]), f"{case}: render depth"
+        if case == "-3e38 y":
+            assert int((~fin_o).sum()) > 0  # the case does exercise the overflow
