@@ -233,9 +233,19 @@ extern "C" int drtk_amd_interpolation_normal_matrix_values_backward(
     const void* bary_img, int64_t N, int64_t F, int64_t pair_sN, int64_t H, int64_t W, void* bary_grad,
     drtk_stream_t stream) {
   if (bad(N, F, H, W) || (pair_sN != 0 && pair_sN != F * 9)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W == 0) return DRTK_OK;
-  if (!grad_values || !pair_indices || !index_img || !bary_img || !bary_grad) return DRTK_ERR_INVALID_ARGUMENT;
+  if (!bary_grad) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (F == 0) {
+    // No faces: every pixel is background and its gradient is zero.  The pair table and grad_values are empty
+    // then and have no storage -- a null pointer is not a missing argument here (same idiom as
+    // drtk_amd_interpolation_matrix_backward above: write the output, return when there is nothing to scatter).
+    const size_t es = dtype == DRTK_F32 ? 4 : 8;
+    if (fill_bytes_async(bary_grad, 0, es * 3 * N * H * W, s) != DRTK_OK) return DRTK_ERR_LAUNCH;
+    return DRTK_OK;
+  }
+  if (!grad_values || !pair_indices || !index_img || !bary_img) return DRTK_ERR_INVALID_ARGUMENT;
   const dim3 grid(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N));
 #define CALL hipLaunchKernelGGL((normal_matrix_values_backward_kernel<T>), grid, dim3(kBlock), 0, s, static_cast<const T*>(grad_values), pair_indices, index_img, static_cast<const T*>(bary_img), pair_sN, H * W, static_cast<T*>(bary_grad))
   DRTK_DISPATCH(dtype, CALL, CALL)

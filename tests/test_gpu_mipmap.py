@@ -263,3 +263,72 @@ def test_randomised_mipmap_cases(block):
             F.run_case(c)
         except AssertionError as e:
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
+
+
+def test_zero_sized_dimensions_of_the_texture_and_sparse_ops():
+    """mipmap_grid_sample, transform, screen_space_uv_derivative and the sparse interpolation operators with each
+    dimension in turn set to zero, forward and backward through the Python API: right shapes, finite values, no
+    error -- an empty tensor's null pointer is not a missing argument (the backward of the normal-matrix values
+    rejected a mesh without faces while its forward accepted it).  Faces WITHOUT vertices are rejected on purpose:
+    every index would be out of range."""
+    import drtk_amd
+    from drtk_amd import synthetic as S
+
+    def finite(*ts):
+        for t in ts:
+            d = t.to_dense() if t.layout != th.strided else t
+            assert d.numel() == 0 or bool(th.isfinite(d.float()).all())
+
+    for zero in ("N", "C", "H", "W"):
+        d = dict(N=2, C=3, H=5, W=7)
+        d[zero] = 0
+        N, C, H, W = d["N"], d["C"], d["H"], d["W"]
+        for mode in ("bilinear", "bicubic"):
+            tex = [th.rand(N, C, 16, 16, device=DEV).requires_grad_(True), th.rand(N, C, 8, 8, device=DEV).requires_grad_(True)]
+            grid = (th.rand(N, H, W, 2, device=DEV) * 2 - 1).requires_grad_(True)
+            jac = th.randn(N, H, W, 2, 2, device=DEV) * 0.05
+            out = drtk_amd.mipmap_grid_sample(tex, grid, jac, 4, mode=mode, padding_mode="border")
+            assert tuple(out.shape) == (N, C, H, W)
+            out.sum().backward()
+            assert grid.grad.shape == grid.shape and tex[0].grad.shape == tex[0].shape and tex[1].grad.shape == tex[1].shape
+            finite(out, grid.grad, tex[0].grad, tex[1].grad)
+
+    v0, vi = S.uv_sphere(6, 8, device=DEV)
+    tri = vi.shape[0] // 2  # a mid-latitude triangle: the first row touches the pole and has zero area (singular uv Jacobian)
+    for zero in ("N", "H", "W", "V", "F"):
+        N, H, W = (0 if zero == "N" else 2), (0 if zero == "H" else 12), (0 if zero == "W" else 16)
+        v = v0[:0] if zero == "V" else v0
+        f = vi[:0] if zero == "F" else vi
+        V = v.shape[0]
+        cams = S.ring_cameras(N, max(W, 1), max(H, 1), device=DEV)
+        vN = v[None].expand(N, -1, -1).contiguous().requires_grad_(True)
+        v_pix = drtk_amd.transform(vN, *cams)
+        assert tuple(v_pix.shape) == (N, V, 3)
+        v_pix.sum().backward()
+        assert vN.grad.shape == vN.shape
+        finite(v_pix, vN.grad)
+
+        index = th.full((N, H, W), -1, dtype=th.int32, device=DEV)
+        if f.shape[0] and V and index.numel():
+            index.view(-1)[::2] = tri
+        bary = th.rand(N, 3, H, W, device=DEV)
+        vt = th.rand(N, V, 2, device=DEV)
+        uv_args = (vN.detach(), vt, f, f, index, bary, index != -1, cams[0], cams[1], cams[2])
+        if zero == "V":
+            with pytest.raises(RuntimeError, match="invalid argument"):
+                drtk_amd.screen_space_uv_derivative(*uv_args)
+            with pytest.raises(RuntimeError, match="expected num_vertices to be positive"):
+                drtk_amd.interpolation_normal_matrix(f, index, bary, V)
+            continue
+        jac = drtk_amd.screen_space_uv_derivative(*uv_args)
+        assert tuple(jac.shape) == (N, H, W, 2, 2)
+        finite(jac)
+        b = bary.clone().requires_grad_(True)
+        A = drtk_amd.interpolation_matrix(f, index, b, V)
+        M = drtk_amd.interpolation_normal_matrix(f, index, b, V)
+        assert A.shape[1] == V and tuple(M.shape) == (V, V)
+        (A.values().sum() + M.values().sum()).backward()
+        assert b.grad.shape == b.shape
+        finite(A, M, b.grad)
+        if zero == "F":
+            assert float(b.grad.abs().sum()) == 0.0 and A.shape[0] == 0
