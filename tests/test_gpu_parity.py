@@ -891,3 +891,71 @@ def test_non_finite_and_huge_vertex_coordinates():
         assert th.equal(rd_g[fin_o], rd_o[fin_o]), f"{case}: render depth"
         if case == "-3e38 y":
             assert int((~fin_o).sum()) > 0  # the case does exercise the overflow
+
+
+@pytest.mark.parametrize("which", ["channels", "views"])
+def test_tensors_beyond_two_to_the_31_elements(which):
+    """288 GB per GPU invites images that no 32-bit element index can address: one 8192^2 view with 40 channels
+    (2.7e9 elements; the planes of channels >= 32 start beyond 2^31), or 12 such views (bary_img: 2.4e9 elements;
+    the last views lie beyond 2^31).  Those planes / views must equal the same planes / views computed ALONE in a
+    small call -- bit for bit in the forward passes, to summation-order noise in the gradients.  ~30 GB."""
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    if th.cuda.get_device_properties(0).total_memory < 64 * 2**30:
+        pytest.skip("needs ~30 GB of device memory")
+    R = 8192
+    nl, no = S.MESH_SIZES["100k"]
+
+    def rel(a, b, what, tol=2e-5):
+        err, ref = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= tol * ref, f"{what}: max err {err:.3e} vs max {ref:.3e}"
+
+    if which == "channels":
+        C, lo = 40, 32
+        v, vi = S.sphere_views(1, nl, no, R, R, lobes=0.05, device=DEV)
+        _, index = capi.rasterize(v, vi, R, R)
+        _, bary = capi.render(v, vi, index)
+        g = th.Generator(device=DEV).manual_seed(1)
+        attr = th.rand(1, v.shape[1], C, device=DEV, generator=g)
+        out = capi.interpolate(attr, vi, index, bary)
+        assert out.numel() > 2**31
+        assert th.equal(out[:, lo:], capi.interpolate(attr[..., lo:].contiguous(), vi, index, bary)), "interpolate"
+        go = th.empty_like(out)
+        for c in range(C):
+            go[:, c] = th.rand(1, R, R, device=DEV, generator=g) * 2 - 1
+        ag, bg = capi.interpolate_backward(go, attr, vi, index, bary)
+        ag_s, _ = capi.interpolate_backward(go[:, lo:].contiguous(), attr[..., lo:].contiguous(), vi, index, bary)
+        rel(ag[..., lo:], ag_s, "attribute gradient of the channels beyond 2^31")
+        acc = th.zeros_like(bg)  # the bary gradient sums over ALL channels: five 8-channel calls
+        for c0 in range(0, C, 8):
+            acc += capi.interpolate_backward(go[:, c0:c0 + 8].contiguous(), attr[..., c0:c0 + 8].contiguous(), vi, index, bary)[1]
+        rel(bg, acc, "bary gradient")
+        del acc, ag, bg, ag_s
+        out *= (index != -1)[:, None]
+        eg = capi.edge_grad_backward_fused(v, out, index, vi, bary, go)
+        acc = th.zeros_like(eg)  # the edge term is a sum over channels of per-channel products
+        for c0 in range(0, C, 8):
+            acc += capi.edge_grad_backward_fused(v, out[:, c0:c0 + 8].contiguous(), index, vi, bary, go[:, c0:c0 + 8].contiguous())
+        rel(eg, acc, "fused edge gradient")
+    else:
+        N = 12
+        v, vi = S.sphere_views(N, nl, no, R, R, lobes=0.05, device=DEV)
+        d, index = capi.rasterize(v, vi, R, R)
+        depth, bary = capi.render(v, vi, index)
+        assert bary.numel() > 2**31
+        for n in (0, N - 1):
+            d1, i1 = capi.rasterize(v[n:n + 1].contiguous(), vi, R, R)
+            assert th.equal(index[n:n + 1], i1) and th.equal(d[n:n + 1], d1), f"rasterize, view {n}"
+            de1, b1 = capi.render(v[n:n + 1].contiguous(), vi, i1)
+            assert th.equal(bary[n:n + 1], b1) and th.equal(depth[n:n + 1], de1), f"render, view {n}"
+        del d1, i1, de1, b1
+        g = th.Generator(device=DEV).manual_seed(2)
+        gd = th.rand(N, R, R, device=DEV, generator=g)
+        gb = th.empty_like(bary)
+        for n in range(N):
+            gb[n] = th.rand(3, R, R, device=DEV, generator=g) * 2 - 1
+        gv = capi.render_backward(v, vi, index, gd, gb)
+        n = N - 1
+        gv1 = capi.render_backward(v[n:n + 1].contiguous(), vi, index[n:n + 1].contiguous(), gd[n:n + 1].contiguous(), gb[n:n + 1].contiguous())
+        rel(gv[n:n + 1], gv1, "vertex gradient of the last view")
