@@ -1,0 +1,69 @@
+"""GPU (-m gpu): bench.py as the driver runs it -- `python bench.py ...` at N = 1 and
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+for N > 1 -- prints exactly ONE JSON line (rank 0) that carries the contract's keys.  A one-GPU box cannot run RCCL
+between ranks, so the two ranks share the GPU and use gloo (bench.py's test switches DRTK_DIST_BACKEND / DRTK_FORCE_DEVICE):
+everything around the collective is the real thing -- rank set-up, view sharding, the side-stream gradient reducer on
+HIP streams, max-over-ranks timing, rank 0 reporting while the other rank waits at the final barrier.  Small workload:
+this checks the launch path and the contract, not performance."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--mesh", "10k", "--res", "512", "--views", "2", "--channels", "3", "--steps", "3", "--warmup", "1", "--kernel-reps", "2"]
+TOP = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+       "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, extra_env=None):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, f"{' '.join(cmd)} exited {r.returncode}\n{r.stderr[-3000:]}"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}:\n{r.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+def _check_common(d, n_gpus):
+    assert TOP <= set(d), f"missing keys: {sorted(TOP - set(d))}"
+    assert d["n_gpus"] == n_gpus and d["steps"] == 3 and d["warmup"] == 1
+    assert d["unit"] == "Mpix/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    # value = pixels of ALL ranks / max-over-ranks time
+    px = n_gpus * d["config"]["views_per_gpu"] * d["config"]["height"] * d["config"]["width"]
+    assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf)
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+
+
+def test_single_process_line_carries_roofline_and_cpu_baseline():
+    d = _run([sys.executable, "bench.py", *SMALL, "--cpu-sample-views", "1"])
+    _check_common(d, 1)
+    cb = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb)
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mpix/s"
+
+
+def test_two_ranks_under_torch_distributed_run():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", *SMALL]
+    d = _run(cmd, {"DRTK_DIST_BACKEND": "gloo", "DRTK_FORCE_DEVICE": "0"})
+    _check_common(d, 2)
+    assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
+    assert "sharded 2-way" in d["config"]["parallelism"] and "all-reduce" in d["config"]["parallelism"]
