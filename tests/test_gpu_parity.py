@@ -959,3 +959,39 @@ def test_tensors_beyond_two_to_the_31_elements(which):
         n = N - 1
         gv1 = capi.render_backward(v[n:n + 1].contiguous(), vi, index[n:n + 1].contiguous(), gd[n:n + 1].contiguous(), gb[n:n + 1].contiguous())
         rel(gv[n:n + 1], gv1, "vertex gradient of the last view")
+
+
+@pytest.mark.parametrize("shape", [(3000, 24, 20, 3), (65535, 4, 4, 1), (700, 65, 33, 16)])
+def test_many_small_views(shape):
+    """Thousands of tiny views, up to the batch limit of 65535: the view is blockIdx.y in every kernel, the
+    blockIdx.x -> tile mapping runs with one or two blocks per image, the rasterizer picks 64-pixel tiles for
+    images smaller than a tile.  Against the oracle: forward bit-identical, gradients at the usual bar."""
+    import oracle as O
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    N, H, W, C = shape
+    v, vi = S.sphere_views(N, 6, 8, H, W)
+    g = th.Generator().manual_seed(0)
+    attr = th.rand(N, v.shape[1], C, generator=g)
+    go = th.rand(N, C, H, W, generator=g) * 2 - 1
+    gd = th.rand(N, H, W, generator=g)
+    gb = th.rand(N, 3, H, W, generator=g)
+    d_o, i_o = O.rasterize(v, vi, H, W, nthreads=0)
+    d_g, i_g = capi.rasterize(dev(v), dev(vi), H, W)
+    assert th.equal(i_g.cpu(), i_o) and th.equal(d_g.cpu(), d_o)
+    assert 0.2 < float((i_o != -1).float().mean()) < 0.7
+    rd_o, rb_o = O.render(v, vi, i_o, nthreads=0)
+    rd_g, rb_g = capi.render(dev(v), dev(vi), i_g)
+    assert th.equal(rd_g.cpu(), rd_o) and th.equal(rb_g.cpu(), rb_o)
+    img_o = O.interpolate(attr, vi, i_o, rb_o, nthreads=0)
+    assert th.equal(capi.interpolate(dev(attr), dev(vi), i_g, rb_g).cpu(), img_o)
+    close(capi.render_backward(dev(v), dev(vi), i_g, dev(gd), dev(gb)), O.render_backward(v, vi, i_o, gd, gb, nthreads=0), "render backward")
+    ag_o, bg_o = O.interpolate_backward(go, attr, vi, i_o, rb_o, nthreads=0)
+    ag_g, bg_g = capi.interpolate_backward(dev(go), dev(attr), dev(vi), i_g, rb_g)
+    close(ag_g, ag_o, "attr grad")
+    close(bg_g, bg_o, "bary grad")
+    img = img_o * (i_o != -1)[:, None]
+    eg_o = O.edge_grad_backward(v, img, i_o, vi, go, nthreads=0)
+    vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False, nthreads=0)
+    close(capi.edge_grad_backward_fused(dev(v), dev(img), i_g, dev(vi), rb_g, dev(go)), vg_o, "fused edge grad")
