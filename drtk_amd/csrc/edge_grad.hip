@@ -525,7 +525,10 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 // contributions (pixel A: -gA on the axis, -zA on z; pixel B: -gB, -zB; each times its own pixel's
 // barycentrics) through the run reduction of segscatter.hpp with six corner slots (A0..A2, B0..B2) and
 // two components each.
-template <typename T>
+// IDX_VEC: index_img is 16-byte aligned (its rows are fetched as int4); otherwise four scalar loads per row --
+// the only global vector access of this kernel, so that a contiguous but merely element-aligned index_img (a view
+// into a flat buffer) stays on the fused route.  W % 4 == 0 in both cases.
+template <typename T, bool IDX_VEC>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_pairs_kernel(
     const T* __restrict__ v_pix, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ bary_img, const T* __restrict__ gdx, const T* __restrict__ gdy, int64_t V, int64_t vi_sN,
@@ -567,8 +570,14 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
   for (int r = 0; r <= kRows; ++r) {
     const int y = y_base + r;
     if (in_x && y < H) {
-      const int4 q = *reinterpret_cast<const int4*>(idx_n + int64_t(y) * W + x0);
-      row[r][0] = q.x, row[r][1] = q.y, row[r][2] = q.z, row[r][3] = q.w;
+      const int32_t* rp = idx_n + int64_t(y) * W + x0; // x0 % 4 == 0 and W % 4 == 0: x0 + 3 < W
+      if constexpr (IDX_VEC) {
+        const int4 q = *reinterpret_cast<const int4*>(rp);
+        row[r][0] = q.x, row[r][1] = q.y, row[r][2] = q.z, row[r][3] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row[r][j] = rp[j];
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) row[r][j] = -1;
@@ -762,12 +771,8 @@ int launch_edge_dots(const T* img, const T* grad_output, const int32_t* index_im
   return DRTK_OK;
 }
 
-template <typename T>
-bool fused_vec_ok(const T* img, const T* grad_output, const int32_t* index_img, const void* workspace, int64_t W) {
-  return (W % 4 == 0) && (reinterpret_cast<uintptr_t>(img) % (4 * sizeof(T)) == 0) &&
-      (reinterpret_cast<uintptr_t>(grad_output) % (4 * sizeof(T)) == 0) &&
-      (reinterpret_cast<uintptr_t>(workspace) % (4 * sizeof(T)) == 0) &&
-      (reinterpret_cast<uintptr_t>(index_img) % 16 == 0);
+inline bool aligned_to(const void* p, size_t a) {
+  return reinterpret_cast<uintptr_t>(p) % a == 0;
 }
 
 template <typename T>
@@ -781,13 +786,24 @@ int edge_grad_backward_fused_impl(
   if (N * HW == 0) return DRTK_OK;
   T* gdx = static_cast<T*>(workspace);
   T* gdy = gdx + N * HW;
-  if (fused_vec_ok<T>(img, grad_output, index_img, workspace, W)) {
-    const int st = launch_edge_dots<T>(img, grad_output, index_img, N, C, H, W, gdx, gdy, true, stream);
+  if (W % 4 == 0) {
+    // The ROUTE -- and with it the workspace, 2 planes here against 5 below -- is decided by the shape alone,
+    // exactly like drtk_amd_edge_grad_backward_fused_workspace_bytes(), which sees no pointers.  Pointer alignment
+    // only picks the load width inside the route: inputs that are contiguous but merely element-aligned (views
+    // into a flat buffer) used to fall through to the 5-plane route with the 2 planes the query had promised.
+    const bool vec_a = aligned_to(img, 4 * sizeof(T)) && aligned_to(grad_output, 4 * sizeof(T)) &&
+        aligned_to(workspace, 4 * sizeof(T)) && aligned_to(index_img, 16);
+    const int st = launch_edge_dots<T>(img, grad_output, index_img, N, C, H, W, gdx, gdy, vec_a, stream);
     if (st != DRTK_OK) return st;
     const int strips_x = static_cast<int>(ceil_div(W, kWave * 4));
     const int64_t waves = int64_t(strips_x) * ceil_div(H, 4);
     const dim3 grid(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((edge_scatter_pairs_kernel<T>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, xcd_strip(ceil_div(int64_t(strips_x) * 4, kBlock / kWave)));
+    const int strip = xcd_strip(ceil_div(int64_t(strips_x) * 4, kBlock / kWave));
+    if (aligned_to(index_img, 16)) {
+      hipLaunchKernelGGL((edge_scatter_pairs_kernel<T, true>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
+    } else {
+      hipLaunchKernelGGL((edge_scatter_pairs_kernel<T, false>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
+    }
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;
   }

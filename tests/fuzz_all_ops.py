@@ -60,11 +60,23 @@ def make_case(seed):
                 go=go, gd=gd, gb=gb)
 
 
-def run_case(c):
+def misaligned(x):
+    """`x` on the device as a CONTIGUOUS tensor whose pointer is only element-aligned: one element into a flat
+    buffer (what unpacking a flat parameter buffer gives).  16-byte vector paths must not be taken for it."""
+    x = x.to(DEV)
+    flat = th.empty(x.numel() + 8, dtype=x.dtype, device=DEV)
+    out = flat[1:1 + x.numel()].view(x.shape)
+    out.copy_(x)
+    assert out.is_contiguous() and (x.numel() == 0 or out.data_ptr() % 16 != 0)
+    return out
+
+
+def run_case(c, place=None):
+    """`place(tensor)` puts an input on the device (default: a plain copy; `misaligned` for odd pointers)."""
     import oracle as O
     from drtk_amd import capi
 
-    d = lambda x: x.to(DEV)  # noqa: E731
+    d = place or (lambda x: x.to(DEV))
     v, vi, H, W = c["v"], c["vi"], c["H"], c["W"]
     tight = c["dtype"] == th.float64
     d_o, i_o = O.rasterize(v, vi, H, W, nthreads=0)
