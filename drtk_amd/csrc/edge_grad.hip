@@ -837,6 +837,7 @@ extern "C" int drtk_amd_edge_grad_backward(
   if (N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || N > 65535 ||
       (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31))
     return DRTK_ERR_INVALID_ARGUMENT;
+  if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return DRTK_ERR_INVALID_ARGUMENT; // include/drtk_amd.h, alignment
   size_t need = 0;
   if (drtk_amd_edge_grad_backward_workspace_bytes(dtype, N, H, W, &need) != DRTK_OK) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W > 0) {
@@ -874,6 +875,7 @@ extern "C" int drtk_amd_edge_grad_backward_fused(
   if (N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || N > 65535 ||
       (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31))
     return DRTK_ERR_INVALID_ARGUMENT;
+  if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return DRTK_ERR_INVALID_ARGUMENT; // include/drtk_amd.h, alignment
   size_t need = 0;
   if (drtk_amd_edge_grad_backward_fused_workspace_bytes(dtype, N, H, W, &need) != DRTK_OK) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * V > 0 && !grad_v_pix) return DRTK_ERR_INVALID_ARGUMENT;

@@ -997,6 +997,8 @@ extern "C" int drtk_amd_rasterize(
     int64_t vi_sN, int64_t H, int64_t W, int wireframe, float* depth_img, int32_t* index_img,
     void* workspace, size_t workspace_bytes, drtk_stream_t stream) {
   if (N < 0 || V < 0 || F < 0 || H <= 0 || W <= 0) return DRTK_ERR_INVALID_ARGUMENT; // :464-468
+  // 64-bit counters / packed pixels updated with 64-bit atomics live in the workspace (include/drtk_amd.h, alignment)
+  if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return DRTK_ERR_INVALID_ARGUMENT;
   if (V >= 0x10000000LL) return DRTK_ERR_TOO_MANY_VERTICES;                           // :459-462
   if (wireframe) {
     if (N > 65535 || N * H * W >= (int64_t(1) << 40) || (dtype != DRTK_F32 && dtype != DRTK_F64)) return DRTK_ERR_INVALID_ARGUMENT;

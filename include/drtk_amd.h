@@ -15,6 +15,13 @@
  *       index_img       [N,H,W] int32  (-1 = empty)
  *       depth_img       [N,H,W]        bary_img   [N,3,H,W]   (planar)
  *       attrs           [N,V,C]        img / out  [N,C,H,W]   (planar)
+ *   - alignment: tensor pointers need the alignment of their ELEMENT type only (4 bytes for float / int32, 8 for
+ *     double) -- a contiguous view at any element offset of a larger buffer is fine, for inputs and for outputs.
+ *     The kernels take their 16-byte vector paths when a tensor happens to be 16-byte aligned (every hipMalloc /
+ *     torch allocation is) and the image width allows it; otherwise they fall back to scalar accesses or rely on
+ *     the platform's support for dword-aligned wide accesses (tests/test_gpu_parity.py, ..._odd_element_offsets).
+ *     WORKSPACES must be 16-byte aligned (they hold 64-bit counters updated atomically); this is checked:
+ *     DRTK_ERR_INVALID_ARGUMENT otherwise.
  *   - `dtype` selects float or double for every floating tensor of the call (the reference
  *     dispatches float/double only: src/include/kernel_utils.h:35-57); indices are int32.
  *   - `stream` is a hipStream_t (NULL = the null stream).  No call synchronises the device or

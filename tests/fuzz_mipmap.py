@@ -60,11 +60,12 @@ def make_case(seed):
                 dtype=dtype)
 
 
-def run_case(c):
+def run_case(c, place=None):
+    """`place(tensor)` puts an input on the device (default: a plain copy; fuzz_all_ops.misaligned for odd pointers)."""
     import oracle as O
     from drtk_amd import capi
 
-    d = lambda x: x.to(DEV)  # noqa: E731
+    d = place or (lambda x: x.to(DEV))
     args = (c["max_aniso"], c["padding"], c["mode"], c["align"], c["force"], c["clip"])
     f64 = c["dtype"] == th.float64
     tol = dict(atol=1e-11, rtol=1e-10) if f64 else dict(atol=2e-5, rtol=2e-5)

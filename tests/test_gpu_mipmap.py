@@ -332,3 +332,18 @@ def test_zero_sized_dimensions_of_the_texture_and_sparse_ops():
         finite(A, M, b.grad)
         if zero == "F":
             assert float(b.grad.abs().sum()) == 0.0 and A.shape[0] == 0
+
+
+def test_randomised_mipmap_cases_with_inputs_at_odd_element_offsets():
+    """The sampler reads `grid` as 8-byte and `vt_dxdy_img` as 16-byte vectors per pixel; with contiguous inputs that
+    are only element-aligned (views one element into a flat buffer) the results are those of the aligned call
+    (platform support for dword-aligned wide accesses; include/drtk_amd.h, alignment)."""
+    import fuzz_all_ops as FA
+    import fuzz_mipmap as F
+
+    for seed in range(15):
+        c = F.make_case(seed)
+        try:
+            F.run_case(c, place=FA.misaligned)
+        except Exception as e:
+            raise AssertionError(f"seed {seed}: {F.describe(c)}: {type(e).__name__}: {e}") from e

@@ -1030,3 +1030,42 @@ def test_contiguous_inputs_at_odd_element_offsets():
         grads.append(vv.grad)
     close(grads[1], grads[0], "edge_grad_estimator backward with misaligned inputs", atol=1e-4)
     assert float(grads[0].abs().max()) > 0
+
+
+def test_c_abi_output_and_workspace_pointers_at_odd_element_offsets():
+    """A C caller sub-allocating from an arena: OUTPUT pointers that are only element-aligned (ptr % 16 = 4, 8, 12)
+    give the bit-identical images and nothing is written outside them -- rasterize stores its tiles as 16-byte
+    vectors whenever W % 4 == 0 and relies on the platform's dword-aligned wide accesses (include/drtk_amd.h,
+    alignment).  A misaligned WORKSPACE (64-bit atomics live there) is refused, not dereferenced."""
+    import ctypes
+
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    H, W, N = 96, 128, 2
+    v, vi = S.sphere_views(N, 12, 16, H, W, second_sphere=True, device=DEV)
+    want_d, want_i = capi.rasterize(v, vi, H, W)
+    L = capi.lib()
+    n = N * H * W
+    fi = th.empty(n + 8, dtype=th.int32, device=DEV)
+    fd = th.empty(n + 8, dtype=th.float32, device=DEV)
+    nbytes = capi.rasterize_workspace_bytes(N, vi.shape[0], H, W)
+    ws = th.empty(nbytes + 16, dtype=th.uint8, device=DEV)
+
+    def call(off, ws_off):
+        return L.drtk_amd_rasterize(
+            ctypes.c_int(0), ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(vi.data_ptr()), ctypes.c_int64(N), ctypes.c_int64(v.shape[1]),
+            ctypes.c_int64(vi.shape[0]), ctypes.c_int64(0), ctypes.c_int64(H), ctypes.c_int64(W), ctypes.c_int(0),
+            ctypes.c_void_p(fd.data_ptr() + 4 * off), ctypes.c_void_p(fi.data_ptr() + 4 * off), ctypes.c_void_p(ws.data_ptr() + ws_off),
+            ctypes.c_size_t(nbytes), ctypes.c_void_p(th.cuda.current_stream().cuda_stream))
+
+    for off in (0, 1, 2, 3):
+        fi.fill_(-7)
+        fd.fill_(-7.0)
+        assert call(off, 0) == 0
+        th.cuda.synchronize()
+        assert th.equal(fi[off:off + n].view(N, H, W), want_i) and th.equal(fd[off:off + n].view(N, H, W), want_d), f"offset {off}"
+        for buf in (fi, fd):
+            assert bool((buf[:off] == -7).all()) and bool((buf[off + n:] == -7).all()), f"offset {off}: wrote outside the image"
+    for ws_off in (4, 8, 12):
+        assert call(0, ws_off) == -1

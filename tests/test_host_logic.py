@@ -48,6 +48,25 @@ def test_c_abi_argument_validation_without_gpu():
                               ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(0), z, z, z,
                               ctypes.c_size_t(0), z)
     assert rc == -5  # V >= 2^28 (rasterize_kernel.cu:459-462)
+    # workspaces hold 64-bit counters updated atomically: they must be 16-byte aligned (include/drtk_amd.h), which is
+    # checked BEFORE the size -- an aligned workspace that is too small is -2, a misaligned one of any size is -1
+    big = ctypes.c_size_t(1 << 30)
+    for wire in (0, 1):
+        args = lambda ws, nbytes: (ctypes.c_int(0), z, z, ctypes.c_int64(1), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0),  # noqa: E731
+                                   ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(wire), ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                   ctypes.c_void_p(ws), nbytes, z)
+        assert L.drtk_amd_rasterize(*args(4096, ctypes.c_size_t(0))) == -2
+        for off in (4, 8, 12):
+            assert L.drtk_amd_rasterize(*args(4096 + off, big)) == -1
+    for fn, extra in ((L.drtk_amd_edge_grad_backward, ()), (L.drtk_amd_edge_grad_backward_fused, ("bary",))):
+        def call(ws, nbytes):
+            a = [ctypes.c_int(0), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16)]
+            a += [ctypes.c_void_p(16)] * len(extra) + [ctypes.c_void_p(16)]                                  # (bary_img,) grad_output
+            a += [ctypes.c_int64(1), ctypes.c_int64(3), ctypes.c_int64(1), ctypes.c_int64(1), ctypes.c_int64(0), ctypes.c_int64(4),
+                  ctypes.c_int64(4), ctypes.c_double(1e4), ctypes.c_void_p(16), ctypes.c_void_p(ws), nbytes, z]
+            return fn(*a)
+        assert call(4096, ctypes.c_size_t(0)) == -2
+        assert call(4096 + 4, big) == -1
 
 
 def test_torch_operator_schemas_match_reference():
