@@ -1069,3 +1069,43 @@ def test_c_abi_output_and_workspace_pointers_at_odd_element_offsets():
             assert bool((buf[:off] == -7).all()) and bool((buf[off + n:] == -7).all()), f"offset {off}: wrote outside the image"
     for ws_off in (4, 8, 12):
         assert call(0, ws_off) == -1
+
+
+def test_many_channels_and_extreme_max_dp_dr():
+    """Feature maps with hundreds / thousands of channels (the sweeps stop at 33; the kernels walk channel blocks with
+    several specialisations) and the edge-gradient clamp at inf (= off, a plausible setting), 1e-30, negative and NaN:
+    against the oracle."""
+    import oracle as O
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    H, W, N = 48, 64, 2
+    v, vi = S.sphere_views(N, 10, 12, H, W, second_sphere=True)
+    _, i_o = O.rasterize(v, vi, H, W)
+    _, rb_o = O.render(v, vi, i_o)
+    for C in (257, 4099):
+        g = th.Generator().manual_seed(C)
+        attr = th.rand(N, v.shape[1], C, generator=g)
+        go = th.rand(N, C, H, W, generator=g) * 2 - 1
+        img_o = O.interpolate(attr, vi, i_o, rb_o, nthreads=0)
+        assert th.equal(capi.interpolate(dev(attr), dev(vi), dev(i_o), dev(rb_o)).cpu(), img_o), f"C={C}: interpolate"
+        ag_o, bg_o = O.interpolate_backward(go, attr, vi, i_o, rb_o, nthreads=0)
+        ag_g, bg_g = capi.interpolate_backward(dev(go), dev(attr), dev(vi), dev(i_o), dev(rb_o))
+        close(ag_g, ag_o, f"C={C}: attr grad")
+        close(bg_g, bg_o, f"C={C}: bary grad", atol=1e-4)
+        img = img_o * (i_o != -1)[:, None]
+        eg_o = O.edge_grad_backward(v, img, i_o, vi, go, nthreads=0)
+        close(capi.edge_grad_backward(dev(v), dev(img), dev(i_o), dev(vi), dev(go)), eg_o, f"C={C}: edge grad", atol=1e-4)
+        vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False)
+        close(capi.edge_grad_backward_fused(dev(v), dev(img), dev(i_o), dev(vi), dev(rb_o), dev(go)), vg_o, f"C={C}: fused edge grad", atol=1e-4)
+    C = 5
+    g = th.Generator().manual_seed(1)
+    attr = th.rand(N, v.shape[1], C, generator=g)
+    go = th.rand(N, C, H, W, generator=g) * 2 - 1
+    img = O.interpolate(attr, vi, i_o, rb_o) * (i_o != -1)[:, None]
+    for M in (float("inf"), 1e30, 1e-30, 1e-3, -1.0, float("nan")):
+        eg_o = O.edge_grad_backward(v, img, i_o, vi, go, M)
+        assert bool(th.isfinite(eg_o).all())
+        close(capi.edge_grad_backward(dev(v), dev(img), dev(i_o), dev(vi), dev(go), M), eg_o, f"max_dp_dr={M}: edge grad")
+        vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False)
+        close(capi.edge_grad_backward_fused(dev(v), dev(img), dev(i_o), dev(vi), dev(rb_o), dev(go), M), vg_o, f"max_dp_dr={M}: fused edge grad")
