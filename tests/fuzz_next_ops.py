@@ -1,0 +1,155 @@
+"""Randomised sweep of the 'next row' ops -- sparse interpolation operators (incl. the device-side A^T A pattern
+builder), screen_space_uv_derivative, pinhole transform -- against the CPU oracle / the f64 PyTorch formulation (not
+collected by pytest: `python tests/fuzz_next_ops.py --cases 200` on a GPU box; a fixed subset runs as
+tests/test_gpu_mipmap.py::test_randomised_sparse_uv_and_transform_cases).  Awkward image sizes, f32 / f64, shared and
+per-view topology, random foreground masks and upstream gradients."""
+import argparse
+import os
+import sys
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+DEV = "cuda:0"
+
+
+def _close(a, ref, what, atol=1e-5, rtol=1e-5):
+    a = a.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    tol = atol + rtol * float(ref.abs().max()) if ref.numel() else atol
+    err = float((a - ref).abs().max()) if ref.numel() else 0.0
+    assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
+
+
+def make_case(seed):
+    from drtk_amd import synthetic as S
+    from drtk_amd.transform import transform
+
+    g = th.Generator().manual_seed(5000 + seed)
+    r = lambda lo, hi: int(th.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    N = r(1, 3)
+    H = [1, 2, 7, 16, 17, 33, 64, 65, 100][r(0, 8)]
+    W = [1, 3, 4, 5, 8, 63, 64, 66, 100, 127, 130][r(0, 10)]
+    dtype = th.float64 if r(0, 2) == 0 else th.float32
+    v_world, vi = S.uv_sphere(r(3, 14), r(3, 18), lobes=0.1 * r(0, 2), dtype=th.float64)
+    cams = S.ring_cameras(N, W, H, dtype=th.float64)
+    per_view_v = r(0, 2) == 0
+    vN = v_world[None].repeat(N, 1, 1)
+    if per_view_v:
+        vN = vN + 0.02 * th.randn(N, 1, 3, generator=g, dtype=th.float64)
+    batched_vi = r(0, 3) == 0
+    if batched_vi:
+        vi = vi[None].repeat(N, 1, 1)
+        if N > 1:
+            vi[1] = vi[1].flip(-1)
+    V = v_world.shape[0]
+    vt = th.rand(N, V, 2, generator=g, dtype=th.float64)
+    return dict(N=N, H=H, W=W, V=V, dtype=dtype, vN=vN.to(dtype), vi=vi.contiguous(), cams=tuple(c.to(dtype) for c in cams),
+                cams64=cams, vN64=vN, vt=vt.to(dtype), batched_vi=batched_vi, seed=seed,
+                mask_keep=th.rand(N, H, W, generator=g) > 0.2, g=g)
+
+
+def run_case(c):
+    import oracle as O
+    import drtk_amd
+    from drtk_amd import capi
+    from drtk_amd.transform import transform, transform_with_v_cam
+
+    d = lambda x: x.to(DEV)  # noqa: E731
+    N, H, W, V, dtype, vi, g = c["N"], c["H"], c["W"], c["V"], c["dtype"], c["vi"], c["g"]
+    f64 = dtype == th.float64
+
+    # ---- transform (forward + gradient wrt v) against the PyTorch formulation in f64 on the CPU
+    v64 = c["vN64"].clone().requires_grad_(True)
+    ref, _ = transform_with_v_cam(v64, *c["cams64"])
+    gout = th.rand(ref.shape, dtype=th.float64, generator=g) * 2 - 1
+    (ref * gout).sum().backward()
+    vd = d(c["vN"]).requires_grad_(True)
+    out = transform(vd, *(d(t) for t in c["cams"]))
+    (out * d(gout.to(dtype))).sum().backward()
+    ttol = dict(atol=1e-9, rtol=1e-11) if f64 else dict(atol=2e-3, rtol=2e-6)  # pixel coordinates are O(W): ~1 ulp at 1e2..1e3
+    _close(out, ref, "transform", **ttol)
+    _close(vd.grad, v64.grad, "transform grad", **(dict(atol=1e-8, rtol=1e-10) if f64 else dict(atol=1e-2, rtol=2e-5)))
+
+    # ---- a consistent rasterization of these views (oracle), shared by the remaining ops
+    v_pix = out.detach().cpu()
+    _, index = O.rasterize(v_pix, vi, H, W)
+    _, bary = O.render(v_pix, vi, index)
+    dvi, dindex, dbary = d(vi), d(index), d(bary)
+
+    # ---- sparse operators
+    crow_o, col_o, val_o, rows_o = O.interpolation_matrix(vi, index, bary)
+    crow, col, values, rows = capi.interpolation_matrix(dvi, dindex, dbary)
+    assert th.equal(crow.cpu(), crow_o) and th.equal(col.cpu(), col_o) and th.equal(rows.cpu(), rows_o), "interpolation matrix structure"
+    assert th.equal(values.cpu(), val_o), "interpolation matrix values"
+    gim = (th.rand(val_o.shape, generator=g, dtype=th.float64) * 2 - 1).to(dtype)
+    assert th.equal(capi.interpolation_matrix_backward(d(gim), dvi, dindex, rows).cpu(), O.interpolation_matrix_backward(gim, vi, index, bary, rows_o)), "interpolation matrix backward"
+    vi3 = vi if vi.ndim == 3 else vi[None].expand(N, -1, -1)  # the oracle's builder takes the expanded topology, like the reference
+    ncrow_o, ncol_o, pair_o = O.normal_matrix_structure(vi3, V)
+    nnz = ncol_o.numel()
+    M = drtk_amd.interpolation_normal_matrix(dvi, dindex, dbary, V)  # pattern built on the device
+    assert th.equal(M.crow_indices().cpu(), ncrow_o) and th.equal(M.col_indices().cpu(), ncol_o), "A^T A pattern"
+    nv_o = O.normal_matrix_values(pair_o, index, bary, nnz)
+    tol = dict(atol=1e-12, rtol=1e-10) if f64 else dict(atol=1e-5, rtol=1e-5)
+    _close(M.values(), nv_o, "A^T A values (python api)", **tol)
+    _close(capi.interpolation_normal_matrix_values(d(pair_o), dindex, dbary, nnz), nv_o, "A^T A values", **tol)
+    gnm = (th.rand(nnz, generator=g, dtype=th.float64) * 2 - 1).to(dtype)
+    _close(capi.interpolation_normal_matrix_values_backward(d(gnm), d(pair_o), dindex, dbary), O.normal_matrix_values_backward(gnm, pair_o, index, bary),
+           "A^T A values backward", **tol)
+
+    # ---- screen_space_uv_derivative (mask within the foreground: background pixels are a documented difference)
+    if c["batched_vi"]:
+        return  # the op takes one topology for all views, like the reference
+    mask = (index != -1) & c["mask_keep"]
+    campos, camrot, focal = c["cams"][0], c["cams"][1], c["cams"][2]
+    want = O.screen_space_uv_derivative(c["vN"], c["vt"], vi, vi, index, bary, mask, campos, camrot, focal)
+    got = capi.screen_space_uv_derivative(d(c["vN"]), d(c["vt"]), dvi, dvi, dindex, dbary, d(mask), d(campos), d(camrot), d(focal))
+    if f64:
+        _close(got, want, "screen_space_uv_derivative", atol=1e-11, rtol=1e-10)  # pins the formula
+        return
+    # f32: the op inverts a 2x2 Jacobian that is nearly singular for triangles seen edge-on; there two f32 evaluations
+    # with different operation orders (the reference's PyTorch composite vs the kernel's closed form) scatter around
+    # the exact value by up to 1e-1 and comparing them WITH EACH OTHER means nothing.  Measured against the f64 result
+    # the two have the same error distribution (median ~1.4e-7 relative, equal 90 % quantiles); the single worst pixel
+    # is heavy-tailed luck -- at the worst pixels of five seeds the composite was 1-4x further off than the kernel, on
+    # a one-pixel sliver of another seed 20x closer.  So the bar is on the DISTRIBUTION: as accurate as the reference
+    # formulation is in f32 (median, 90 % quantile), plus a loose bound on the worst pixel against gross errors.
+    truth = O.screen_space_uv_derivative(c["vN"].double(), c["vt"].double(), vi, vi, index, bary.double(), mask, campos.double(),
+                                         camrot.double(), focal.double())
+    e_g = (got.cpu().double() - truth).abs().amax((-1, -2))
+    e_r = (want.double() - truth).abs().amax((-1, -2))
+    assert bool(th.isfinite(got).all())
+    scale = float(truth.abs().max())
+    assert float(e_g.max()) <= 100 * float(e_r.max()) + 1e-4 * scale + 1e-30, \
+        f"screen_space_uv_derivative (f32): worst pixel {float(e_g.max()):.3e} vs f64, the reference composite's {float(e_r.max()):.3e}"
+    if int(mask.sum()) >= 20:
+        px_scale = truth.abs().amax((-1, -2)).clamp_min(1e-30)
+        rg, rr = (e_g / px_scale)[mask], (e_r / px_scale)[mask]
+        assert float(rg.median()) <= 1e-6, f"screen_space_uv_derivative (f32): median relative error {float(rg.median()):.3e}"
+        q90g, q90r = float(th.quantile(rg, 0.9)), float(th.quantile(rr, 0.9))
+        assert q90g <= 4 * q90r + 1e-6, f"screen_space_uv_derivative (f32): 90 % quantile of the relative error {q90g:.3e}, the composite's {q90r:.3e}"
+
+
+def describe(c):
+    return (f"N={c['N']} H={c['H']} W={c['W']} V={c['V']} F={c['vi'].shape[-2]} {str(c['dtype']).split('.')[-1]} "
+            f"batched_vi={c['batched_vi']}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--first", type=int, default=0)
+    a = ap.parse_args()
+    bad = 0
+    for seed in range(a.first, a.first + a.cases):
+        c = make_case(seed)
+        try:
+            run_case(c)
+        except Exception as e:
+            bad += 1
+            print(f"FAIL seed {seed}: {describe(c)}: {type(e).__name__}: {str(e)[:160]}", flush=True)
+    print(f"{a.cases - bad}/{a.cases} cases passed")
+    sys.exit(1 if bad else 0)

@@ -347,3 +347,20 @@ def test_randomised_mipmap_cases_with_inputs_at_odd_element_offsets():
             F.run_case(c, place=FA.misaligned)
         except Exception as e:
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {type(e).__name__}: {e}") from e
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_randomised_sparse_uv_and_transform_cases(block):
+    """16 seeded cases per block from tests/fuzz_next_ops.py: the sparse interpolation operators (structure and
+    interpolation-matrix values bit-exact, the device-built A^T A pattern identical to the restated one, accumulated
+    values at the usual bar), screen_space_uv_derivative (f64: 1e-10 against the restated composite; f32: as accurate
+    against the f64 result as the reference formulation itself -- the op is ill-conditioned at grazing triangles) and
+    transform + its gradient against the f64 PyTorch formulation; awkward image sizes, shared / per-view topology."""
+    import fuzz_next_ops as F
+
+    for seed in range(16 * block, 16 * block + 16):
+        c = F.make_case(seed)
+        try:
+            F.run_case(c)
+        except Exception as e:
+            raise AssertionError(f"seed {seed}: {F.describe(c)}: {type(e).__name__}: {e}") from e
