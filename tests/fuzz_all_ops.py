@@ -83,6 +83,12 @@ def run_case(c, place=None):
     d_g, i_g = capi.rasterize(d(v), d(vi), H, W)
     assert th.equal(i_g.cpu(), i_o), "index_img"
     assert th.equal(d_g.cpu(), d_o), "rasterize depth"
+    # wireframe mode: CUDA-only in the reference, so this holds the kernel to the RESTATEMENT of that source (parity with
+    # the reference itself is unpinned); the diamond rule is exact float comparisons -> bit-exact
+    wd_o, wi_o = O.rasterize_lines(v, vi, H, W)
+    wd_g, wi_g = capi.rasterize(d(v), d(vi), H, W, wireframe=True)
+    assert th.equal(wi_g.cpu(), wi_o), "wireframe index_img"
+    assert th.equal(wd_g.cpu(), wd_o), "wireframe depth"
     rd_o, rb_o = O.render(v, vi, i_o, nthreads=0)
     rd_g, rb_g = capi.render(d(v), d(vi), i_g)
     assert th.equal(rd_g.cpu(), rd_o) and th.equal(rb_g.cpu(), rb_o), "render forward bits"
