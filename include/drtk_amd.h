@@ -117,7 +117,9 @@ int drtk_amd_interpolate_masked(
 
 /* interpolate_backward  replaces interpolate_cuda_backward (interpolate_kernel.cu:642-697)
  * attr_grad [N,V,C] (NULL = not wanted) is zero-filled then accumulated; bary_grad [N,3,H,W]
- * (NULL = not wanted) is fully written.  At least one must be non-NULL.
+ * (NULL = not wanted) is fully written.  An EMPTY output (N*V*C == 0 / N*H*W == 0) has no storage, so NULL for it
+ * carries no information: both NULL is DRTK_ERR_INVALID_ARGUMENT only when both gradients would have had elements,
+ * otherwise there is nothing to write and the call returns DRTK_OK (e.g. a batch of zero views).
  */
 int drtk_amd_interpolate_backward(
     drtk_dtype_t dtype, const void* grad_out, const void* attrs, const int32_t* vi,
