@@ -1109,3 +1109,69 @@ def test_many_channels_and_extreme_max_dp_dr():
         close(capi.edge_grad_backward(dev(v), dev(img), dev(i_o), dev(vi), dev(go), M), eg_o, f"max_dp_dr={M}: edge grad")
         vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False)
         close(capi.edge_grad_backward_fused(dev(v), dev(img), dev(i_o), dev(vi), dev(rb_o), dev(go), M), vg_o, f"max_dp_dr={M}: fused edge grad")
+
+
+def test_inconsistent_shapes_and_dtypes_are_rejected_like_the_reference():
+    """Every TORCH_CHECK of the reference's launchers that guards a shape or dtype relation between the tensors of
+    one call (render_kernel.cu:285-336, interpolate_kernel.cu:459-530, edge_grad_module.cpp:37-115, rasterize_kernel.cu:
+    423-468) has its counterpart, with the reference's message: a missing one would not be a wrong answer but an
+    out-of-bounds access.  Also for the fused edge_grad extension, which takes bary_img in place of v_pix_img."""
+    import drtk_amd  # noqa: F401  (registers the operators)
+
+    N, V, F, C, H, W = 2, 9, 6, 4, 8, 12
+    g = th.Generator(device=DEV).manual_seed(0)
+    v = th.rand(N, V, 3, device=DEV, generator=g) + th.tensor([0, 0, 2.0], device=DEV)
+    vi = th.randint(0, V, (N, F, 3), device=DEV, generator=g).int()
+    index = th.randint(-1, F, (N, H, W), device=DEV, generator=g).int()
+    bary = th.rand(N, 3, H, W, device=DEV, generator=g)
+    attr = th.rand(N, V, C, device=DEV, generator=g)
+    img = th.rand(N, C, H, W, device=DEV, generator=g)
+    vpi = th.rand(N, 3, H, W, device=DEV, generator=g)
+    RA, R, I = th.ops.rasterize_ext.rasterize, th.ops.render_ext.render, th.ops.interpolate_ext.interpolate
+    E, EF = th.ops.edge_grad_ext.edge_grad_estimator, th.ops.edge_grad_ext.edge_grad_estimator_fused
+    v4 = th.rand(N, V, 4, device=DEV)
+    vi4 = th.zeros(N, F, 4, dtype=th.int32, device=DEV)
+    one = lambda t: t[:1].contiguous()  # noqa: E731
+    cases = [
+        (r"rasterize\(\): expected first dim of vi to match", lambda: RA(v, one(vi), H, W, False)),
+        (r"rasterize\(\): expected third dim of v and last dim of vi to be 3", lambda: RA(v4, vi, H, W, False)),
+        (r"rasterize\(\): expected third dim of v and last dim of vi to be 3", lambda: RA(v, vi4, H, W, False)),
+        (r"render\(\): expected v to have floating point type", lambda: R(v.int(), vi, index)),
+        (r"render\(\): expected vi to have int32 type", lambda: R(v, vi.long(), index)),
+        (r"render\(\): expected index_img to have int32 type", lambda: R(v, vi, index.long())),
+        (r"render\(\): expected v.ndim == 3", lambda: R(v[0], vi, index)),
+        (r"render\(\): expected v.ndim == 3", lambda: R(v, vi, index[0])),
+        (r"render\(\): expected v and index_img to have same batch size", lambda: R(v, vi, one(index))),
+        (r"render\(\): expected first dim of vi to match first dim of v", lambda: R(v, one(vi), index)),
+        (r"render\(\): expected third dim of v and vi to be 3", lambda: R(v4, vi, index)),
+        (r"render\(\): expected third dim of v and vi to be 3", lambda: R(v, vi[..., :2].contiguous(), index)),
+        (r"interpolate\(\): expected vert_attributes and bary_img to have same dtype", lambda: I(attr.double(), vi, index, bary)),
+        (r"interpolate\(\): expected vert_attributes to have floating point type", lambda: I(attr.int(), vi, index, bary.int())),
+        (r"interpolate\(\): expected vi to have int32 type", lambda: I(attr, vi.long(), index, bary)),
+        (r"interpolate\(\): expected index_img to have int32 type", lambda: I(attr, vi, index.long(), bary)),
+        (r"interpolate\(\): expected vert_attributes.ndim == 3", lambda: I(attr, vi, index, bary[:, 0])),
+        (r"interpolate\(\): expected vert_attributes, index_img and bary_img to have same batch size", lambda: I(one(attr), one(vi), index, bary)),
+        (r"interpolate\(\): expected vert_attributes, index_img and bary_img to have same batch size", lambda: I(attr, vi, index, one(bary))),
+        (r"interpolate\(\): expected last dim of vi to be 3 and second dim of bary_img to be 3", lambda: I(attr, vi, index, th.rand(N, 4, H, W, device=DEV))),
+        (r"interpolate\(\): expected last dim of vi to be 3 and second dim of bary_img to be 3", lambda: I(attr, vi4, index, bary)),
+        (r"interpolate\(\): expected first dim of vi to match first dim of vert_attributes", lambda: I(attr, one(vi), index, bary)),
+        (r"interpolate\(\): expected H and W dims of index_img and bary_img to match", lambda: I(attr, vi, index[:, : H - 1].contiguous(), bary)),
+        (r"interpolate\(\): expected H and W dims of index_img and bary_img to match", lambda: I(attr, vi, index[:, :, : W - 2].contiguous(), bary)),
+        (r"interpolate\(\): expected H and W dims of index_img and bary_img to match", lambda: I(attr, vi, th.zeros(N, H + 4, W, dtype=th.int32, device=DEV), bary)),
+        (r"edge_grad_estimator\(\): expected width and height of v_pix_img, img, and index_img to match", lambda: E(v, vpi, vi, img[..., : W - 2].contiguous(), index, 1e4)),
+        (r"edge_grad_estimator\(\): expected width and height of v_pix_img, img, and index_img to match", lambda: E(v, vpi[:, :, : H - 1].contiguous(), vi, img, index, 1e4)),
+        (r"edge_grad_estimator\(\): expected v and index_img to have same batch size", lambda: E(v, vpi, vi, one(img), index, 1e4)),
+        (r"edge_grad_estimator\(\): expected third dim of v_pix to be of size 3", lambda: E(v, vpi[:, :2].contiguous(), vi, img, index, 1e4)),
+        (r"edge_grad_estimator\(\): expected third dim of v_pix to be of size 3", lambda: E(v4, vpi, vi, img, index, 1e4)),
+        (r"edge_grad_estimator\(\): expected index_img to have int32 type", lambda: E(v, vpi, vi, img, index.long(), 1e4)),
+        (r"edge_grad_estimator\(\): expected v_pix, v_pix_img, and img to have floating point type", lambda: E(v, vpi, vi, img.int(), index, 1e4)),
+        (r"edge_grad_estimator\(\): expected width and height of v_pix_img, img, and index_img to match", lambda: EF(v, vi, bary, img[..., : W - 2].contiguous(), index, 1e4)),
+        (r"edge_grad_estimator\(\): expected width and height of v_pix_img, img, and index_img to match", lambda: EF(v, vi, bary[:, :, : H - 1].contiguous(), img, index, 1e4)),
+        (r"edge_grad_estimator\(\): expected v and index_img to have same batch size", lambda: EF(v, vi, bary, one(img), index, 1e4)),
+        (r"edge_grad_estimator\(\): expected bary_img of shape \[N, 3, H, W\]", lambda: EF(v, vi, bary[:, :2].contiguous(), img, index, 1e4)),
+    ]
+    for pattern, fn in cases:
+        with pytest.raises(RuntimeError, match=pattern):
+            fn()
+    # and the consistent call works
+    assert tuple(I(attr, vi, index, bary).shape) == (N, C, H, W)
