@@ -364,3 +364,63 @@ def test_randomised_sparse_uv_and_transform_cases(block):
             F.run_case(c)
         except Exception as e:
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {type(e).__name__}: {e}") from e
+
+
+def test_inconsistent_shapes_and_dtypes_are_rejected_by_the_sampler_and_the_sparse_ops():
+    """The relations the reference checks between the tensors of one call (mipmap_grid_sampler_kernel.cu:911-990,
+    interpolate_kernel.cu:703-836), with its messages -- plus two it does not check and would index out of bounds on:
+    the spatial size of vt_dxdy_img against grid, and vertex indices beyond num_vertices in the A^T A pattern."""
+    import drtk_amd  # noqa: F401  (registers the operators)
+
+    N, C, H, W, V, F = 2, 3, 6, 10, 9, 6
+    g = th.Generator(device=DEV).manual_seed(0)
+
+    def tex(n=N, c=C, dt=th.float32):
+        return [th.rand(n, c, 16, 16, device=DEV, dtype=dt), th.rand(n, c, 8, 8, device=DEV, dtype=dt)]
+
+    grid = th.rand(N, H, W, 2, device=DEV) * 2 - 1
+    jac = th.randn(N, H, W, 2, 2, device=DEV) * 0.05
+    M = th.ops.mipmap_grid_sampler_ext.mipmap_grid_sampler_2d
+    m = lambda t, gr, j: M(t, gr, j, 4, 1, 0, False, False, False)  # noqa: E731
+    vi = th.randint(0, V, (N, F, 3), device=DEV, generator=g).int()
+    index = th.randint(-1, F, (N, H, W), device=DEV, generator=g).int()
+    bary = th.rand(N, 3, H, W, device=DEV, generator=g)
+    pair = th.zeros(N, F, 9, dtype=th.int32, device=DEV)
+    IM, NM = th.ops.interpolate_ext.interpolation_matrix, th.ops.interpolate_ext.interpolation_normal_matrix
+    NV = th.ops.interpolate_ext.interpolation_normal_matrix_values
+    one = lambda t: t[:1].contiguous()  # noqa: E731
+    S = r"mipmap_aniso_grid_sampler_2d\(\): "
+    cases = [
+        (S + "expected input to have at least one mipmap level", lambda: m([], grid, jac)),
+        (S + "at most 11 mipmap levels", lambda: m([th.rand(N, C, 4, 4, device=DEV)] * 12, grid, jac)),
+        (S + "expected grid, vt_dxdy_img and input to have same batch size", lambda: m(tex(), one(grid), one(jac))),
+        (S + "expected grid, vt_dxdy_img and input to have same batch size", lambda: m(tex(), grid, one(jac))),
+        (S + "expected grid to have size 2 in last dimension", lambda: m(tex(), th.rand(N, H, W, 3, device=DEV), jac)),
+        (S + "expected vt_dxdy_img to have size 2 in last two dimension", lambda: m(tex(), grid, th.rand(N, H, W, 2, 3, device=DEV))),
+        (S + "expected 4D input and grid with same number of dimensions and 5D vt_dxdy_img", lambda: m(tex(), grid, jac[..., 0])),
+        (S + "expected 4D input and grid with same number of dimensions and 5D vt_dxdy_img", lambda: m(tex(), grid[..., 0], jac)),
+        (S + "expected input and grid to have same dtype", lambda: m(tex(dt=th.float64), grid, jac)),
+        (S + "expected all inputs to have same device, dtype, layout", lambda: m([tex()[0], th.rand(1, C, 8, 8, device=DEV)], grid, jac)),
+        (S + "expected all inputs to have same device, dtype, layout", lambda: m([tex()[0], th.rand(N, C + 1, 8, 8, device=DEV)], grid, jac)),
+        (S + "expected all inputs to have same device, dtype, layout", lambda: m([tex()[0], th.rand(N, C, 8, 8, device=DEV, dtype=th.float64)], grid, jac)),
+        (r"grid_sampler\(\): expected input to have non-empty spatial dimensions", lambda: m([th.rand(N, C, 0, 16, device=DEV)], grid, jac)),
+        (S + "expected vt_dxdy_img to match grid in device, dtype and spatial size", lambda: m(tex(), grid, jac[:, : H - 2].contiguous())),
+        (S + "expected vt_dxdy_img to match grid in device, dtype and spatial size", lambda: m(tex(), grid[:, : H - 2].contiguous(), jac)),
+        (r"interpolation_matrix\(\): expected vi, index_img and bary_img shapes to agree", lambda: IM(vi, one(index), bary)),
+        (r"interpolation_matrix\(\): expected vi, index_img and bary_img shapes to agree", lambda: IM(vi, index[:, : H - 1].contiguous(), bary)),
+        (r"interpolation_matrix\(\): expected vi, index_img and bary_img shapes to agree", lambda: IM(vi, index, th.rand(N, 4, H, W, device=DEV))),
+        (r"interpolation_matrix\(\): expected vi, index_img and bary_img shapes to agree", lambda: IM(th.zeros(N, F, 4, dtype=th.int32, device=DEV), index, bary)),
+        (r"interpolation_matrix\(\): expected vi, index_img and bary_img shapes to agree", lambda: IM(one(vi), index, bary)),
+        (r"interpolation_matrix\(\): expected bary_img to have floating point type", lambda: IM(vi, index, bary.int())),
+        (r"interpolation_normal_matrix\(\): expected vi, index_img and bary_img shapes to agree", lambda: NM(vi, index[:, :, : W - 1].contiguous(), bary, V)),
+        (r"interpolation_normal_matrix\(\): vi contains a vertex index outside", lambda: NM(vi, index, bary, 3)),
+        (r"interpolation_normal_matrix_values\(\): expected pair_indices \[N,F,9\]", lambda: NV(pair[..., :8].contiguous(), index, bary, 10)),
+        (r"interpolation_normal_matrix_values\(\): expected pair_indices, index_img and bary_img shapes to agree", lambda: NV(one(pair), index, bary, 10)),
+        (r"interpolation_normal_matrix_values\(\): expected pair_indices to have int32 type", lambda: NV(pair.long(), index, bary, 10)),
+        (r"interpolation_normal_matrix_values\(\): expected pair_indices, index_img and bary_img shapes to agree", lambda: NV(pair, index[:, : H - 1].contiguous(), bary, 10)),
+        (r"interpolation_normal_matrix_values\(\): expected nnz to be non-negative", lambda: NV(pair, index, bary, -1)),
+    ]
+    for pattern, fn in cases:
+        with pytest.raises(RuntimeError, match=pattern):
+            fn()
+    assert tuple(m(tex(), grid, jac).shape) == (N, C, H, W)
