@@ -1175,3 +1175,89 @@ def test_inconsistent_shapes_and_dtypes_are_rejected_like_the_reference():
             fn()
     # and the consistent call works
     assert tuple(I(attr, vi, index, bary).shape) == (N, C, H, W)
+
+
+def test_partial_use_of_outputs_and_inputs_through_autograd():
+    """What real losses do: use only depth_img or only bary_img of render (the engine passes an UNDEFINED gradient
+    for the other output), ask gradients for attributes but not geometry or the reverse, hand a strided upstream
+    gradient, call backward twice, detach the image or the barycentrics before edge_grad_estimator, register a
+    v_pix_img hook (unfused route).  Values, not just which gradients flow."""
+    import drtk_amd
+    from drtk_amd import synthetic as S
+
+    H, W, C, N = 64, 96, 5, 2
+    v0, vi = S.sphere_views(N, 12, 16, H, W, second_sphere=True, device=DEV)
+    attr0 = th.rand(N, v0.shape[1], C, device=DEV)
+    g = th.Generator(device=DEV).manual_seed(0)
+    wd = th.rand(N, H, W, device=DEV, generator=g)
+    wb = th.rand(N, 3, H, W, device=DEV, generator=g)
+    wi = th.rand(N, C, H, W, device=DEV, generator=g)
+
+    def rel(a, b, what, tol=5e-6):
+        err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        assert err <= tol, f"{what}: relative error {err:.2e}"
+
+    def render_grad(use_depth, use_bary):
+        v = v0.clone().requires_grad_(True)
+        index = drtk_amd.rasterize(v, vi, H, W)
+        depth, bary = drtk_amd.render(v, vi, index)
+        terms = ([(depth * wd).sum()] if use_depth else []) + ([(bary * wb).sum()] if use_bary else [])
+        loss = sum(terms[1:], terms[0])  # an output that is not used gets an undefined gradient in backward
+        loss.backward()
+        return v.grad
+
+    both = render_grad(True, True)
+    rel(render_grad(True, False) + render_grad(False, True), both, "render: depth-only + bary-only vs both")
+
+    def interp(attr_req, v_req, noncontig=False, twice=False):
+        v = v0.clone().requires_grad_(v_req)
+        attr = attr0.clone().requires_grad_(attr_req)
+        index = drtk_amd.rasterize(v, vi, H, W)
+        _, bary = drtk_amd.render(v, vi, index)
+        img = drtk_amd.interpolate(attr, vi, index, bary)
+        assert img.requires_grad == (attr_req or v_req)
+        if not img.requires_grad:
+            return None, None
+        up = wi.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) if noncontig else wi
+        assert up.is_contiguous() != noncontig
+        img.backward(up, retain_graph=twice)
+        if twice:
+            img.backward(up)
+        return attr.grad, v.grad
+
+    a_full, v_full = interp(True, True)
+    assert interp(False, False) == (None, None)
+    a_only, none = interp(True, False)
+    assert none is None
+    rel(a_only, a_full, "interpolate: attributes only")
+    none, v_only = interp(False, True)
+    assert none is None
+    rel(v_only, v_full, "interpolate: geometry only")
+    a_nc, v_nc = interp(True, True, noncontig=True)
+    rel(a_nc, a_full, "strided upstream gradient (attributes)")
+    rel(v_nc, v_full, "strided upstream gradient (geometry)")
+    a2, v2 = interp(True, True, twice=True)
+    rel(a2, 2 * a_full, "backward twice (attributes)")
+    rel(v2, 2 * v_full, "backward twice (geometry)")
+
+    def edge(mode, hook=None):
+        v = v0.clone().requires_grad_(True)
+        attr = attr0.clone().requires_grad_(mode == "full")
+        index = drtk_amd.rasterize(v, vi, H, W)
+        _, bary = drtk_amd.render(v, vi, index)
+        img = drtk_amd.interpolate(attr, vi, index, bary) * (index != -1)[:, None]
+        if mode == "detached_img":
+            img = img.detach()
+        out = drtk_amd.edge_grad_estimator(v_pix=v, vi=vi, bary_img=bary.detach() if mode == "detached_bary" else bary, img=img,
+                                           index_img=index, v_pix_img_hook=hook)
+        (out * wi).sum().backward()
+        return v.grad
+
+    e_full = edge("full")
+    rel(edge("v_only"), e_full, "edge_grad_estimator: attributes without grad")
+    e_det = edge("detached_img")  # only the edge term reaches v
+    assert bool(th.isfinite(e_det).all()) and float(e_det.abs().max()) > 0
+    assert bool(th.isfinite(edge("detached_bary")).all())
+    seen = []
+    rel(edge("v_only", hook=lambda gr: seen.append(tuple(gr.shape))), e_full, "edge_grad_estimator: hook (unfused) route vs fused route")
+    assert seen == [(N, 3, H, W)]
