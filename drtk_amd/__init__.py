@@ -16,3 +16,21 @@ from drtk_amd.screen_space_uv_derivative import screen_space_uv_derivative  # no
 from drtk_amd.transform import transform, transform_with_v_cam  # noqa: F401
 
 __version__ = "0.1.0"
+
+# The public surface.  Same names, arguments and defaults as `drtk.*` for everything on the hot path and its "next"
+# rows; `interpolate_masked` is this package's one addition (interpolate with the background written as 0).  Not
+# provided: grid_scatter, msi, filter2d and the pure-PyTorch `*_ref` models (out of scope).
+__all__ = [
+    "rasterize",
+    "rasterize_with_depth",
+    "render",
+    "interpolate",
+    "interpolate_masked",
+    "edge_grad_estimator",
+    "interpolation_matrix",
+    "interpolation_normal_matrix",
+    "mipmap_grid_sample",
+    "screen_space_uv_derivative",
+    "transform",
+    "transform_with_v_cam",
+]
