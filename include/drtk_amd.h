@@ -29,6 +29,9 @@
  *   - return value: DRTK_OK or a negative drtk_status_t; drtk_amd_status_string() explains it.
  *     Argument validation mirrors the reference's TORCH_CHECKs where it can be expressed on raw
  *     sizes; tensor-level checks (dtype, device, ndim) live in the torch shim.
+ *   - reproducibility: forward outputs and per-pixel gradients are bit-identical from run to run; per-VERTEX
+ *     gradients (grad_v, attr_grad, grad_v_pix) are accumulated with float atomics in varying order and agree to
+ *     ~1e-7 of their largest value between runs, like the reference's atomicAdd scatter.
  *   - thread-safety: re-entrant; no global mutable state.
  */
 #ifndef DRTK_AMD_H
