@@ -536,8 +536,14 @@ constexpr int kTileW = 16;  // pixel tile
 constexpr int kWin = 32;    // texel window side
 constexpr int kWinLevels = 3;
 // `dbg` (diagnostics, profiles/kernel_bench.py --flags): 1 = no texture-gradient accumulation, 2 = no texel reads,
-// 4 = no flush.  Ablation at the bench shape: 6.0 ms total, 2.2 without the accumulation, 1.7 without all three --
-// the LDS float atomics (4 per tap, level and channel, neighbouring pixels on the same cells) are the bound.
+// 4 = no flush.  Where the 6.0 ms of the bench shape go (finer timing-only variants, r01): the global-atomic fallback for
+// corners outside the windows ~1.5 ms, the four LDS adds ~0.8 ms, the flush 0.5 ms, texel reads 0.2 ms, everything else
+// (tap set-up, window bookkeeping, barriers) the rest.  Flag 1 alone overstates the atomics: it also drops the fallback
+// and lets the compiler delete the bookkeeping (2.2 ms remain).  On that scene 91.5 % of the (tap, level) pairs hit the
+// windows, 7.0 % miss by POSITION (anisotropic taps: a 16-pixel tile spans up to 16 * N * 2 texels along the major
+// axis), 1.5 % by level; 16 % of the tiles have a miss and the worst 1 % hold a third of them (atlas seam, silhouette).
+// Measured dead end: the same LDS split 2048 / 768 / 256 cells over the levels with every window shaped like its tile's
+// bounding box -- 1-4 % (6.06 -> 6.02 ms at 1 texel/px, 11.5 -> 11.0 at 4), one outlier pixel stretches the box.
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
