@@ -125,6 +125,39 @@ def test_cpu_tensors_fail_loudly_no_fallback():
         drtk_amd.interpolate(v, vi, th.zeros(1, 4, 4, dtype=th.int32), th.zeros(1, 3, 4, 4))
 
 
+def test_missing_native_libraries_fail_loudly(tmp_path):
+    """No binaries -> ImportError that says what to do, at `import drtk_amd` and from the ctypes binding.  Never a
+    silent eager / CPU substitute.  Run in a subprocess on a copy of the package's Python files WITHOUT its .so files,
+    so neither the real binaries nor this process's already-loaded operators are involved."""
+    import shutil
+    import subprocess
+    import sys
+
+    src = os.path.join(ROOT, "drtk_amd")
+    dst = tmp_path / "drtk_amd"
+    for dirpath, dirnames, files in os.walk(src):
+        dirnames[:] = [d for d in dirnames if d not in ("__pycache__", "csrc")]
+        rel = os.path.relpath(dirpath, src)
+        (dst / rel).mkdir(parents=True, exist_ok=True)
+        for f in files:
+            if f.endswith(".py"):
+                shutil.copy(os.path.join(dirpath, f), dst / rel / f)
+    assert not list(dst.rglob("*.so"))
+
+    def run(code):
+        return subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {str(tmp_path)!r}); " + code],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=str(tmp_path))
+
+    r = run("import drtk_amd")
+    assert r.returncode != 0 and "ImportError" in r.stderr, r.stderr[-2000:]
+    assert "native libraries are not built" in r.stderr and "python -m drtk_amd.build" in r.stderr
+    assert "libdrtk_amd.so" in r.stderr and "drtk_amd_torch_ops.so" in r.stderr  # names what is missing
+    # ... and no submodule can be reached around that check (a submodule import runs the package's __init__ first)
+    for mod in ("drtk_amd.capi", "drtk_amd.rasterize", "drtk_amd.render", "drtk_amd.mipmap_grid_sample"):
+        r = run(f"import {mod}")
+        assert r.returncode != 0 and "native libraries are not built" in r.stderr, (mod, r.stderr[-1500:])
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "drtk_amd")
     for dirpath, _, files in os.walk(pkg):
