@@ -185,6 +185,42 @@ def test_library_fills_with_a_kernel_not_with_hipMemset():
     assert not bad, "\n".join(bad)
 
 
+def test_only_the_cpu_baseline_leg_and_the_smoke_check_use_the_oracle():
+    """Outside tests/ and oracle/ itself: bench.py may reach into oracle/ only inside cpu_baseline() (the reported
+    baseline, never the thing measured), __graft_entry__.py only to build the checker and in smoke(); the profiling
+    scripts not at all."""
+    import ast
+
+    pat = re.compile(r"import\s+oracle|from\s+oracle|[\"']oracle[\"']|drtk_oracle|ref_build|_ref/")
+
+    def offending(path, allowed_functions):
+        src = open(path).read()
+        tree = ast.parse(src)
+        spans = [(n.lineno, n.end_lineno) for n in ast.walk(tree)
+                 if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef)) and n.name in allowed_functions]
+        doc_lines = set()
+        for n in ast.walk(tree):  # prose in docstrings / help strings is not a use
+            if isinstance(n, ast.Constant) and isinstance(n.value, str) and ("\n" in n.value or " " in n.value):
+                doc_lines.update(range(n.lineno, n.end_lineno + 1))
+        bad = []
+        for no, line in enumerate(src.splitlines(), 1):
+            if pat.search(line.split("#")[0]) and no not in doc_lines and not any(a <= no <= b for a, b in spans):
+                bad.append(f"{os.path.basename(path)}:{no}: {line.strip()}")
+        return bad
+
+    assert offending(os.path.join(ROOT, "bench.py"), {"cpu_baseline", "_cpu_backend"}) == []  # the leg and its loader
+    bench_src = open(os.path.join(ROOT, "bench.py")).read()
+    assert len(re.findall(r"_cpu_backend\(", bench_src)) == 2  # its definition + the one call in cpu_baseline()
+    assert len(re.findall(r"cpu_baseline\(", bench_src)) == 2   # its definition + the one call, rank 0 at N = 1
+    assert offending(os.path.join(ROOT, "__graft_entry__.py"), {"build", "smoke"}) == []
+    for dirpath, dirnames, files in os.walk(os.path.join(ROOT, "profiles")):
+        dirnames[:] = [d for d in dirnames if d != "__pycache__"]
+        for f in files:
+            if f.endswith((".py", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), f"profiles/{f} reaches into the oracle"
+
+
 def test_synthetic_mesh_sizes():
     from drtk_amd import synthetic as S
 
