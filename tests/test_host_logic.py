@@ -221,6 +221,48 @@ def test_only_the_cpu_baseline_leg_and_the_smoke_check_use_the_oracle():
                 assert not pat.search(src), f"profiles/{f} reaches into the oracle"
 
 
+def test_committed_profile_artefacts_describe_one_collection():
+    """profiles/rNN/: the bench line, the PMC traffic summary and the rocprofv3 kernel summary of a round come from
+    ONE run of profiles/scripts/collect_round.sh (counter passes first, then the bench that reads them).  So the bench
+    line's `roofline.traffic` is the sum of that traffic.json over the kernels the line names, those kernels appear in
+    the rocprofv3 summary, and their profiler averages add up to the HIP-event `ms_per_launch` (the profiler adds a
+    little per launch: within 5 %)."""
+    import glob
+    import json
+
+    rounds = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*")))
+    checked = 0
+    for rdir in rounds:
+        if not os.path.exists(os.path.join(rdir, "bench_n1.json")):
+            continue  # a round directory opened before its first collection; once the bench line is there, all three are
+        checked += 1
+        bench = json.loads(open(os.path.join(rdir, "bench_n1.json")).read().strip().splitlines()[-1])
+        roof = bench["roofline"]
+        names = roof["hip_kernels"]
+        assert names, "the bench line must name the HIP kernels of the dominant op"
+
+        kernels = json.load(open(os.path.join(rdir, "traffic.json")))["kernels"]
+        total = sum(rec["hbm_bytes"] for name, rec in kernels.items() if any(pat in name for pat in names))
+        assert int(total) == roof["traffic"], f"{rdir}: bench_n1.json and traffic.json are from different collections"
+        # traffic at or below the algorithmic bytes: nothing is re-read (some lines stay in L2 / MALL)
+        assert 0.5 * roof["algorithmic_bytes"] < roof["traffic"] < 1.25 * roof["algorithmic_bytes"]
+
+        avg_us = {}
+        for line in open(os.path.join(rdir, "bench_step_kernel_stats.txt")):
+            parts = line.split(None, 4)
+            if len(parts) == 5 and parts[0].isdigit():
+                for pat in names:
+                    if pat in parts[4]:
+                        avg_us[pat] = avg_us.get(pat, 0.0) + float(parts[2])
+        assert sorted(avg_us) == sorted(names), f"{rdir}: rocprofv3 summary lacks {set(names) - set(avg_us)}"
+        profiler_ms = sum(avg_us.values()) / 1e3
+        assert abs(profiler_ms - roof["ms_per_launch"]) <= 0.05 * roof["ms_per_launch"], (profiler_ms, roof["ms_per_launch"])
+
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+        assert abs(roof["achieved"] - roof["algorithmic_bytes"] / (roof["ms_per_launch"] * 1e-3) / 1e9) < 1.0
+    assert checked >= 1, "no profiles/rNN directory holds a collection"
+
+
 def test_synthetic_mesh_sizes():
     from drtk_amd import synthetic as S
 
