@@ -5,7 +5,10 @@
   drtk_amd/drtk_amd_torch_ops.so torch-op shim (rasterize_ext / render_ext / interpolate_ext /
                                  edge_grad_ext schemas + autograd), g++ against libtorch, links the above
 
-`python -m drtk_amd.build` builds both; __graft_entry__.build() calls build_all().
+`python drtk_amd/build.py` builds both (`--force` rebuilds, `--dry-run` only reports what is missing or stale);
+__graft_entry__.build() calls build_all().  Run the FILE, not `python -m drtk_amd.build`: `-m` imports the package
+first, and the package refuses to import before these libraries exist (no fallback path) -- which is why this
+module imports nothing from it.
 """
 import os
 import subprocess
@@ -91,5 +94,23 @@ def build_all(force=False, verbose=True):
     return LIB, OPS
 
 
+def _state(target, deps):
+    if not os.path.isfile(target):
+        return "missing"
+    present = [d for d in deps if os.path.isfile(d)]
+    return "up to date" if len(present) == len(deps) and _newer(target, deps) else "stale"
+
+
+def dry_run():
+    """What build_all() would do, without compiling anything."""
+    kdeps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
+    odeps = [os.path.join(CSRC, "torch_ops.cpp"), os.path.join(INC, "drtk_amd.h"), LIB, __file__]
+    for target, deps in ((LIB, kdeps), (OPS, odeps)):
+        print(f"[drtk_amd] {target}: {_state(target, deps)}")
+
+
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--dry-run" in sys.argv:
+        dry_run()
+    else:
+        build_all(force="--force" in sys.argv)

@@ -23,7 +23,7 @@ def lib() -> ctypes.CDLL:
     if _lib is None:
         path = native_library_paths()[0]
         if not os.path.isfile(path):
-            raise ImportError(f"{path} is missing: run `python -m drtk_amd.build`")
+            raise ImportError(f"{path} is missing: run `python {os.path.join(os.path.dirname(path), 'build.py')}`")
         L = ctypes.CDLL(path)
         L.drtk_amd_status_string.restype = ctypes.c_char_p
         L.drtk_amd_status_string.argtypes = [ctypes.c_int]

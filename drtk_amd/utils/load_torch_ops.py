@@ -51,7 +51,8 @@ def load_torch_ops(extension: str = "drtk.rasterize_ext") -> None:
             raise ImportError(
                 "drtk_amd native libraries are not built: missing "
                 + ", ".join(missing)
-                + ". Run `python -m drtk_amd.build` (needs hipcc for gfx950)."
+                + f". Run `python {os.path.join(_PKG, 'build.py')}` (needs hipcc for gfx950; run the file -- "
+                "`python -m drtk_amd.build` would import this package first and end up here again)."
             )
         th.ops.load_library(_OPS)
         _loaded = True

@@ -128,7 +128,12 @@ def test_cpu_tensors_fail_loudly_no_fallback():
 def test_missing_native_libraries_fail_loudly(tmp_path):
     """No binaries -> ImportError that says what to do, at `import drtk_amd` and from the ctypes binding.  Never a
     silent eager / CPU substitute.  Run in a subprocess on a copy of the package's Python files WITHOUT its .so files,
-    so neither the real binaries nor this process's already-loaded operators are involved."""
+    so neither the real binaries nor this process's already-loaded operators are involved.
+
+    The advice in that error has to be runnable in exactly that state: the command it names is executed here (with
+    --dry-run, nothing is compiled).  It is the build FILE; `python -m drtk_amd.build` cannot bootstrap, because -m
+    imports the package first -- build.py therefore imports nothing from the package."""
+    import ast
     import shutil
     import subprocess
     import sys
@@ -150,12 +155,43 @@ def test_missing_native_libraries_fail_loudly(tmp_path):
 
     r = run("import drtk_amd")
     assert r.returncode != 0 and "ImportError" in r.stderr, r.stderr[-2000:]
-    assert "native libraries are not built" in r.stderr and "python -m drtk_amd.build" in r.stderr
+    assert "native libraries are not built" in r.stderr
     assert "libdrtk_amd.so" in r.stderr and "drtk_amd_torch_ops.so" in r.stderr  # names what is missing
     # ... and no submodule can be reached around that check (a submodule import runs the package's __init__ first)
-    for mod in ("drtk_amd.capi", "drtk_amd.rasterize", "drtk_amd.render", "drtk_amd.mipmap_grid_sample"):
-        r = run(f"import {mod}")
-        assert r.returncode != 0 and "native libraries are not built" in r.stderr, (mod, r.stderr[-1500:])
+    for mod in ("drtk_amd.capi", "drtk_amd.rasterize", "drtk_amd.render", "drtk_amd.mipmap_grid_sample", "drtk_amd.build"):
+        r2 = run(f"import {mod}")
+        assert r2.returncode != 0 and "native libraries are not built" in r2.stderr, (mod, r2.stderr[-1500:])
+
+    # the command the error names: extract it, check it is the build file of THIS copy, and run it
+    m = re.search(r"Run `python ([^`]+)`", r.stderr)
+    assert m, r.stderr[-1500:]
+    build_py = m.group(1)
+    assert os.path.samefile(build_py, dst / "build.py"), build_py
+    d = subprocess.run([sys.executable, build_py, "--dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=300, cwd="/")  # from an unrelated directory
+    assert d.returncode == 0, d.stderr[-2000:]
+    lines = [ln for ln in d.stdout.splitlines() if ln.startswith("[drtk_amd]")]
+    assert len(lines) == 2 and all(ln.endswith(": missing") for ln in lines), d.stdout
+    assert "libdrtk_amd.so" in lines[0] and "drtk_amd_torch_ops.so" in lines[1]
+    # `-m` is NOT that command: it ends in the same ImportError (known, and the reason the docs name the file)
+    mrun = subprocess.run([sys.executable, "-m", "drtk_amd.build", "--dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=300, cwd=str(tmp_path))
+    assert mrun.returncode != 0 and "native libraries are not built" in mrun.stderr
+    for doc in ("README.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        assert "python drtk_amd/build.py" in text and "python -m drtk_amd.build" not in text, doc
+
+    # build.py stands alone: standard library at module level, torch only inside the function that needs its paths
+    tree = ast.parse(open(os.path.join(src, "build.py")).read())
+    for node in ast.walk(tree):
+        names = [a.name for a in node.names] if isinstance(node, ast.Import) else (
+            [node.module or ""] if isinstance(node, ast.ImportFrom) else [])
+        assert not any(n.split(".")[0] == "drtk_amd" for n in names), "drtk_amd/build.py must not import the package"
+        assert not (isinstance(node, ast.ImportFrom) and node.level > 0), "no relative imports in drtk_amd/build.py"
+
+    # and the ctypes binding's own check gives the same advice
+    capi_src = open(os.path.join(src, "capi.py")).read()
+    assert "build.py" in capi_src and "-m drtk_amd.build" not in capi_src
 
 
 def test_product_never_touches_the_oracle():
