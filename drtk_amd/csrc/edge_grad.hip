@@ -227,11 +227,16 @@ __device__ __forceinline__ bool pix_in_tri(const TriInfo<T>& t, int x, int y) {
   return false;
 }
 
+// Correctly rounded square roots, as the reference's host path gets from libm.  NOT `__fsqrt_rn`: without
+// OCML_BASIC_ROUNDED_OPERATIONS the toolchain defines it as __ocml_native_sqrt_f32 (the bare 1-ulp v_sqrt_f32,
+// __clang_hip_math.h), and one ulp in a normal's length is enough to flip the sign that get_dp_dr takes from a
+// near-zero `d` -- a difference of 2 * max_dp_dr in the output of that pixel.  The builtin is lowered with the
+// compiler's correction steps (HIP's default -fhip-fp32-correctly-rounded-divide-sqrt).
 __device__ __forceinline__ float sqrt_t(float x) {
-  return __fsqrt_rn(x);
+  return __builtin_sqrtf(x);
 }
 __device__ __forceinline__ double sqrt_t(double x) {
-  return __dsqrt_rn(x);
+  return __builtin_sqrt(x);
 }
 
 // edge_grad_kernel.cu:89-100 ; normalize = v * (1 / sqrt(dot)) as on the reference's host path

@@ -35,11 +35,13 @@ struct LevelTable {
   int w[kMaxLevels];
 };
 
+// Correctly rounded (the footprint lengths feed a floor() that picks the mip level).  Not `__fsqrt_rn`, which this
+// toolchain defines as the native 1-ulp square root -- see edge_grad.hip: sqrt_t.
 __device__ __forceinline__ float sqrt_rn(float x) {
-  return __fsqrt_rn(x);
+  return __builtin_sqrtf(x);
 }
 __device__ __forceinline__ double sqrt_rn(double x) {
-  return __dsqrt_rn(x);
+  return __builtin_sqrt(x);
 }
 
 // GridSampler.cuh primitives -------------------------------------------------------------------

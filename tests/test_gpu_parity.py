@@ -604,6 +604,26 @@ def test_randomised_shapes(block):
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
 
 
+def test_edge_grad_sign_decisions_at_near_parallel_normals_follow_the_reference():
+    """Where a pixel pair straddles two DIFFERENT surfaces whose projected normals are almost parallel, the
+    reference's get_dp_dr (edge_grad_kernel_cpu.cpp:113-137) clamps |d| to |b_x| / max_dp_dr and takes the SIGN from
+    a `d` that is zero up to rounding: the output of that pixel is +-max_dp_dr * (...), so the last bit of the
+    normals decides between two answers 2 * max_dp_dr apart (the reference's own --fast-math build disagrees with its
+    strict build on these pixels; tests/diag_edge_three_way.py prints the comparison).  The kernel therefore has to
+    round every step of that chain like the reference's host code -- in particular a CORRECTLY ROUNDED square root,
+    which `__fsqrt_rn` is not on this toolchain.  These fuzz seeds (two intersecting spheres, f32, max_dp_dr = 1e4)
+    were off by 8e2 - 2e4 at 2 - 14 pixels each with the native square root; 1 case in 600 draws such a pixel."""
+    import fuzz_all_ops as F
+
+    for seed in (10000, 10151, 10586, 11009, 12587):
+        c = F.make_case(seed)
+        assert c["kind"] == 2 and c["dtype"] == th.float32  # the generator still draws the case this test is about
+        try:
+            F.run_case(c)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
+
+
 def test_non_contiguous_inputs_and_concurrent_streams():
     """Boundary conventions of the reference: arbitrary input strides are accepted (the ops make
     their own contiguous copies where they need them), and the ops are re-entrant -- two Python threads on two

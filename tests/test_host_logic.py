@@ -221,6 +221,33 @@ def test_library_fills_with_a_kernel_not_with_hipMemset():
     assert not bad, "\n".join(bad)
 
 
+def test_kernels_use_correctly_rounded_roots_and_quotients():
+    """Discrete decisions of the reference hang on the last bit of normalised vectors (edge_grad's get_dp_dr sign,
+    the mip level's floor), so square roots and divisions that feed them are the IEEE ones.  `__fsqrt_rn` LOOKS like
+    one, but without OCML_BASIC_ROUNDED_OPERATIONS __clang_hip_math.h defines it as __ocml_native_sqrt_f32 (bare
+    v_sqrt_f32, 1 ulp); the native / approximate families are equally out.  `__builtin_amdgcn_rcpf` is allowed in
+    render.hip only, where the backward's quotients are documented as 1-2 ulp on purpose (no decision depends on
+    them), and in rasterize.hip as the SEED of exact_rcp: one Markstein correction makes it the correctly rounded
+    reciprocal, which drtk_amd_selftest_exact_div checks exhaustively over all 2^23 significands on the device (GPU
+    suite).  Behaviour pinned on the GPU by test_edge_grad_sign_decisions_at_near_parallel_normals_follow_the_reference."""
+    banned = re.compile(r"__fsqrt_r[nduz]|__frsqrt_rn|__ocml_native_|__builtin_amdgcn_(sqrt|rsq|rcp)|\b(rsqrtf?|__f(div|sqrt)def|"
+                        r"__fdividef|__expf|__logf|__log2f|__powf|__sinf|__cosf)\b")
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "drtk_amd", "csrc")):
+        for f in files:
+            if not f.endswith((".hip", ".hpp", ".cpp", ".h")):
+                continue
+            for no, line in enumerate(open(os.path.join(dirpath, f), errors="ignore"), 1):
+                code = line.split("//")[0]
+                m = banned.search(code)
+                if m and not (f in ("render.hip", "rasterize.hip") and m.group(0).startswith("__builtin_amdgcn_rcp")):
+                    bad.append(f"{f}:{no}: {line.strip()}")
+    assert not bad, "\n".join(bad)
+    build_py = open(os.path.join(ROOT, "drtk_amd", "build.py")).read()
+    assert "-fno-fast-math" in build_py and "-ffp-contract=off" in build_py
+    assert "-fno-hip-fp32-correctly-rounded-divide-sqrt" not in build_py and "-ffast-math" not in build_py
+
+
 def test_only_the_cpu_baseline_leg_and_the_smoke_check_use_the_oracle():
     """Outside tests/ and oracle/ itself: bench.py may reach into oracle/ only inside cpu_baseline() (the reported
     baseline, never the thing measured), __graft_entry__.py only to build the checker and in smoke(); the profiling
