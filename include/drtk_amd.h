@@ -220,6 +220,11 @@ int drtk_amd_mipmap_grid_sampler_2d_backward(
  *   v [N,V,3] world-space (v_sN = 3V, or 0 for one shared [V,3]);  vt [N,T,2] (vt_sN = 2T or 0)
  *   vi, vti [F,3] int32;  index_img [N,H,W];  bary_img [N,3,H,W];  mask [N,H,W] uint8 or NULL
  *   campos [N,3], camrot [N,3,3], focal [N,2,2].   Pixels with index -1 or mask 0 are written 0.
+ * A face with ZERO UV AREA: the reference inverts every face's UV edge matrix up front (face_dpdt,
+ * drtk/utils/geometry.py:71-82, th.inverse) and raises for the whole call, visible face or not.  This kernel works
+ * per pixel: pixels of such a face get the non-finite quotients of that zero determinant, every other pixel is
+ * unaffected.  In float32 the two 2x2 inverses are ill-conditioned for triangles seen edge-on; accuracy there is
+ * that of the reference's float32 composite, not 1e-5.
  * Forward only (the reference composite is differentiable through autograd; its consumer,
  * mipmap_grid_sampler_2d, defines no gradient for this input).
  */

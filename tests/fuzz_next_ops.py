@@ -105,8 +105,15 @@ def run_case(c):
         return  # the op takes one topology for all views, like the reference
     mask = (index != -1) & c["mask_keep"]
     campos, camrot, focal = c["cams"][0], c["cams"][1], c["cams"][2]
-    want = O.screen_space_uv_derivative(c["vN"], c["vt"], vi, vi, index, bary, mask, campos, camrot, focal)
     got = capi.screen_space_uv_derivative(d(c["vN"]), d(c["vt"]), dvi, dvi, dindex, dbary, d(mask), d(campos), d(camrot), d(focal))
+    try:
+        want = O.screen_space_uv_derivative(c["vN"], c["vt"], vi, vi, index, bary, mask, campos, camrot, focal)
+    except th.linalg.LinAlgError:
+        # A face with zero UV area: the reference's face_dpdt (drtk/utils/geometry.py:71-82) inverts every face's UV
+        # edge matrix with th.inverse, which RAISES for the whole call -- there is no reference output for this mesh.
+        # The kernel is per pixel (include/drtk_amd.h): it must still run, and write 0 wherever index is -1 / mask is 0.
+        assert bool((got.cpu()[~mask] == 0).all()), "screen_space_uv_derivative: background / masked pixels must be 0"
+        return "reference undefined: a face with zero UV area makes the reference composite raise"
     if f64:
         _close(got, want, "screen_space_uv_derivative", atol=1e-11, rtol=1e-10)  # pins the formula
         return
@@ -143,13 +150,16 @@ if __name__ == "__main__":
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
     a = ap.parse_args()
-    bad = 0
+    bad, undefined = 0, 0
     for seed in range(a.first, a.first + a.cases):
         c = make_case(seed)
         try:
-            run_case(c)
+            note = run_case(c)
+            if note:
+                undefined += 1
+                print(f"NOTE seed {seed}: {describe(c)}: {note}", flush=True)
         except Exception as e:
             bad += 1
             print(f"FAIL seed {seed}: {describe(c)}: {type(e).__name__}: {str(e)[:160]}", flush=True)
-    print(f"{a.cases - bad}/{a.cases} cases passed")
+    print(f"{a.cases - bad}/{a.cases} cases passed" + (f" ({undefined} of them only up to screen_space_uv_derivative: reference undefined)" if undefined else ""))
     sys.exit(1 if bad else 0)
