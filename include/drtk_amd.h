@@ -39,8 +39,8 @@
  *     that pixel is +-max_dp_dr * ...) -- its own builds differ from one another at that pixel: the shipped host
  *     build is -O3 --fast-math (setup.py:23-24), the CUDA build normalises with ::rnorm3df where the host divides by
  *     sqrt (cuda_math_helper.h:173-176).  Expect differences of 2 * max_dp_dr at a few such silhouette pixels when
- *     comparing against those (about one two-object scene in 600 has one); against the strict evaluation there are
- *     none.
+ *     comparing against those (about 1 in 150 of the small two-object float32 test scenes has one); against the
+ *     strict evaluation there are none.
  *   - thread-safety: re-entrant; no global mutable state.
  */
 #ifndef DRTK_AMD_H
