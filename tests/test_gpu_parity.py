@@ -604,6 +604,20 @@ def test_randomised_shapes(block):
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
 
 
+def test_rasterize_large_random_scenes_are_bit_exact():
+    """16 seeded cases from tests/fuzz_raster_large.py: the binning passes at sizes the small-scene fuzzers never reach
+    (up to 2048 x 1536 and 17 x 4096, 1e3 - 3e5 triangles per view, tiny / medium / screen-filling mix, clustered
+    per-tile lists, quantised depths with exact ties): index_img and depth_img equal the oracle's bit for bit."""
+    import fuzz_raster_large as R
+
+    for seed in range(16):
+        c = R.make_case(seed)
+        try:
+            R.run_case(c)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: {R.describe(c)}: {e}") from e
+
+
 def test_python_api_routes_agree_on_randomised_shapes():
     """48 seeded cases from tests/fuzz_python_api.py: through the `drtk_amd.*` functions and the torch-operator shim,
     forward outputs equal the C-ABI results bit for bit, and the gradients of the whole pipeline agree between the
