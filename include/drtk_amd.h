@@ -35,9 +35,10 @@
  *   - knife-edge decisions: float arithmetic follows the reference's HOST source in its written order under IEEE
  *     rules (no contraction, correctly rounded / and sqrt), i.e. what a strict build of its CPU kernels evaluates.
  *     Where the reference decides on a quantity that is zero up to rounding -- the sign get_dp_dr takes from `d`
- *     where two DIFFERENT surfaces with parallel faces meet in the image: instanced or translated copies, offset
- *     shells (edge_grad_kernel_cpu.cpp:113-137; d ~ 1e-9 in exact arithmetic, the output of that pixel is
- *     +-max_dp_dr * ...) -- its own builds differ from one another at that pixel: the shipped host
+ *     where two DIFFERENT surfaces meet in the image with face normals equal to ~1e-8 yet not bit-identical
+ *     (edge_grad_kernel_cpu.cpp:113-137; d ~ 1e-9 in exact arithmetic, the output of that pixel is +-max_dp_dr * ...;
+ *     exact instanced copies give d == 0 and generic offsets |d| ~ 1e-6: both signed stably) -- its own builds
+ *     differ from one another at that pixel: the shipped host
  *     build is -O3 --fast-math (setup.py:23-24), the CUDA build normalises with ::rnorm3df where the host divides by
  *     sqrt (cuda_math_helper.h:173-176).  Expect differences of 2 * max_dp_dr at a few such silhouette pixels when
  *     comparing against those (about 1 in 150 of the small two-object float32 test scenes has one); against the
