@@ -265,6 +265,46 @@ def test_randomised_mipmap_cases(block):
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
 
 
+def near_isotropic_case(seed=0, H=128, W=128, tex=64):
+    """Footprints within a few ulp of ISOTROPIC (what a surface seen face-on produces): du/dx = p/tex * (1 + k1 ulp),
+    dv/dy = p/tex * (1 + k2 ulp), k in -3..3.  The tap count ceil(p_max / p_min) jumps from 1 to 2 as that ratio
+    crosses 1 -- measured on the oracle, 0.2 in the output of a [0,1] texture for a 3e-7 change of one length."""
+    g = th.Generator().manual_seed(seed)
+    base = th.rand(1, 3, tex, tex, generator=g)
+    levels = [base]
+    while levels[-1].shape[-1] > 1:
+        levels.append(th.nn.functional.avg_pool2d(levels[-1], 2))
+    levels = [lv.contiguous() for lv in levels]
+    grid = th.rand(1, H, W, 2, generator=g) * 1.8 - 0.9
+    p = 0.5 + 7.5 * th.rand(1, H, W, generator=g)
+    ulp = 2.0 ** -23
+    k1 = th.randint(-3, 4, (1, H, W), generator=g).float()
+    k2 = th.randint(-3, 4, (1, H, W), generator=g).float()
+    jac = th.zeros(1, H, W, 2, 2)
+    jac[..., 0, 0] = (p / tex) * (1 + k1 * ulp)
+    jac[..., 1, 1] = (p / tex) * (1 + k2 * ulp)
+    return levels, grid, jac
+
+
+def test_tap_count_at_near_isotropic_footprints_follows_the_reference():
+    """The anisotropic tap count is a DISCONTINUOUS function of the two footprint lengths (sqrt of a sum of squares
+    each): with a square root that is only 1 ulp accurate (`__fsqrt_rn` = the native root on this toolchain) two
+    lengths that round to the same float can come out different, the ratio leaves 1 and the kernel takes 2 taps where
+    the reference takes 1.  sqrt, /, ceil are IEEE on both sides now; the level selection, by
+    contrast, is continuous across integer levels (floor + blend weight) and needs no such care."""
+    import oracle as O
+    from drtk_amd import capi
+
+    for seed in range(4):
+        levels, grid, jac = near_isotropic_case(seed)
+        for mode in (0, 2):  # bilinear, bicubic
+            want = O.mipmap_grid_sampler_2d(levels, grid, jac, 4, 0, mode)
+            got = capi.mipmap_grid_sampler_2d([t.to(DEV) for t in levels], grid.to(DEV), jac.to(DEV), 4, 0, mode).cpu()
+            err = (got - want).abs().amax(1)
+            nbad = int((err > 1e-5).sum())
+            assert nbad == 0, f"seed {seed} mode {mode}: {nbad} of {err.numel()} pixels differ, worst {float(err.max()):.3e} (a tap-count flip is ~1e-1)"
+
+
 def test_zero_sized_dimensions_of_the_texture_and_sparse_ops():
     """mipmap_grid_sample, transform, screen_space_uv_derivative and the sparse interpolation operators with each
     dimension in turn set to zero, forward and backward through the Python API: right shapes, finite values, no
