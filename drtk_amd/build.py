@@ -65,6 +65,31 @@ def build_kernels(force=False, verbose=True):
     return LIB
 
 
+ABLATE_LIB = os.path.join(ROOT, "profiles", "libdrtk_amd_ablate.so")
+
+
+def build_ablation(force=False, verbose=True):
+    """profiles/libdrtk_amd_ablate.so: the same sources with -DDRTK_AMD_ABLATION, i.e. WITH the phase switches
+    and `drtk_amd_debug_set_flags` (csrc/common.hpp).  A profiling tool's library (profiles/kernel_bench.py
+    --flags ...); it lives outside the package, the product never loads it and build_all() does not build it."""
+    deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
+    if not force and _newer(ABLATE_LIB, deps):
+        return ABLATE_LIB
+    objs, cmds = [], []
+    for s in KERNEL_SRCS:
+        o = os.path.join(CSRC, s + ".ablate.o")
+        objs.append(o)
+        cmds.append([HIPCC, *HIP_FLAGS, "-DDRTK_AMD_ABLATION", "-c", os.path.join(CSRC, s), "-o", o])
+    with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
+        list(ex.map(_run, cmds))
+    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", ABLATE_LIB, *objs])
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print(f"[drtk_amd] built {ABLATE_LIB}")
+    return ABLATE_LIB
+
+
 def build_torch_ops(force=False, verbose=True):
     import torch
     from torch.utils import cpp_extension as ce
@@ -112,5 +137,7 @@ def dry_run():
 if __name__ == "__main__":
     if "--dry-run" in sys.argv:
         dry_run()
+    elif "--ablation" in sys.argv:
+        build_ablation(force="--force" in sys.argv)
     else:
         build_all(force="--force" in sys.argv)

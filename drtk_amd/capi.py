@@ -18,10 +18,22 @@ _lib = None
 DRTK_F32, DRTK_F64 = 0, 1
 
 
+_lib_path = None
+
+
+def use_profiling_library(path: str) -> None:
+    """profiles/kernel_bench.py --flags only: bind this module to the ablation build of the same sources
+    (profiles/libdrtk_amd_ablate.so, `python drtk_amd/build.py --ablation`) instead of the product library.
+    Must be called before the first C-ABI call of the process."""
+    global _lib_path
+    assert _lib is None, "the C-ABI library is already loaded"
+    _lib_path = path
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        path = native_library_paths()[0]
+        path = _lib_path or native_library_paths()[0]
         if not os.path.isfile(path):
             raise ImportError(f"{path} is missing: run `python {os.path.join(os.path.dirname(path), 'build.py')}`")
         L = ctypes.CDLL(path)
@@ -29,7 +41,7 @@ def lib() -> ctypes.CDLL:
         L.drtk_amd_status_string.argtypes = [ctypes.c_int]
         L.drtk_amd_version.restype = ctypes.c_char_p
         for name in EXPORTS:
-            if name not in ("drtk_amd_status_string", "drtk_amd_version", "drtk_amd_debug_set_flags"):
+            if name not in ("drtk_amd_status_string", "drtk_amd_version"):
                 getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib
@@ -60,7 +72,6 @@ EXPORTS = [
     "drtk_amd_transform_pinhole",
     "drtk_amd_transform_pinhole_backward",
     "drtk_amd_selftest_exact_div",
-    "drtk_amd_debug_set_flags",
 ]
 
 

@@ -71,12 +71,17 @@ int fill_bytes_async(void* p, int value, size_t bytes, hipStream_t stream) {
   return DRTK_OK;
 }
 
+#ifdef DRTK_AMD_ABLATION
 static int g_debug_flags = 0;
 int debug_flags() {
   return g_debug_flags;
 }
+#endif
 } // namespace drtk_amd
 
+#ifdef DRTK_AMD_ABLATION
+// profiling build only (profiles/libdrtk_amd_ablate.so); not declared in include/drtk_amd.h, not in libdrtk_amd.so
 extern "C" void drtk_amd_debug_set_flags(int flags) {
   drtk_amd::g_debug_flags = flags;
 }
+#endif

@@ -98,9 +98,17 @@ __device__ __forceinline__ int tile_index(int strip) {
   return strip <= 1 ? b : xcd_tile(b, static_cast<int>(gridDim.x), strip);
 }
 
-// Diagnostics only (profiles/*.py): bit mask that lets single phases of a kernel be switched off to
-// attribute time.  0 in normal operation.
+// Ablation switches (profiles/kernel_bench.py --flags): a bit mask that switches single phases of a kernel off so
+// that their time can be attributed.  They exist ONLY in the separate profiling build (-DDRTK_AMD_ABLATION ->
+// profiles/libdrtk_amd_ablate.so, drtk_amd/build.py build_ablation()): in the product library the mask is the
+// compile-time constant 0, every DRTK_DBG() test folds to `false`, and there is no symbol that could set it.
+#ifdef DRTK_AMD_ABLATION
 int debug_flags();
+#define DRTK_DBG(mask, bit) (((mask) & (bit)) != 0)
+#else
+constexpr int debug_flags() { return 0; }
+#define DRTK_DBG(mask, bit) false
+#endif
 // Strip length for tile_index(): the tiles of 16 consecutive image rows (128 KB of every float plane at
 // W = 2048 -- strips of 64 to 256 KB measured best for every planar kernel, profiles/kernel_bench.py
 // --flags).  Diagnostics: debug flags >> 10 override it (1 = linear order).

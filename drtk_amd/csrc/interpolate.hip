@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         s_vid[wave][0 * kRunPad + lane] = vid0;
         s_vid[wave][1 * kRunPad + lane] = vid1;
         s_vid[wave][2 * kRunPad + lane] = vid2;
-        const bool use_table = TABLE && covered && !(dbg & 2) && vid0 != vid1 && vid0 != vid2 && vid1 != vid2;
+        const bool use_table = TABLE && covered && !DRTK_DBG(dbg, 2) && vid0 != vid1 && vid0 != vid2 && vid1 != vid2;
         s_slot[wave][0 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid0) : -1;
         s_slot[wave][1 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid1) : -1;
         s_slot[wave][2 * kRunPad + lane] = use_table ? table_slot(t_keys[wave], vid2) : -1;
@@ -212,12 +212,12 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
         for (int cb = 0; cb < CC; cb += CV) {
           T g[CV];
 #pragma unroll
-          for (int cc = 0; cc < CV; ++cc) g[cc] = (dbg & 4) ? T(1) : go_p[int64_t(c0 + cb + cc) * HW];
+          for (int cc = 0; cc < CV; ++cc) g[cc] = DRTK_DBG(dbg, 4) ? T(1) : go_p[int64_t(c0 + cb + cc) * HW];
           if constexpr (HAS_VERT) {
 #pragma unroll
             for (int cc = 0; cc < CV; ++cc) s_g[wave][(cb + cc) * kRunPad + lane] = g[cc];
           }
-          if (HAS_BARY && !(dbg & 8)) {
+          if (HAS_BARY && !DRTK_DBG(dbg, 8)) {
             T u0[CV], u1[CV], u2[CV];
             if constexpr (CV == 4) {
               const V4 q0 = *reinterpret_cast<const V4*>(a0 + c0 + cb);
@@ -257,13 +257,13 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
       }
       if constexpr (HAS_VERT) {
         wave_lds_sync();
-        if (cov != 0 && !(dbg & 1)) {
+        if (cov != 0 && !DRTK_DBG(dbg, 1)) {
           const T* sg = s_g[wave];
           const T* sb = s_b[wave];
           scatter_runs<T>(
               heads, cov, s_slot[wave], s_vid[wave], 3 * CC, CC, t_vals[wave], CHUNK, attr_grad_n, C, c0,
-              [sg, sb, dbg](int k, int c, int g4, T* x) {
-                if (dbg & 64) {
+              [=](int k, int c, int g4, T* x) {
+                if (DRTK_DBG(dbg, 64)) {
                   x[0] = x[1] = x[2] = x[3] = T(1);
                   return;
                 }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
       }
     }
     if constexpr (TABLE) {
-      if (!(dbg & 16)) table_flush<T>(t_keys[wave], t_vals[wave], CHUNK, CC, attr_grad_n, C, c0);
+      if (!DRTK_DBG(dbg, 16)) table_flush<T>(t_keys[wave], t_vals[wave], CHUNK, CC, attr_grad_n, C, c0);
     }
   }
 }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
       wave_lds_sync();
       // 4. phase 2: run sums per (corner, channel) lane -> one 64-byte atomic request per corner and run
       //    (a per-vertex LDS table in front of the atomics was measured slower here: 1.01 vs 0.83 ms)
-      if (cov != 0 && !(dbg & 1)) {
+      if (cov != 0 && !DRTK_DBG(dbg, 1)) {
         const T* sg = s_g[wave];
         const T* sb = s_b[wave];
         scatter_runs<T>(
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
       }
       // 5. bary gradient: interpolate_kernel.cu:238-246 accumulation order (channels ascending)
       T bg0 = T(0), bg1 = T(0), bg2 = T(0);
-      if (covered && !(dbg & 8)) {
+      if (covered && !DRTK_DBG(dbg, 8)) {
         V4 D0[QH], D1[QH], D2[QH]; // second half: requested now, used after the first half's products
 #pragma unroll
         for (int q = 0; q < QH; ++q) {
@@ -512,7 +512,7 @@ int interpolate_backward_impl(
       debug_flags(), strip)
   const bool small_c = C <= 4;
   // float only: the double instantiation would need > 256 VGPRs for the same pipeline
-  const bool wide = sizeof(T) == 4 && attr_grad && bary_grad && cvec && (C % 16 == 0) && !(debug_flags() & 128);
+  const bool wide = sizeof(T) == 4 && attr_grad && bary_grad && cvec && (C % 16 == 0) && !DRTK_DBG(debug_flags(), 128);
   if (wide) {
     if constexpr (sizeof(T) == 4) {
       hipLaunchKernelGGL(

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
           const GlobalPtr<const T> p = inp + c * plane;
           const T gOut = go[c] * alpha;
           if (gOut != T(0)) { // a zero upstream gradient (masked background) adds nothing
-            if (dbg & 1) {
+            if (DRTK_DBG(dbg, 1)) {
             } else if (cell >= 0) {
               T* wp = s_win + l * win_lstride + c * (kWin * kWin) + cell;
               if (q.o_nw >= 0) lds_add(wp, q.nw * gOut);
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
           }
           // texel values for the grid gradient: the two texels of a row in one 8-byte load when both exist
           T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
-          if (gOut != T(0) && !(dbg & 2)) { // with a zero upstream gradient every term below is +-0 * finite
+          if (gOut != T(0) && !DRTK_DBG(dbg, 2)) { // with a zero upstream gradient every term below is +-0 * finite
             if (q.o_nw >= 0 && q.o_ne >= 0) {
               const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_nw);
               v_nw = t2.x, v_ne = t2.y;
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   // cells outside the level were never written (only in-bounds corners are accumulated)
   for (int l = 0; l < kWinLevels; ++l) {
     const int d = ref + l;
-    if (d >= mipmaps || s_ox[l] == INT32_MAX || (dbg & 4)) continue;
+    if (d >= mipmaps || s_ox[l] == INT32_MAX || DRTK_DBG(dbg, 4)) continue;
     const int h = s_h[d], w = s_w[d];
     const int64_t plane = int64_t(h) * w;
     const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
@@ -826,7 +826,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   const int64_t count = N * H * W;
   if (count == 0) return DRTK_OK;
   if (!grid || !vt_dxdy_img || !grad_grid || (C > 0 && !grad_out)) return DRTK_ERR_INVALID_ARGUMENT;
-  if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !(debug_flags() & 512)) {
+  if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileW));
     hipLaunchKernelGGL(
         (mipmap_backward_tiled_kernel<float>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)),

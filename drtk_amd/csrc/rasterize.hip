@@ -651,7 +651,7 @@ __device__ __forceinline__ void raster_lanes(
   const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
   const int tl = (s.tl0 ? 1 : 0) | (s.tl1 ? 2 : 0) | (s.tl2 ? 4 : 0);
   unsigned long long todo = __ballot(valid && bx0 <= bx1 && by0 <= by1);
-  if (dbg & 1) todo = 0;
+  if (DRTK_DBG(dbg, 1)) todo = 0;
   while (todo) {
     const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
     todo &= todo - 1;
@@ -683,7 +683,7 @@ __device__ __forceinline__ void raster_lanes(
     T ex[3]; // -(px - ax) * dy part, constant over rows
 #pragma unroll
     for (int k = 0; k < 3; ++k) ex[k] = (px - u.ax[k]) * u.dy[k];
-    if (lx < bw && !(dbg & 2)) {
+    if (lx < bw && !DRTK_DBG(dbg, 2)) {
       for (int y = uby0 + ly; y <= uby1; y += sh) {
         const T py = static_cast<T>(y);
         T b0 = ((py - u.ay[0]) * u.dx[0] - ex[0]) * u.s[0];
@@ -691,7 +691,7 @@ __device__ __forceinline__ void raster_lanes(
         T b2 = ((py - u.ay[2]) * u.dx[2] - ex[2]) * u.s[2];
         if (!((b0 >= T(0)) && (b1 >= T(0)) && (b2 >= T(0)))) continue;
         if ((!(u.tl & 1) && b0 == T(0)) || (!(u.tl & 2) && b1 == T(0)) || (!(u.tl & 4) && b2 == T(0))) continue;
-        if (dbg & 4) {
+        if (DRTK_DBG(dbg, 4)) {
           atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], id);
           continue;
         }
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
         const int g_begin = take_pos ? begin : begin + n_pos, g_end = take_pos ? begin + n_pos : end_all;
         auto accept = [&](const TriSetup<T>& s) -> bool {
           if (!(s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0)) return false;
-          if (phase == 0 || s.z_lo_bits == 0 || (dbg & 16)) return true;
+          if (phase == 0 || s.z_lo_bits == 0 || DRTK_DBG(dbg, 16)) return true;
           const int cx0 = (max(s.bb_min_x, x0) - x0) >> 3, cx1 = (min(s.bb_max_x, x1) - x0) >> 3;
           const int cy0 = (max(s.bb_min_y, y0) - y0) >> 3, cy1 = (min(s.bb_max_y, y1) - y0) >> 3;
           if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 16) return true;
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
           int f = 0;
           bool valid = false;
           TriSetup<T> s = {};
-          if (i < end && !(dbg & 8)) {
+          if (i < end && !DRTK_DBG(dbg, 8)) {
             f = pairs[i];
             valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
             valid = valid && accept(s);

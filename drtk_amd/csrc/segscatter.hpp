@@ -87,7 +87,7 @@ __device__ __forceinline__ void scatter_runs(
   // lane channel c addresses component c_off + c * c_step of the table entry / destination row
   // (default: c itself), so callers can scatter a strided subset of the components
   auto flush = [&](int k, int c_lane, int start, T acc, bool exclusive) {
-    if (dbg & 32) return;
+    if (DRTK_DBG(dbg, 32)) return;
     const int c = c_off + c_lane * c_step;
     const int s = slot ? slot[k * kRunPad + start] : -1; // slot == nullptr: no table, always direct
     if (s < -1) return;                                   // -2: this corner receives nothing in this run

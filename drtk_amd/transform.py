@@ -1,11 +1,24 @@
 """Pinhole `transform` -- the step before the hot path (drtk/transform.py:13-119,
-drtk/utils/projection.py:33-53,486-540).  Only the undistorted pinhole model is provided (the
-distortion models are outside the hot-path scope).  On a HIP device, when the camera parameters do
+drtk/utils/projection.py:33-53,486-540).  Same signature as the reference; only the undistorted pinhole
+model is provided (`distortion_mode` None / "pinhole" / a list of those) -- the distortion models are
+outside the hot-path scope and raise NotImplementedError instead of computing something else.  On a HIP device, when the camera parameters do
 not require gradients, `transform` runs as ONE fused kernel each way (`drtk_amd_ext::transform_pinhole`,
 csrc/transform.hip); otherwise the PyTorch formulation below is used."""
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple, Union
 
 import torch as th
+
+
+def _require_pinhole(distortion_mode, distortion_coeff, fov=None, lut_vector_field=None, lut_spacing=None) -> None:
+    """The reference's mode handling (utils/projection.py:537-561) restricted to what is built here."""
+    if distortion_mode is not None:
+        assert distortion_coeff is not None, "Missing distortion coefficients."
+    modes = set(distortion_mode) if isinstance(distortion_mode, (list, tuple)) else {distortion_mode}
+    if not modes <= {None, "pinhole"}:
+        raise NotImplementedError(
+            f"drtk_amd.transform implements the pinhole camera only; distortion_mode={distortion_mode!r} "
+            "(radial-tangential / fisheye / fisheye62 of drtk.utils.projection) is outside the rasterize -> render -> "
+            "interpolate -> edge_grad path this package rebuilds (DESIGN.md, out of scope)")
 
 
 def project_pinhole(v_cam: th.Tensor, focal: th.Tensor, princpt: th.Tensor) -> th.Tensor:
@@ -26,6 +39,11 @@ def transform_with_v_cam(
     princpt: Optional[th.Tensor] = None,
     K: Optional[th.Tensor] = None,
     Rt: Optional[th.Tensor] = None,
+    distortion_mode: Optional[Union[List[str], str]] = None,
+    distortion_coeff: Optional[th.Tensor] = None,
+    fov: Optional[th.Tensor] = None,
+    lut_vector_field: Optional[th.Tensor] = None,
+    lut_spacing: Optional[th.Tensor] = None,
 ) -> Tuple[th.Tensor, th.Tensor]:
     if not ((camrot is not None and campos is not None) ^ (Rt is not None)):
         raise ValueError("You must provide exactly one of Rt or (campos, camrot).")
@@ -37,6 +55,7 @@ def transform_with_v_cam(
     if focal is None:
         focal = K[:, :2, :2]
         princpt = K[:, :2, 2]
+    _require_pinhole(distortion_mode, distortion_coeff, fov, lut_vector_field, lut_spacing)
     # camrot @ (v - campos) per vertex as one [N,V,3]x[N,3,3] batched product (see project_pinhole)
     v_cam = th.bmm(v - campos[:, None], camrot.transpose(1, 2))
     v_pix = project_pinhole(v_cam, focal, princpt)
@@ -51,9 +70,12 @@ def transform(
     princpt: Optional[th.Tensor] = None,
     K: Optional[th.Tensor] = None,
     Rt: Optional[th.Tensor] = None,
+    distortion_mode: Optional[Union[List[str], str]] = None,
+    distortion_coeff: Optional[th.Tensor] = None,
+    fov: Optional[th.Tensor] = None,
 ) -> th.Tensor:
     """World space `[N,V,3]` (or one shared `[1,V,3]`) -> `(x_pix, y_pix, z_cam)`;
-    `v_cam = camrot @ (v - campos)`."""
+    `v_cam = camrot @ (v - campos)`.  Signature of drtk/transform.py:13-24."""
     if v.is_cuda and v.dtype in (th.float32, th.float64):
         if not ((camrot is not None and campos is not None) ^ (Rt is not None)):
             raise ValueError("You must provide exactly one of Rt or (campos, camrot).")
@@ -65,6 +87,7 @@ def transform(
         if focal is None:
             focal = K[:, :2, :2]
             princpt = K[:, :2, 2]
+        _require_pinhole(distortion_mode, distortion_coeff, fov)
         cams = (campos, camrot, focal, princpt)
         if not (th.is_grad_enabled() and any(c.requires_grad for c in cams)):
             from drtk_amd.utils import load_torch_ops
@@ -74,4 +97,4 @@ def transform(
                 v = v[:1]  # expanded world-space vertices: keep them shared, the kernel broadcasts
             return th.ops.drtk_amd_ext.transform_pinhole(v, *cams)
         return transform_with_v_cam(v, *cams)[0]
-    return transform_with_v_cam(v, campos, camrot, focal, princpt, K, Rt)[0]
+    return transform_with_v_cam(v, campos, camrot, focal, princpt, K, Rt, distortion_mode, distortion_coeff, fov)[0]

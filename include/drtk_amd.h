@@ -269,10 +269,6 @@ int drtk_amd_transform_pinhole_backward(
 int drtk_amd_selftest_exact_div(
     drtk_dtype_t dtype, uint64_t seed, int64_t count, uint64_t* d_mismatches, drtk_stream_t stream);
 
-/* Diagnostics for profiling scripts: a bit mask that switches single kernel phases off so that
- * their time can be attributed.  Results are WRONG while it is non-zero; default 0. */
-void drtk_amd_debug_set_flags(int flags);
-
 #ifdef __cplusplus
 }
 #endif

@@ -14,8 +14,20 @@ ever sees the resulting .so files, which are git-ignored but travel with the gpu
     genuine NVIDIA `cuda_runtime.h` that this image ships inside the triton wheel
     (<site-packages>/triton/backends/nvidia/include) on the include path.  That is the header
     src/include/cuda_math_helper.h:11 asks for on its plain-C++ branch (std::min/std::max,
-    <cmath>) -- no stand-in headers, no stubs.  The reference's autograd modules (*_module.cpp)
-    are NOT built: they need the CUDA entry points to link.
+    <cmath>) -- no stand-in headers, no stubs.
+  * build_modules(): the reference's OWN torch-op modules (src/<x>/<x>_module.cpp: schemas, the four
+    C++ autograd Functions, autocast wrappers) + the same *_kernel_cpu.cpp, one .so per extension
+    (oracle/_ref/<x>_ext.so), so that the reference's Python package (drtk/*.py) runs end to end on
+    CPU in the build container -- used by oracle/gen_golden_refpy.py only.  The modules also name the
+    CUDA launchers (<x>_cuda, defined in *.cu: they need nvcc, which this image lacks, so they are NOT
+    built and NOT replaced by any code of ours): at link time each of those names is made an ALIAS of the
+    reference's own CPU twin of the same signature (`-Wl,--defsym,<mangled x_cuda>=<mangled x_cpu>`,
+    names read from the objects with nm; torch refuses to register a null kernel pointer, so the
+    symbols cannot simply stay undefined), i.e. the CUDA dispatch-key slots and the `is_cuda()`
+    branches -- which CPU tensors never reach -- point at reference code, and nothing is written in
+    their place.  These libraries register the reference's real namespaces
+    (rasterize_ext, ...), so they can never be loaded next to drtk_amd's own shim: the generator is a
+    process of its own.
     NOTE (measured here): the other route -- hipcc host-only, which makes the header take its
     `<hip/hip_runtime.h>` branch -- compiles but is WRONG on the host: `using ::min/::max`
     (cuda_math_helper.h:114-121) then binds to HIP's host-side `int max(int,int)`, so
@@ -29,6 +41,7 @@ ever sees the resulting .so files, which are git-ignored but travel with the gpu
 Never run the reference's own setup.py; never copy its sources.
 """
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -124,6 +137,61 @@ def build(variants=("strict", "fast"), force=False, verbose=True):
         if verbose:
             print(f"[ref_build] built {so}")
     return [os.path.join(OUT, f"libdrtk_ref_{v}.so") for v in variants]
+
+
+MODULES = ("rasterize", "render", "interpolate", "edge_grad")
+
+
+def module_path(name):
+    return os.path.join(OUT, f"{name}_ext.so")
+
+
+def build_modules(force=False, verbose=True, flags=("-O2", "-ffp-contract=off", "-fno-fast-math")):
+    """oracle/_ref/<x>_ext.so = /root/reference/src/<x>/<x>_module.cpp + <x>_kernel_cpu.cpp (strict
+    flags, like the fixtures), CUDA launcher symbols left null -- see the module docstring."""
+    if not available():
+        raise RuntimeError(f"reference sources under {REF} or triton's cuda_runtime.h not found; nothing to build")
+    os.makedirs(OUT, exist_ok=True)
+    inc, libdir, abi = _torch_flags()
+    common = [
+        CXX, "-std=c++17", "-fPIC", "-w", "-DNO_PYBIND", f"-D_GLIBCXX_USE_CXX11_ABI={abi}",
+        f"-I{REF}/src/include", f"-I{cuda_include_dir()}", *inc, *flags,
+    ]
+
+    def one(name):
+        so = module_path(name)
+        srcs = [os.path.join(REF, "src", name, f"{name}_module.cpp"), os.path.join(REF, "src", name, f"{name}_kernel_cpu.cpp")]
+        if (not force) and os.path.isfile(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs + [__file__]):
+            return f"[ref_build] {so} up to date"
+        objs = []
+        for s in srcs:
+            o = os.path.join(OUT, f"mod_{os.path.basename(s)}.o")
+            _run(common + ["-c", s, "-o", o])
+            objs.append(o)
+        undefined = {u for u in _run(["nm", "-u", objs[0]]).split() if u.startswith("_Z")}
+        alias = []
+        for u in sorted(undefined):
+            m = re.match(r"_Z(\d+)([A-Za-z0-9_]+?)(RKN2at6Tensor.*)$", u)
+            if m is None or "_cuda" not in m.group(2)[: int(m.group(1))]:
+                continue
+            name = m.group(2)[: int(m.group(1))]
+            rest = m.group(2)[int(m.group(1)):] + m.group(3)
+            twin = name.replace("_cuda", "_cpu")
+            cpu = f"_Z{len(twin)}{twin}{rest}"
+            if cpu not in undefined:
+                raise RuntimeError(f"{u}: no CPU twin {cpu} among the module's references")
+            alias.append(f"-Wl,--defsym,{u}={cpu}")
+        _run(["g++", "-shared", "-o", so, *objs, *alias, f"-L{libdir}",
+              "-ltorch", "-ltorch_cpu", "-lc10", f"-Wl,-rpath,{libdir}"])
+        for o in objs:
+            os.remove(o)
+        return f"[ref_build] built {so} (CUDA launcher names aliased to their CPU twins: {len(alias)})"
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for msg in ex.map(one, MODULES):
+            if verbose:
+                print(msg)
+    return [module_path(m) for m in MODULES]
 
 
 def load(variant="strict"):

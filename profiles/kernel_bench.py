@@ -21,8 +21,22 @@ ap.add_argument("--res", type=int, default=2048)
 ap.add_argument("--channels", type=int, default=16)
 ap.add_argument("--tex", type=int, default=4096)
 ap.add_argument("--uvscale", type=float, default=1.0)
-ap.add_argument("--flags", default="0", help="comma list of drtk_amd_debug_set_flags values to time every kernel under")
+ap.add_argument("--flags", default="0", help="comma list of ablation masks to time every kernel under; anything but 0 "
+                "needs the ablation build (python drtk_amd/build.py --ablation -> profiles/libdrtk_amd_ablate.so): the "
+                "product library has no such switches")
 a = ap.parse_args()
+ABLATE = a.flags != "0" or bool(os.environ.get("DRTK_ABLATE"))
+if ABLATE:
+    _path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdrtk_amd_ablate.so")
+    assert os.path.isfile(_path), f"{_path} missing: run `python drtk_amd/build.py --ablation`"
+    capi.use_profiling_library(_path)
+
+
+def set_flags(flags):
+    if ABLATE:
+        capi.lib().drtk_amd_debug_set_flags(flags)
+
+
 dev = "cuda:0"
 nl, no = S.MESH_SIZES[a.mesh]
 v, vi = S.sphere_views(a.views, nl, no, a.res, a.res, lobes=0.05, device=dev)
@@ -73,7 +87,7 @@ if "mipmap" in a.only:
     kernels["torch_grid_sample_fwd"] = lambda: th.nn.functional.grid_sample(tex[0], uvn, mode="bilinear", padding_mode="border", align_corners=False)
 th.cuda.synchronize()
 for flags in [int(x) for x in a.flags.split(",")]:
-    capi.lib().drtk_amd_debug_set_flags(flags)
+    set_flags(flags)
     for name, fn in kernels.items():
         if a.only and name not in a.only.split(","):
             continue
@@ -85,13 +99,13 @@ for flags in [int(x) for x in a.flags.split(",")]:
         ev1.record()
         th.cuda.synchronize()
         print(f"{name}{'' if flags == 0 else f' [flags={flags}]'}: {ev0.elapsed_time(ev1) / a.reps:.3f} ms")
-capi.lib().drtk_amd_debug_set_flags(0)
+set_flags(0)
 
 if os.environ.get("DRTK_ABLATE"):
     L = capi.lib()
     fn = kernels[os.environ["DRTK_ABLATE"]]
     for flags in [int(x) for x in os.environ.get('DRTK_ABLATE_FLAGS', '0,1,32,64,96,16').split(',')]:
-        L.drtk_amd_debug_set_flags(flags)
+        set_flags(flags)
         fn()
         th.cuda.synchronize()
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
@@ -101,4 +115,4 @@ if os.environ.get("DRTK_ABLATE"):
         e1.record()
         th.cuda.synchronize()
         print(f"ablate {os.environ['DRTK_ABLATE']} flags={flags:2d}: {e0.elapsed_time(e1) / 5:.3f} ms")
-    L.drtk_amd_debug_set_flags(0)
+    set_flags(0)

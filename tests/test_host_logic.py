@@ -22,6 +22,17 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/drtk_amd.h but not exported"
     assert sorted(capi.EXPORTS) == declared
+    # ... and nothing else: in particular no ablation switch (those live only in profiles/libdrtk_amd_ablate.so,
+    # built with -DDRTK_AMD_ABLATION for profiles/kernel_bench.py --flags)
+    import subprocess
+
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "drtk_amd", "libdrtk_amd.so")], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (drtk_amd_\w+)", syms)))
+    assert exported == declared, set(exported) ^ set(declared)
+    assert "debug" not in syms
+    for f in os.listdir(os.path.join(ROOT, "drtk_amd", "csrc")):
+        src = open(os.path.join(ROOT, "drtk_amd", "csrc", f)).read()
+        assert not re.search(r"\bdbg\s*&|debug_flags\(\)\s*(&|>>)", src.replace("debug_flags() >> 10", "")) , f"{f}: phase switch outside DRTK_DBG()"
     assert b"gfx950" in capi.lib().drtk_amd_version()
     assert capi.lib().drtk_amd_status_string(0) == b"ok"
 
