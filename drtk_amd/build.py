@@ -4,6 +4,7 @@
   drtk_amd/libdrtk_amd.so        HIP kernels + C ABI (include/drtk_amd.h); hipcc, no torch dependency
   drtk_amd/drtk_amd_torch_ops.so torch-op shim (rasterize_ext / render_ext / interpolate_ext /
                                  edge_grad_ext schemas + autograd), g++ against libtorch, links the above
+  drtk/<name>_ext.so             importable extension modules of the `import drtk` drop-in (gcc, CPython API)
 
 `python drtk_amd/build.py` builds both (`--force` rebuilds, `--dry-run` only reports what is missing or stale);
 __graft_entry__.build() calls build_all().  Run the FILE, not `python -m drtk_amd.build`: `-m` imports the package
@@ -113,9 +114,36 @@ def build_torch_ops(force=False, verbose=True):
     return OPS
 
 
+EXT_NAMES = ["rasterize_ext", "render_ext", "interpolate_ext", "edge_grad_ext", "mipmap_grid_sampler_ext"]
+SHIM = os.path.join(ROOT, "drtk")
+
+
+def build_ext_modules(force=False, verbose=True):
+    """drtk/<name>_ext.so for the `import drtk` drop-in: importable CPython modules (PyInit_<name>_ext) that pull
+    in drtk_amd_torch_ops.so -- see csrc/ext_module.c."""
+    import sysconfig
+
+    src = os.path.join(CSRC, "ext_module.c")
+    outs = []
+    for name in EXT_NAMES:
+        so = os.path.join(SHIM, name + ".so")
+        outs.append(so)
+        if not force and _newer(so, [src, OPS, __file__]):
+            continue
+        _run([
+            os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", f"-DDRTK_EXT_NAME={name}",
+            f"-I{sysconfig.get_paths()['include']}", src, "-o", so, "-Wl,--no-as-needed", f"-L{PKG}",
+            "-l:drtk_amd_torch_ops.so", "-Wl,-rpath,$ORIGIN/../drtk_amd",
+        ])
+        if verbose:
+            print(f"[drtk_amd] built {so}")
+    return outs
+
+
 def build_all(force=False, verbose=True):
     build_kernels(force=force, verbose=verbose)
     build_torch_ops(force=force, verbose=verbose)
+    build_ext_modules(force=force, verbose=verbose)
     return LIB, OPS
 
 

@@ -180,20 +180,26 @@ def test_hip_transform_matches_reference_fixture(tag):
 
 
 @pytest.mark.gpu
-def test_hip_step_matches_the_reference_python_stack():
+@pytest.mark.parametrize("package", ["drtk_amd", "drtk"])
+def test_hip_step_matches_the_reference_python_stack(package):
     """GPU: full step through drtk_amd (fused edge route without a hook, reference-shaped route with one) against
-    the reference's own stack; the gradient a hook sees and what its return value does included."""
-    import drtk_amd
+    the reference's own stack; the gradient a hook sees and what its return value does included.  `drtk` = the same
+    through the `import drtk` drop-in at the repo root."""
+    import importlib
 
-    _check_step(drtk_amd, DEV, close)
+    _check_step(importlib.import_module(package), DEV, close)
 
 
 @pytest.mark.gpu
 def test_hip_two_triangles_follows_the_reference_script():
-    """GPU: test/two_triangles.py at 64x64 against the curve of the reference's own stack."""
-    import torch.nn.functional as thf
+    """GPU: test/two_triangles.py at 64x64 against the curve of the reference's own stack, spelled like the script
+    (`from drtk import edge_grad_estimator, interpolate, rasterize, render`, :11) through the drop-in package."""
+    import types
 
-    import drtk_amd as ops
+    import torch.nn.functional as thf
+    from drtk import edge_grad_estimator, interpolate, rasterize, render
+
+    ops = types.SimpleNamespace(edge_grad_estimator=edge_grad_estimator, interpolate=interpolate, rasterize=rasterize, render=render)
 
     _, r = load_golden("refpy_two_triangles")
     vi, vt, tex = r["vi"].to(DEV), r["vt"].to(DEV), r["tex"].to(DEV)
