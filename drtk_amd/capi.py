@@ -100,6 +100,36 @@ def _i(x) -> ctypes.c_int64:
     return ctypes.c_int64(int(x))
 
 
+def _on_tensor_device(fn):
+    """Runs `fn` with the device of its first tensor argument made current.  The library sizes its grids from, and
+    launches on, hipGetDevice() -- the torch-op shim installs a device guard for that, this is the same guard for
+    ctypes callers: tensors on cuda:1 while cuda:0 is current would otherwise be launched against the wrong device.
+    Tensors of one call that live on different devices are an error."""
+    import functools
+
+    def tensors(args):
+        for a in args:
+            if isinstance(a, th.Tensor):
+                yield a
+            elif isinstance(a, (list, tuple)):
+                yield from (x for x in a if isinstance(x, th.Tensor))
+
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        ts = list(tensors(list(args) + list(kwargs.values())))
+        if not ts:
+            return fn(*args, **kwargs)
+        if not ts[0].is_cuda:
+            raise DrtkAmdError("drtk_amd implements the MI355X (HIP) path only; got a CPU tensor")
+        devs = {t.device for t in ts}
+        if len(devs) != 1:
+            raise DrtkAmdError(f"drtk_amd: tensors of one call on different devices: {sorted(map(str, devs))}")
+        with th.cuda.device(ts[0].device):
+            return fn(*args, **kwargs)
+
+    return guarded
+
+
 def _stream(t: th.Tensor, stream) -> ctypes.c_void_p:
     if not t.is_cuda:
         raise DrtkAmdError("drtk_amd implements the MI355X (HIP) path only; got a CPU tensor")
@@ -131,6 +161,7 @@ def rasterize_lines_workspace_bytes(N, H, W) -> int:
     return out.value
 
 
+@_on_tensor_device
 def rasterize(v, vi, height, width, stream=None, workspace=None, wireframe=False) -> Tuple[th.Tensor, th.Tensor]:
     v = v.contiguous()
     N, V, _ = v.shape
@@ -148,6 +179,7 @@ def rasterize(v, vi, height, width, stream=None, workspace=None, wireframe=False
     return depth, index
 
 
+@_on_tensor_device
 def render(v, vi, index_img, stream=None):
     v = v.contiguous()
     index_img = index_img.contiguous()
@@ -164,6 +196,7 @@ def render(v, vi, index_img, stream=None):
     return depth, bary
 
 
+@_on_tensor_device
 def render_backward(v, vi, index_img, grad_depth_img, grad_bary_img, stream=None):
     v = v.contiguous()
     index_img = index_img.contiguous()
@@ -180,6 +213,7 @@ def render_backward(v, vi, index_img, grad_depth_img, grad_bary_img, stream=None
     return grad_v
 
 
+@_on_tensor_device
 def interpolate(attrs, vi, index_img, bary_img, stream=None, masked=False):
     attrs = attrs.contiguous()
     index_img = index_img.contiguous()
@@ -201,6 +235,7 @@ def interpolate_masked(attrs, vi, index_img, bary_img, stream=None):
     return interpolate(attrs, vi, index_img, bary_img, stream, masked=True)
 
 
+@_on_tensor_device
 def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires_grad=True,
                          bary_requires_grad=True, stream=None):
     grad_out = grad_out.contiguous()
@@ -220,6 +255,7 @@ def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires
     return ag, bg
 
 
+@_on_tensor_device
 def interpolation_matrix(vi, index_img, bary_img, stream=None):
     """-> (crow_indices, col_indices, values, row_pixels); row_pixels/crow are built with torch ops
     (the caller's side of the C ABI), columns and values by drtk_amd_interpolation_matrix."""
@@ -240,6 +276,7 @@ def interpolation_matrix(vi, index_img, bary_img, stream=None):
     return crow, col, values, row_pixels
 
 
+@_on_tensor_device
 def interpolation_matrix_backward(grad_values, vi, index_img, row_pixels, stream=None):
     grad_values = grad_values.contiguous()
     index_img = index_img.contiguous()
@@ -265,6 +302,7 @@ def _pairs(pair_indices, N):
     return p, p.shape[1] * 9, p.shape[1]
 
 
+@_on_tensor_device
 def interpolation_normal_matrix_values(pair_indices, index_img, bary_img, nnz, stream=None):
     index_img = index_img.contiguous()
     bary_img = bary_img.contiguous()
@@ -279,6 +317,7 @@ def interpolation_normal_matrix_values(pair_indices, index_img, bary_img, nnz, s
     return values
 
 
+@_on_tensor_device
 def interpolation_normal_matrix_values_backward(grad_values, pair_indices, index_img, bary_img, stream=None):
     grad_values = grad_values.contiguous()
     index_img = index_img.contiguous()
@@ -303,6 +342,7 @@ def _level_table(levels):
     return lv, ptrs, lh, lw
 
 
+@_on_tensor_device
 def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0, interpolation_mode=0,
                            align_corners=False, force_max_aniso=False, clip_grad=False, stream=None):
     lv, ptrs, lh, lw = _level_table(levels)
@@ -321,6 +361,7 @@ def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0,
     return out
 
 
+@_on_tensor_device
 def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_aniso, padding_mode=0,
                                     interpolation_mode=0, align_corners=False, force_max_aniso=False,
                                     clip_grad=False, stream=None):
@@ -343,6 +384,7 @@ def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_ani
     return glv, ggrid
 
 
+@_on_tensor_device
 def screen_space_uv_derivative(v, vt, vi, vti, index_img, bary_img, mask, campos, camrot, focal, stream=None):
     """v [N,V,3] or shared [V,3]; vt [N,T,2] or shared [T,2]; mask bool/uint8 [N,H,W] or None."""
     index_img = index_img.contiguous()
@@ -372,6 +414,7 @@ def edge_grad_backward_workspace_bytes(dtype, N, H, W) -> int:
     return out.value
 
 
+@_on_tensor_device
 def edge_grad_backward(v_pix, img, index_img, vi, grad_output, max_dp_dr=1e4, stream=None, workspace=None):
     v_pix = v_pix.contiguous()
     img = img.contiguous()
@@ -392,6 +435,7 @@ def edge_grad_backward(v_pix, img, index_img, vi, grad_output, max_dp_dr=1e4, st
     return out
 
 
+@_on_tensor_device
 def edge_grad_backward_fused(v_pix, img, index_img, vi, bary_img, grad_output, max_dp_dr=1e4, stream=None):
     """grad_v_pix [N,V,3] = interpolate_backward(edge_grad_backward(...), v_pix, ...) in one call."""
     v_pix = v_pix.contiguous()

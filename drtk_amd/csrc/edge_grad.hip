@@ -482,9 +482,7 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
     if (e[j]) s_list[wave][total + __popcll(m & lt)] = static_cast<uint16_t>(lane * 4 + j);
     total += __popcll(m);
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_sync();
 
   const T* v_n = v_pix + int64_t(n) * V * 3;
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
@@ -507,9 +505,7 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
       s_out[wave][2][local] = oz;
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_wave_barrier();
+  wave_lds_sync();
   if (in_range) {
     T* o = out + int64_t(n) * 3 * HW + pix0;
 #pragma unroll

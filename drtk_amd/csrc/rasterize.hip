@@ -192,7 +192,11 @@ __device__ __forceinline__ bool tri_setup(
     const T zmin = min3(p0z, p1z, p2z);
     s.z_lo_bits = 0;
     if (delta < T(0.25)) {
-      const float lo = static_cast<float>(zmin * (T(1) - delta));
+      // ... and depth = 1 / epsclamp(depth_inverse) never exceeds 1 / eps (1e8 in f32, 1e16 in f64): geometry
+      // beyond that comes out AT 1 / eps, below its own min z, so the bound is the smaller of the two.
+      const T cap = (T(1) / Eps<T>::value()) * (T(1) - T(2e-6));
+      const T zb = zmin * (T(1) - delta);
+      const float lo = static_cast<float>(zb < cap ? zb : cap);
       const uint32_t bits = __float_as_uint(lo);
       s.z_lo_bits = (lo > 0.0f && bits > 8u) ? bits - 8u : 0u; // 8 ulps below, against the rounding of `lo` itself
     }

@@ -32,11 +32,17 @@ constexpr int kTileRows = 16;      // a workgroup (4 waves) covers 64 x 16 pixel
 constexpr int kTableProbes = 6;
 
 // Orders this wave's LDS writes before its later LDS reads by other lanes (wave-private staging
-// areas need no workgroup barrier: a wave's DS operations execute in order).
+// areas need no workgroup barrier: a wave's DS operations execute in order).  The hardware side is the
+// lgkmcnt(0) wait; the two wavefront-scope fences are for the COMPILER -- the barrier and waitcnt builtins carry no
+// memory semantics of their own, so without a release before and an acquire after nothing would forbid moving a
+// lane's plain LDS store below, or another lane's load above, the barrier (fence / wave_barrier / fence, the idiom
+// of HIP's own __syncwarp-style helpers).  Wavefront scope emits no instruction: disassembly unchanged.
 __device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0) only: do NOT drain outstanding global stores
   __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ void table_init(int32_t* keys) { // wave-private table

@@ -34,6 +34,15 @@ def screen_space_uv_derivative(
     """
     if dist_mode is not None:
         raise NotImplementedError("screen_space_uv_derivative(): only the undistorted pinhole projection is implemented")
+    if th.is_grad_enabled() and any(t.requires_grad for t in (v, vt, campos, camrot, focal)):
+        # The reference's composite would carry gradients from vt_dxdy_img back to these; the kernel is forward only.
+        # Its one consumer on the path, mipmap_grid_sample, defines no gradient for vt_dxdy_img (mipmap_grid_sampler_
+        # module.cpp backward returns none for it), so a rendering loss is unaffected -- anything else that
+        # differentiates through the Jacobians gets zeros, hence said once (Python shows a warning once per call site).
+        import warnings
+
+        warnings.warn("drtk_amd.screen_space_uv_derivative is not differentiable: vt_dxdy_img carries no gradient to v, vt or the "
+                      "camera (harmless in front of mipmap_grid_sample, which defines none for it)", stacklevel=2)
     with th.no_grad():
         return th.ops.drtk_amd_ext.screen_space_uv_derivative(
             v, vt, vi.int(), vti.int(), index_img, bary_img, mask, campos, camrot, focal

@@ -464,9 +464,14 @@ def test_sparse_operators_empty_and_background_only():
     assert float(bary.grad.abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("seed,ntri,scale,dtype", [(0, 20000, 40.0, th.float32), (1, 6000, 160.0, th.float32),
-                                                   (2, 60000, 12.0, th.float32), (3, 15000, 30.0, th.float64)])
-def test_rasterize_random_soup_is_bit_exact(seed, ntri, scale, dtype):
+@pytest.mark.parametrize("seed,ntri,scale,dtype,zscale", [
+    (0, 20000, 40.0, th.float32, 1.0), (1, 6000, 160.0, th.float32, 1.0), (2, 60000, 12.0, th.float32, 1.0),
+    (3, 15000, 30.0, th.float64, 1.0),
+    # depths beyond 1 / eps (1e8 in f32, 1e16 in f64): `1 / epsclamp(depth_inverse)` clamps them all to 1 / eps, below
+    # their own min z, and every pixel is an exact tie that must go to the lowest id -- the hierarchical-z bound has
+    # to know that cap (round-1 advisory); and depths straddling it
+    (4, 20000, 40.0, th.float32, 2e8), (5, 20000, 40.0, th.float32, 3e7), (6, 15000, 30.0, th.float64, 2e16)])
+def test_rasterize_random_soup_is_bit_exact(seed, ntri, scale, dtype, zscale):
     """Hierarchical-z stress: a triangle soup of random orientation, size and depth -- heavy overdraw,
     slivers, mixed facing in every tile, layers at nearly equal depth -- must give exactly the oracle's
     index and depth images (the rejection test may only drop triangles that cannot win a pixel)."""
@@ -481,7 +486,7 @@ def test_rasterize_random_soup_is_bit_exact(seed, ntri, scale, dtype):
     layer = th.randint(0, 4, (N, ntri, 1, 1), generator=g).float()
     z = 2.0 + layer + th.rand(N, ntri, 3, 1, generator=g) * 1e-3 * th.rand(N, ntri, 1, 1, generator=g)
     z[:, ::11] = 2.5  # exactly equal depths: ties go by id
-    v = th.cat([xy, z], -1).reshape(N, ntri * 3, 3).contiguous().to(dtype)
+    v = th.cat([xy.double(), z.double() * zscale], -1).reshape(N, ntri * 3, 3).contiguous().to(dtype)
     vi = th.arange(ntri * 3, dtype=th.int32).view(ntri, 3)
     want_d, want_i = O.rasterize(v, vi, H, W, nthreads=0)
     got_d, got_i = capi.rasterize(v.to(DEV), vi.to(DEV), H, W)
