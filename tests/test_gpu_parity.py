@@ -543,6 +543,28 @@ def test_wireframe_matches_restatement_bit_exact():
             assert th.equal(got_d.cpu(), want_d), (name, dt)
 
 
+def test_wireframe_kernel_gives_the_hand_derived_known_answers():
+    """The HIP wireframe kernel against answers that do not come from any implementation: the paper cases and the
+    exact-rational model of tests/wireframe_known_answers.py, through the C ABI and through drtk_amd.rasterize."""
+    import drtk_amd
+    import wireframe_known_answers as K
+    from drtk_amd import capi
+
+    def via_capi(v, vi, H, W):
+        d, i = capi.rasterize(v.to(DEV), vi.to(DEV), H, W, wireframe=True)
+        return d.cpu(), i.cpu()
+
+    def via_python_api(v, vi, H, W):
+        d, i = drtk_amd.rasterize_with_depth(v.to(DEV), vi.to(DEV), H, W, wireframe=True)
+        return d.cpu(), i.cpu()
+
+    for dt in (th.float32, th.float64):
+        K.check(via_capi, dt)
+    K.check(via_python_api)
+    K.check_against_exact_model(via_capi, range(60))
+    K.check_against_exact_model(via_capi, range(60, 80), th.float64)
+
+
 def test_wireframe_python_api_and_invariants():
     import drtk_amd
     from drtk_amd import synthetic as S

@@ -153,3 +153,17 @@ def test_sparse_pattern_is_pinned_by_reference_values(name):
         for b in range(3):
             adj[f[:, a], f[:, b]] = True
     assert th.equal(dense_pat, adj)
+
+
+def test_wireframe_restatement_gives_the_hand_derived_known_answers():
+    """Wireframe mode has no reference CPU twin and no reference test: the restatement is held to answers worked out on
+    paper from the rules of rasterize_kernel.cu:170-400 (tests/wireframe_known_answers.py: diamond rule on axis-aligned,
+    45-degree and slope-2 edges incl. corner touches, all 16 nibble values, occluding fill, drawn-beats-fill ties, the
+    unwritten canvas border, the culls), and to the same rules evaluated in exact rational arithmetic on random
+    quarter-pixel-grid scenes."""
+    import wireframe_known_answers as K
+
+    for dt in (th.float32, th.float64):
+        K.check(lambda v, vi, H, W: O.rasterize_lines(v, vi, H, W), dt)
+    K.check_against_exact_model(lambda v, vi, H, W: O.rasterize_lines(v, vi, H, W), range(16))
+    K.check_against_exact_model(lambda v, vi, H, W: O.rasterize_lines(v, vi, H, W), range(16, 20), th.float64)
