@@ -185,7 +185,7 @@ def test_autograd_contracts():
     res3 = ops.edge_grad_estimator(vr3, vi, b.detach(), img, index)
     assert th.equal(res3, img)
     (res3 * res3).sum().backward()
-    close(vr3.grad, vr2.grad, "fused vs unfused edge_grad_estimator", atol=1e-4)
+    close(vr3.grad, vr2.grad, "fused vs unfused edge_grad_estimator")
     # vi may be [N,F,3] or [F,3]
     idx2 = ops.rasterize(v, vi[None].repeat(v.shape[0], 1, 1), H, W)
     assert th.equal(idx2, index)
@@ -294,17 +294,65 @@ def test_full_size_view_matches_oracle(cfg):
     img_o = O.interpolate(attr, vi, i_o, rb_o, nthreads=0)
     assert th.equal(capi.interpolate(dev(attr), dev(vi), i_g, dev(rb_o)).cpu(), img_o), "interpolate forward is not bit-identical"
     close(capi.render_backward(dev(v), dev(vi), i_g, dev(gd), dev(gbar)),
-          O.render_backward(v, vi, i_o, gd, gbar, nthreads=0), "render backward", atol=1e-4)
+          O.render_backward(v, vi, i_o, gd, gbar, nthreads=0), "render backward")
     ag_o, bg_o = O.interpolate_backward(go, attr, vi, i_o, rb_o, nthreads=0)
     ag_g, bg_g = capi.interpolate_backward(dev(go), dev(attr), dev(vi), i_g, dev(rb_o))
-    close(ag_g, ag_o, "attr grad", atol=1e-4)
+    close(ag_g, ag_o, "attr grad")
     close(bg_g, bg_o, "bary grad")
     img = img_o * (i_o != -1)[:, None]
     eg_o = O.edge_grad_backward(v, img, i_o, vi, go, nthreads=0)
     close(capi.edge_grad_backward(dev(v), dev(img), i_g, dev(vi), dev(go)), eg_o, "edge grad")
     vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False, nthreads=0)
-    close(capi.edge_grad_backward_fused(dev(v), dev(img), i_g, dev(vi), dev(rb_o), dev(go)), vg_o,
-          "fused edge grad", atol=1e-4)
+    close(capi.edge_grad_backward_fused(dev(v), dev(img), i_g, dev(vi), dev(rb_o), dev(go)), vg_o, "fused edge grad")
+    # All at the north-star bar, 1e-5 + 1e-5 * max|ref| (round 1 had 1e-4 here without need).  Measured on MI355X
+    # (tests/diag_full_size_errors.py, largest |difference| / bar): render backward 4.6e-5 / 3.9e-4, 2.7e-5 / 1.7e-3,
+    # 3.8e-5 / 1.4e-3; attribute gradient 5.7e-5 / 4.4e-4, 3.4e-5 / 3.0e-4, 3.6e-5 / 2.7e-4; fused edge route
+    # 7.2e-7 / 3.9e-3, 5.1e-7 / 5.9e-5, 4.8e-7 / 3.6e-5 for the three configurations -- and against the f64 oracle the
+    # HIP sums are as near as (attribute gradient: 4-8x nearer than) the f32 oracle's.
+
+
+@pytest.mark.parametrize("mesh,res", [("100k", 2048), ("250k", 2048)])
+def test_full_size_index_img_against_the_reference_built_with_its_own_fast_math_flags(mesh, res):
+    """Depth-ordering policy at size.  Fixtures and oracle follow the strict-IEEE build of the reference; its own
+    setup.py builds with `-O3 --fast-math` (setup.py:23-24), and SURVEY App. A.1 measured ~1 pixel in 1 M changing
+    owner between the two.  Here the HIP rasterizer is compared with the reference's kernel AS BUILT WITH ITS OWN
+    FLAGS (oracle/_ref/libdrtk_ref_fast.so, compiled from /root/reference in the build container) on a full
+    benchmark view: the index images may differ only where two triangles' depths at that pixel agree to rounding
+    (a few float32 ulp) -- a near-tie decided by the compiler's choice of contraction, not by the algorithm."""
+    import os
+
+    from conftest import ROOT
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    if not os.path.isfile(os.path.join(ROOT, "oracle", "_ref", "libdrtk_ref_fast.so")):
+        pytest.skip("oracle/_ref/libdrtk_ref_fast.so not built (needs /root/reference in the build container)")
+    from backends import RefBackend
+
+    nl, no = S.MESH_SIZES[mesh]
+    v, vi = S.sphere_views(1, nl, no, res, res, lobes=0.05)
+    d_f, i_f = RefBackend("fast").rasterize(v, vi, res, res)
+    d_g, i_g = capi.rasterize(dev(v), dev(vi), res, res)
+    d_g, i_g = d_g.cpu(), i_g.cpu()
+    covered = int((i_f >= 0).sum())
+    assert covered > 0.4 * res * res
+    # coverage itself is exact arithmetic on both sides (edge functions of the same operands): same covered set
+    assert th.equal(i_g >= 0, i_f >= 0)
+    # depth: --fast-math contracts and reassociates, moving LSBs
+    rel = ((d_g.double() - d_f.double()).abs() / d_f.double().clamp(min=1e-30))[i_f >= 0]
+    assert float(rel.max()) <= 4e-7, float(rel.max())
+    differ = i_g != i_f
+    n_diff = int(differ.sum())
+    # every disagreement is a near-tie: the two winners' depths at the pixel are within 4 float32 ulp of each other
+    assert float(rel_at(differ, d_g, d_f)) <= 4 * 2.0 ** -23, (n_diff, float(rel_at(differ, d_g, d_f)))
+    assert n_diff <= max(8, covered // 100000), f"{n_diff} of {covered} covered pixels change owner under --fast-math"
+    print(f"[{mesh}@{res}] index_img vs the reference's --fast-math build: {n_diff} of {covered} covered px differ (all depth near-ties)")
+
+
+def rel_at(mask, a, b):
+    if not bool(mask.any()):
+        return th.zeros(())
+    return ((a.double() - b.double()).abs() / b.double().clamp(min=1e-30))[mask].max()
 
 
 @pytest.mark.parametrize("dtype", [th.float32, th.float64])
