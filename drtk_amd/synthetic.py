@@ -143,3 +143,57 @@ def fwd_bwd_step(v_pix: th.Tensor, vi: th.Tensor, attr: th.Tensor, height: int, 
     loss = (img * img).mean() + depth_img.mean()
     loss.backward()
     return loss, index_img
+
+
+def uv_sphere_atlas(n_lat: int, n_lon: int, device="cpu", dtype=th.float32) -> Tuple[th.Tensor, th.Tensor]:
+    """Latitude / longitude texture atlas of `uv_sphere(n_lat, n_lon)`: `(vt [(n_lat+1)*(n_lon+1), 2]` in `[0,1]`,
+    `vti [F,3] int32)`.  The atlas has its own topology -- one more column of uv vertices than the mesh has, so that
+    the last column of quads runs to u = 1 instead of wrapping back to u = 0 (no seam triangles spanning the whole
+    texture); faces are in the order of `uv_sphere`'s `vi`."""
+    i = th.arange(n_lat + 1, dtype=th.float64)
+    j = th.arange(n_lon + 1, dtype=th.float64)
+    # keep the atlas a little inside the texture so that the outermost taps stay off the border handling
+    u = (0.02 + 0.96 * j / n_lon)[None, :].expand(n_lat + 1, -1)
+    w = (0.02 + 0.96 * i / n_lat)[:, None].expand(-1, n_lon + 1)
+    vt = th.stack([u, w], dim=-1).reshape(-1, 2)
+    ii = th.arange(n_lat)[:, None].expand(-1, n_lon)
+    jj = th.arange(n_lon)[None, :].expand(n_lat, -1)
+    s = n_lon + 1
+    v00, v01, v10, v11 = ii * s + jj, ii * s + jj + 1, (ii + 1) * s + jj, (ii + 1) * s + jj + 1
+    t0 = th.stack([v00, v10, v11], dim=-1)
+    t1 = th.stack([v00, v11, v01], dim=-1)
+    vti = th.stack([t0, t1], dim=2).reshape(-1, 3).to(th.int32)
+    return vt.to(dtype).to(device), vti.to(device)
+
+
+def texture_pyramid(n: int, channels: int, size: int, seed: int = 1, device="cpu", dtype=th.float32, max_levels: int = 11):
+    """`[n, channels, size, size]` of smooth colour fields plus noise, and its box-filtered mip chain (finest first,
+    at most `max_levels` levels -- the sampler's limit, mipmap_grid_sampler_kernel.cu:912)."""
+    g = th.Generator(device="cpu").manual_seed(seed)
+    yy, xx = th.meshgrid(th.linspace(0, 1, size, dtype=th.float32), th.linspace(0, 1, size, dtype=th.float32), indexing="ij")
+    base = th.stack([0.5 + 0.5 * th.sin((3 + c) * math.pi * xx + c) * th.cos((2 + c) * math.pi * yy) for c in range(channels)])
+    lv = [(0.7 * base[None] + 0.3 * th.rand(n, channels, size, size, generator=g)).to(device)]
+    while lv[-1].shape[-1] > 1 and len(lv) < max_levels:
+        lv.append(th.nn.functional.avg_pool2d(lv[-1], 2))
+    return [t.to(dtype) for t in lv]
+
+
+def textured_shading(ops, v_world, v_pix, vi, vt, vti, tex, campos, camrot, focal, height, width, max_aniso=8,
+                     uv_jacobian=None, mipmap=None):
+    """Forward of BASELINE.json configs[4]'s textured pipeline, spelled with the drtk functions of `ops`:
+    rasterize -> render -> interpolate(uv) -> screen_space_uv_derivative -> mipmap_grid_sample -> mask ->
+    edge_grad_estimator (the reference's usage: drtk/mipmap_grid_sample.py:17-128, drtk/screen_space_uv_derivative.py:
+    15-80).  `uv_jacobian` / `mipmap` let a test substitute those two stages.  Returns a dict of the stage outputs."""
+    index_img = ops.rasterize(v_pix, vi, height, width)
+    depth_img, bary_img = ops.render(v_pix, vi, index_img)
+    mask = index_img != -1
+    uv_img = ops.interpolate(vt, vti, index_img, bary_img)  # [N,2,H,W]; fp16-stored uv is upcast by the op under autocast
+    jac_fn = uv_jacobian if uv_jacobian is not None else ops.screen_space_uv_derivative
+    vt_dxdy_img = jac_fn(v_world, vt.float() if vt.dtype == th.float16 else vt, vi, vti, index_img, bary_img, mask, campos, camrot, focal)
+    grid = (uv_img.permute(0, 2, 3, 1) * 2 - 1) * mask[..., None]
+    sample = mipmap if mipmap is not None else ops.mipmap_grid_sample
+    shaded = sample(tex, grid, vt_dxdy_img, max_aniso, padding_mode="border")
+    img = shaded * mask[:, None]
+    img = ops.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
+    return dict(index_img=index_img, depth_img=depth_img, bary_img=bary_img, uv_img=uv_img, vt_dxdy_img=vt_dxdy_img,
+                shaded=shaded, img=img)
