@@ -5,18 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): per GPU 8 camera views of a
-100 352-triangle "head" UV sphere at 2048x2048, 16 attribute channels, float32.  One step =
+Workload (default = `--config 3` = BASELINE.json configs[2], the one the metric is quoted on): per GPU 8 camera views
+of a 100 352-triangle "head" UV sphere at 2048x2048, 16 attribute channels, float32.  One step =
 transform -> rasterize -> render -> interpolate(C=16) -> mask -> edge_grad_estimator ->
 loss = mean(img^2) + mean(depth) -> backward, producing gradients for the SHARED world-space
 vertices [V,3] and SHARED attributes [1,V,C]; with N > 1 ranks every rank renders its own 8 views
-(weak scaling) and the shared gradients are summed with ONE fused RCCL all-reduce per step.
-All inputs are resident in HBM before the timed region.
+(weak scaling) and the shared gradients are summed over RCCL, each shared tensor's all-reduce launched on a side
+stream the moment its gradient is final (drtk_amd/dist.py).  All inputs are resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line.  `value` = all ranks' pixels / max-over-ranks wall time of the K timed
-steps.  `roofline` prices the dominant kernel (algorithmic bytes per SURVEY.md §8d / its HIP-event
-time, measured on the launch stream right after the timed region on the same tensors);
-`cpu_baseline` times the CPU oracle on this host's cores on a bounded sample of the same workload.
+Other configurations (parity-test cases of BASELINE.json, measured for profiles/rNN/other_configs/, never the
+headline): `--config 2` 4 views, 10k triangles, 512^2, C=3; `--config 4` 8 views/GPU, 250k triangles, 2048^2, C=16
+(BASELINE configs[3]: 64 views over 8 GPUs); `--config 5` = `--workload textured`: 1M triangles, 4096^2, uv
+interpolate -> screen_space_uv_derivative -> mipmap_grid_sample -> mask -> edge_grad_estimator with the uv attributes
+and the texture pyramid stored in fp16 under autocast (BASELINE configs[4]).  (Numbering as in SURVEY.md 8: config k =
+BASELINE.json configs[k-1].)
+
+Rank 0 prints ONE JSON line.  `value` = all ranks' pixels / max-over-ranks wall time of the K timed steps.
+`roofline` prices the single HIP kernel with the largest average duration: SURVEY.md 8d's algorithmic bytes of the
+tensors that kernel streams / its HIP-event time, measured live through the library's per-kernel timing
+(drtk_amd_kernel_timing_*: a pair of HIP events around every launch, on the stream it is launched on) over extra
+steps of the same workload right after the timed region; `path_roofline` holds the per-op and whole-path figures;
+`cpu_baseline` times the reference's own CPU kernels (oracle/_ref) or the CPU oracle on this host's cores on a
+bounded sample of the same workload.
 """
 import argparse
 import json
@@ -32,107 +42,100 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
+CONFIGS = {  # SURVEY.md 8 numbering; config k = BASELINE.json configs[k-1]
+    2: dict(workload="mesh", mesh="10k", res=512, views=4, channels=3),
+    3: dict(workload="mesh", mesh="100k", res=2048, views=8, channels=16),
+    4: dict(workload="mesh", mesh="250k", res=2048, views=8, channels=16),
+    5: dict(workload="textured", mesh="1M", res=4096, views=2, channels=3),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--views", type=int, default=8, help="views per GPU")
-    ap.add_argument("--mesh", default="100k", choices=["10k", "100k", "250k", "1M"])
-    ap.add_argument("--res", type=int, default=2048)
-    ap.add_argument("--channels", type=int, default=16)
-    ap.add_argument("--cpu-sample-views", type=int, default=2, help="views timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--kernel-reps", type=int, default=5)
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configs[k-1]; 3 = the headline")
+    ap.add_argument("--workload", default=None, choices=["mesh", "textured"])
+    ap.add_argument("--views", type=int, default=None, help="views per GPU")
+    ap.add_argument("--mesh", default=None, choices=["10k", "100k", "250k", "1M"])
+    ap.add_argument("--res", type=int, default=None)
+    ap.add_argument("--channels", type=int, default=None)
+    ap.add_argument("--tex", type=int, default=4096, help="textured workload: texture size")
+    ap.add_argument("--cpu-sample-views", type=int, default=None, help="views timed on the CPU (0 = skip)")
+    ap.add_argument("--kernel-steps", type=int, default=5, help="extra steps run under the per-kernel HIP-event timing")
+    ap.add_argument("--no-graph", action="store_true", help="skip the captured-graph timing of the same step")
+    ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)  # internal: this process only captures + replays the step
+    a = ap.parse_args()
+    if a.workload == "textured" and a.config == 3:
+        a.config = 5
+    for k, v in CONFIGS[a.config].items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    if a.cpu_sample_views is None:
+        a.cpu_sample_views = 2 if a.workload == "mesh" else 1
+    return a
 
 
-def algorithmic_bytes_per_px(C):
-    """bytes that must cross HBM per pixel for each op."""
+# ---- algorithmic bytes per pixel (f32), per op and per HIP kernel ----------------------------------------
+def op_bytes_per_px(C):
     return {
         "rasterize": 8,
         "render": 4 + 16,
         "interpolate": 16 + 4 * C,
-        "interpolate_vpix": 16 + 12,
-        "edge_grad_backward": 4 + 8 * C + 12,
         # fused edge_grad backward + v_pix scatter: reads index, img, grad_out and bary; no per-pixel write
         "edge_grad_backward_fused": 4 + 8 * C + 12,
-        "interpolate_backward_vpix": 28,
         "interpolate_backward": 4 * C + 16 + 12,
         "render_backward": 20,
     }
 
 
-# op -> substrings of the HIP kernels it launches (names as rocprofv3 prints them)
-OP_KERNELS = {
-    "rasterize": ["bin_count_kernel", "bin_scan_kernel", "bin_fill_kernel", "tile_raster_kernel"],
-    "render": ["render_kernel<"],
-    "interpolate": ["interpolate_kernel<float, 4, 4>"],
-    "edge_grad_backward": ["edge_dots_kernel", "edge_gather"],
-    "edge_grad_backward_fused": ["edge_dots_kernel", "edge_scatter_pairs_kernel"],
-    "interpolate_backward_vpix": ["interpolate_backward_kernel<float, true, false"],
-    "interpolate_backward": ["interpolate_backward_wide_kernel<float>", "interpolate_backward_kernel<float, true, true, 4, 16>"],
-    "render_backward": ["render_backward_kernel"],
+# HIP kernel (name as spelled at its launch site = prefix of what rocprofv3 prints) -> (op it belongs to, the bytes/px
+# of SURVEY 8d's per-pixel tensors that THIS kernel streams).  Kernels with 0 move per-triangle / per-vertex tables or
+# zero-fill a gradient (counted with the op's write, 8d's accounting rule).
+def kernel_table(C):
+    return {
+        "bin_count_kernel": ("rasterize", 0),
+        "bin_scan_kernel": ("rasterize", 0),
+        "bin_fill_kernel": ("rasterize", 0),
+        "tile_raster_kernel": ("rasterize", 8),                        # index 4 + depth 4 written
+        "render_kernel": ("render", 20),                               # index 4 read, depth 4 + bary 12 written
+        "interpolate_kernel": ("interpolate", 16 + 4 * C),             # index 4 + bary 12 read, C planes written
+        "edge_dots_kernel": ("edge_grad_backward_fused", 4 + 8 * C),   # index 4, img 4C, grad_out 4C read
+        "edge_scatter_pairs_kernel": ("edge_grad_backward_fused", 16), # index 4 + bary 12 read
+        "interpolate_backward_wide_kernel": ("interpolate_backward", 4 * C + 28),   # grad_out 4C, index, bary read; bary_grad 12 written
+        "interpolate_backward_kernel": ("interpolate_backward", 4 * C + 28),
+        "render_backward_kernel": ("render_backward", 20),             # index 4, grad_depth 4, grad_bary 12 read
+        "fill_bytes_kernel": ("zero-fill of gradients / workspaces", 0),
+    }
+
+
+TEXTURED_KERNELS = {  # additional kernels of the textured workload: (stage, bytes/px of per-pixel tensors streamed)
+    "uv_derivative_kernel": ("screen_space_uv_derivative", 16 + 16),   # index 4 + bary 12 read, Jacobian 16 written
+    "mipmap_forward_kernel": ("mipmap_grid_sample", 8 + 16 + 12),      # grid 8 + Jacobian 16 read, RGB 12 written (+ texel gathers)
+    "mipmap_backward_tiled_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),  # grad_out, grid, Jacobian read; grad_grid written
+    "mipmap_backward_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),
 }
 
 
-def measured_traffic(op):
-    """HBM bytes per launch of `op` from the newest committed PMC summary (profiles/rNN/traffic.json:
+def site_name(site):
+    """launch-site spelling '(edge_dots_kernel<T, 4, kStripRows, kDotsWaves>' -> 'edge_dots_kernel'"""
+    return site.strip("()").split("<")[0].strip()
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN/traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on the same kernels and workload,
-    corrected as MI355X_MICROARCH.md prescribes).  None if no profile covers the op."""
+    corrected as MI355X_MICROARCH.md prescribes).  None if no profile covers it."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
-    if not files or op not in OP_KERNELS:
+    if not files:
         return None
-    kernels = json.load(open(files[-1]))["kernels"]
-    total, hit = 0, 0
-    for pat in OP_KERNELS[op]:
-        for name, rec in kernels.items():
-            if pat in name:
-                total += rec["hbm_bytes"]
-                hit += 1
-    return int(total) if hit else None
-
-
-def time_kernels(v_pix, vi, attr, H, W, reps):
-    """Per-kernel HIP-event timing through the C ABI on torch's current stream (the stream the
-    kernels are launched on).  Returns {name: ms}."""
-    from drtk_amd import capi
-
-    def timed(fn):
-        fn()
-        th.cuda.synchronize()
-        ev = [th.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-        ev[0].record()
-        for r in range(reps):
-            fn()
-            ev[r + 1].record()
-        th.cuda.synchronize()
-        return sum(ev[r].elapsed_time(ev[r + 1]) for r in range(reps)) / reps
-
-    out = {}
-    depth0, index = capi.rasterize(v_pix, vi, H, W)
-    depth, bary = capi.render(v_pix, vi, index)
-    img = capi.interpolate(attr, vi, index, bary)
-    img = img * (index != -1)[:, None]
-    g = th.Generator(device=v_pix.device).manual_seed(0)
-    go = th.rand(img.shape, device=v_pix.device, generator=g) * 2 - 1
-    gd = th.rand(depth.shape, device=v_pix.device, generator=g)
-    gb = th.rand(bary.shape, device=v_pix.device, generator=g)
-    ws_r = th.empty(capi.rasterize_workspace_bytes(v_pix.shape[0], vi.shape[0], H, W), dtype=th.uint8, device=v_pix.device)
-    ws_e = th.empty(capi.edge_grad_backward_workspace_bytes(v_pix.dtype, v_pix.shape[0], H, W), dtype=th.uint8, device=v_pix.device)
-    out["rasterize"] = timed(lambda: capi.rasterize(v_pix, vi, H, W, workspace=ws_r))
-    out["render"] = timed(lambda: capi.render(v_pix, vi, index))
-    out["interpolate"] = timed(lambda: capi.interpolate(attr, vi, index, bary))
-    out["interpolate_vpix"] = timed(lambda: capi.interpolate(v_pix, vi, index, bary))
-    out["edge_grad_backward"] = timed(lambda: capi.edge_grad_backward(v_pix, img, index, vi, go, workspace=ws_e))
-    out["edge_grad_backward_fused"] = timed(lambda: capi.edge_grad_backward_fused(v_pix, img, index, vi, bary, go))
-    eg = capi.edge_grad_backward(v_pix, img, index, vi, go)
-    out["interpolate_backward_vpix"] = timed(lambda: capi.interpolate_backward(eg, v_pix, vi, index, bary, True, False))
-    out["interpolate_backward"] = timed(lambda: capi.interpolate_backward(go, attr, vi, index, bary, True, True))
-    out["render_backward"] = timed(lambda: capi.render_backward(v_pix, vi, index, gd, gb))
-    return out
+    for name, rec in json.load(open(files[-1]))["kernels"].items():
+        if site_name(name) == kernel or name.split("(")[0].split("<")[0].split()[-1] == kernel:
+            return int(rec["hbm_bytes"])
+    return None
 
 
 def _cpu_backend():
@@ -196,6 +199,48 @@ def cpu_baseline(v_pix, vi, attr, H, W, n_views, min_seconds=10.0):
     }
 
 
+def cpu_baseline_textured(v_world, v_pix, vi, vt, vti, tex, cams, H, W, min_seconds=8.0):
+    """fwd+bwd of the textured pipeline on ONE view with the CPU oracle (the sampler and the uv Jacobian have no CPU
+    implementation in the reference: `kind` is "port" for this workload)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+
+    cores = O.max_threads()
+    c = lambda t: t[:1].detach().float().cpu().contiguous()  # noqa: E731
+    v, vw, vtc = c(v_pix), v_world.detach().cpu()[None], c(vt)
+    vi_c, vti_c = vi.cpu(), vti.cpu()
+    texc = [c(t) for t in tex]
+    campos, camrot, focal = (c(t) for t in cams[:3])
+    g = th.Generator().manual_seed(0)
+    secs, passes = 0.0, 0
+    while secs < min_seconds and passes < 16:
+        t0 = time.perf_counter()
+        _, index = O.rasterize(v, vi_c, H, W, nthreads=0)
+        depth, bary = O.render(v, vi_c, index, nthreads=0)
+        uv = O.interpolate(vtc, vti_c, index, bary, nthreads=0)
+        mask = index != -1
+        jac = O.screen_space_uv_derivative(vw, vtc, vi_c, vti_c, index, bary, mask, campos, camrot, focal)
+        grid = ((uv.permute(0, 2, 3, 1) * 2 - 1) * mask[..., None]).contiguous()
+        img = O.mipmap_grid_sampler_2d(texc, grid, jac, 8, 1, 0) * mask[:, None]
+        O.interpolate(v, vi_c, index, bary, nthreads=0)  # edge_grad_estimator's forward
+        if passes == 0:
+            go = th.rand(img.shape, generator=g) * 2 - 1
+            gd = th.rand(depth.shape, generator=g)
+        eg = O.edge_grad_backward(v, img, index, vi_c, go, 1e4, nthreads=0)
+        O.interpolate_backward(eg, v, vi_c, index, bary, True, False, nthreads=0)
+        _, gg = O.mipmap_grid_sampler_2d_backward(go * mask[:, None], texc, grid, jac, 8, 1, 0)
+        guv = (gg * 2 * mask[..., None]).permute(0, 3, 1, 2).contiguous()
+        _, gb = O.interpolate_backward(guv, vtc, vti_c, index, bary, True, True, nthreads=0)
+        O.render_backward(v, vi_c, index, gd, gb, nthreads=0)
+        secs += time.perf_counter() - t0
+        passes += 1
+    return {
+        "value": round(passes * H * W / secs / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
+        "sample": f"1 of the views of the same workload, {passes} fwd+bwd passes of the textured pipeline with the CPU oracle "
+                  f"(four ops + restated sampler and uv Jacobian; the latter in PyTorch on the host), {cores} threads, {secs:.2f} s of CPU work",
+    }
+
+
 class _MeanSquare(th.autograd.Function):
     """User-side loss term mean(x^2), written so that forward is ONE reduction pass and backward ONE
     scaling pass over x (plain `(x*x).mean()` or `vector_norm(x)**2/n` cost 2-4 extra passes over the
@@ -212,6 +257,52 @@ class _MeanSquare(th.autograd.Function):
         return x * (g * (2.0 / x.numel()))
 
 
+def timed_loop(step, steps, dev, world):
+    from drtk_amd import dist as ddist
+
+    ddist.barrier_and_sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    ddist.barrier_and_sync(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = th.tensor([elapsed], dtype=th.float64, device=dev)
+        th.distributed.all_reduce(t, op=th.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, loss
+
+
+def graph_child(step, leaves, steps, pixels):
+    """torch's whole-network capture recipe: warm up on a side stream, gradients None so that the captured backward
+    allocates them in the graph's pool, capture ONE step, replay it `steps` times."""
+    for p in leaves:
+        p.grad = None
+    s = th.cuda.Stream()
+    s.wait_stream(th.cuda.current_stream())
+    with th.cuda.stream(s):
+        for _ in range(3):
+            step(reduce=False)
+    th.cuda.current_stream().wait_stream(s)
+    th.cuda.synchronize()
+    for p in leaves:
+        p.grad = None
+    g = th.cuda.CUDAGraph()
+    with th.cuda.graph(g):
+        g_loss = step(reduce=False)
+    g.replay()
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    th.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({
+        "value": round(pixels * steps / el / 1e6, 2), "ms_per_step": round(el / steps * 1e3, 4), "loss": round(float(g_loss.detach()), 6),
+        "note": "the identical step captured with torch.cuda.graph and replayed (same kernels, no host launch / autograd bookkeeping "
+                "between them), in a child process; reported beside the eager headline, never as `value`"}), flush=True)
+
+
 def main():
     args = parse()
     from drtk_amd import dist as ddist
@@ -219,12 +310,20 @@ def main():
     from drtk_amd.transform import transform
 
     rank, world, local_rank = ddist.init_from_env()
+    if args.gpus != world:
+        # Never re-exec or spawn from here: say how to launch instead (a mislabelled n_gpus would poison a scaling curve).
+        raise SystemExit(
+            f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s).  One process per GPU: launch with\n"
+            f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 "
+            f"bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
     assert th.cuda.is_available(), "bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)"
     # DRTK_FORCE_DEVICE: test-only (several ranks on one GPU with DRTK_DIST_BACKEND=gloo)
     dev = th.device("cuda", int(os.environ.get("DRTK_FORCE_DEVICE", local_rank)))
     th.cuda.set_device(dev)
     import drtk_amd
+    from drtk_amd import capi
 
+    textured = args.workload == "textured"
     H = W = args.res
     C = args.channels
     n_local = args.views
@@ -235,103 +334,184 @@ def main():
     mine = ddist.shard_views(n_total, rank, world)
     sl = slice(mine.start, mine.stop)
     campos, camrot, focal, princpt = campos[sl], camrot[sl], focal[sl], princpt[sl]
-    attr = S.random_attributes(1, v_world.shape[0], C, seed=0, device=dev)[:1].contiguous()
-
     v_world = v_world.clone().requires_grad_(True)  # shared across views and ranks
-    attr = attr.clone().requires_grad_(True)        # shared across views and ranks
-    reducer = ddist.SharedGradReducer([v_world, attr])
 
-    def step(fused_mask=False):
+    if textured:
+        vt, vti = S.uv_sphere_atlas(nl, no, device=dev)
+        vt = vt[None].half().requires_grad_(True)  # uv attributes stored in fp16, shared across views and ranks
+        tex = [t.half().requires_grad_(True) for t in S.texture_pyramid(1, 3, args.tex, device=dev)]  # shared fp16 texture pyramid
+        shared = [v_world]  # (vt and the pyramid are fp16 leaves: reduced by a second reducer of their dtype)
+        reducers = [ddist.SharedGradReducer([v_world]), ddist.SharedGradReducer([vt] + tex)]
+    else:
+        attr = S.random_attributes(1, v_world.shape[0], C, seed=0, device=dev)[:1].contiguous()
+        attr = attr.clone().requires_grad_(True)        # shared across views and ranks
+        reducers = [ddist.SharedGradReducer([v_world, attr])]
+
+    leaves = [p for r in reducers for p in r.params]
+
+    def step(fused_mask=False, reduce=True):
+        if reduce:
+            for r in reducers:
+                r.zero_grad()
+        else:  # graph capture: gradients must be allocated by the captured backward pass itself (torch's capture recipe)
+            for p in leaves:
+                p.grad = None
         v_pix = transform(v_world[None], campos, camrot, focal, princpt)  # shared [1,V,3] -> [n_local,V,3]
-        a = attr.expand(n_local, -1, -1)
-        index_img = drtk_amd.rasterize(v_pix, vi, H, W)
-        depth_img, bary_img = drtk_amd.render(v_pix, vi, index_img)
-        if fused_mask:
-            # drtk_amd extension, NOT part of the headline number: interpolate + background mask in one op
-            img = drtk_amd.interpolate_masked(a, vi, index_img, bary_img)
+        if textured:
+            with th.autocast("cuda", dtype=th.float16):
+                out = S.textured_shading(drtk_amd, v_world[None].expand(n_local, -1, -1), v_pix, vi, vt.expand(n_local, -1, -1), vti,
+                                         [t.expand(n_local, -1, -1, -1) for t in tex], campos, camrot, focal, H, W)
+            img, depth_img = out["img"], out["depth_img"]
         else:
-            img = drtk_amd.interpolate(a, vi, index_img, bary_img)
-            # user-side shading and loss (plain PyTorch, timed inside the step): mask the background,
-            # loss = mean(img^2) + mean(depth), written with the cheapest equivalent torch ops
-            img = th.where((index_img != -1)[:, None], img, 0.0)
-        img = drtk_amd.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
+            a = attr.expand(n_local, -1, -1)
+            index_img = drtk_amd.rasterize(v_pix, vi, H, W)
+            depth_img, bary_img = drtk_amd.render(v_pix, vi, index_img)
+            if fused_mask:
+                # drtk_amd extension, NOT part of the headline number: interpolate + background mask in one op
+                img = drtk_amd.interpolate_masked(a, vi, index_img, bary_img)
+            else:
+                img = drtk_amd.interpolate(a, vi, index_img, bary_img)
+                # user-side shading and loss (plain PyTorch, timed inside the step): mask the background,
+                # loss = mean(img^2) + mean(depth), written with the cheapest equivalent torch ops
+                img = th.where((index_img != -1)[:, None], img, 0.0)
+            img = drtk_amd.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
         loss = _MeanSquare.apply(img) + depth_img.mean()
         loss.backward()
-        reducer.all_reduce()
-        v_world.grad = None
-        attr.grad = None
+        if reduce:
+            for r in reducers:
+                r.finish()
         return loss
 
+    import warnings
+
+    warnings.filterwarnings("ignore", message=".*screen_space_uv_derivative is not differentiable.*")
+    if args.graph_child:
+        return graph_child(step, leaves, args.steps, n_total * H * W)
     for _ in range(args.warmup):
         step()
-    ddist.barrier_and_sync(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    ddist.barrier_and_sync(dev)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = th.tensor([elapsed], dtype=th.float64, device=dev)
-        th.distributed.all_reduce(t, op=th.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, loss = timed_loop(step, args.steps, dev, world)
     ms_per_step = elapsed / args.steps * 1e3
     mpix = n_total * H * W * args.steps / elapsed / 1e6
+    comm = reducers[0].timings_ms() if world > 1 else None
+    loss_value = float(loss.detach())
 
     # the same step with the drtk_amd.interpolate_masked extension (reported beside, never as `value`)
-    step(True)
-    ddist.barrier_and_sync(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss_fused = step(True)
-    ddist.barrier_and_sync(dev)
-    elapsed_fused = time.perf_counter() - t0
-    if world > 1:
-        t = th.tensor([elapsed_fused], dtype=th.float64, device=dev)
-        th.distributed.all_reduce(t, op=th.distributed.ReduceOp.MAX)
-        elapsed_fused = float(t.item())
+    ext = None
+    if not textured:
+        step(True)
+        elapsed_fused, loss_fused = timed_loop(lambda: step(True), args.steps, dev, world)
+        ext = {"interpolate_masked": {
+            "note": "same step with drtk_amd.interpolate_masked replacing interpolate + torch.where (identical loss and "
+                    "gradients); an opt-in extension, not the reference API, hence not the headline value",
+            "value": round(n_total * H * W * args.steps / elapsed_fused / 1e6, 2),
+            "ms_per_step": round(elapsed_fused / args.steps * 1e3, 4), "loss": round(float(loss_fused.detach()), 6)}}
+
+    # the same step (reference API) captured once as a HIP graph and replayed: what the launch / autograd overhead costs.
+    # Measured in a fresh CHILD process (started here, never exec'ed over this one) while this process idles: a capture
+    # that goes wrong takes down the process it runs in, and the headline must not depend on it.
+    graph = None
+    if world == 1 and not args.no_graph:
+        import subprocess
+
+        th.cuda.synchronize()
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--steps", str(args.steps), "--config", str(args.config),
+               "--workload", args.workload, "--mesh", args.mesh, "--res", str(args.res), "--views", str(args.views),
+               "--channels", str(args.channels), "--tex", str(args.tex)]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            graph = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+        except Exception as e:
+            graph = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     result = None
     if rank == 0:
-        with th.no_grad():
-            v_pix = transform(v_world[None].expand(n_local, -1, -1), campos, camrot, focal, princpt).contiguous()
-            a_full = attr.detach().expand(n_local, -1, -1).contiguous()
-            kt = time_kernels(v_pix, vi, a_full, H, W, args.kernel_reps)
+        # ---- per-kernel HIP-event timing of the real step (library kernels only; PyTorch glue is t_step - t_ops).
+        # Rank 0 alone runs these steps, so with several ranks they must not enter a collective.
+        alone = world == 1
+        step(reduce=alone)
+        th.cuda.synchronize()
+        capi.kernel_timing_begin()
+        for _ in range(args.kernel_steps):
+            step(reduce=alone)
+        th.cuda.synchronize()
+        sites = capi.kernel_timing_report()
+        table = dict(kernel_table(C), **(TEXTURED_KERNELS if textured else {}))
         P = n_local * H * W
-        bpp = algorithmic_bytes_per_px(C)
-        # ops the step actually launches (drtk_amd.edge_grad_estimator takes the fused route when no
-        # hook is registered); the remaining entries time the reference-graph route for comparison
-        in_step = ["rasterize", "render", "interpolate", "edge_grad_backward_fused", "interpolate_backward",
-                   "render_backward"]
-        dom = max(in_step, key=lambda k: kt[k])
-        ach = bpp[dom] * P / (kt[dom] * 1e-3) / 1e9
-        t_ops = sum(kt[k] for k in in_step)
-        unfused_bpp = 164 + 16 * C  # the figure of the unfused operator boundary
-        fused_bpp = sum(bpp[k] for k in in_step)
+        kernels = {}
+        for site, (count, total_ms) in sites.items():
+            k = site_name(site)
+            rec = kernels.setdefault(k, {"launches_per_step": 0.0, "ms_per_step": 0.0})
+            rec["launches_per_step"] += count / args.kernel_steps
+            rec["ms_per_step"] += total_ms / args.kernel_steps
+        for k, rec in kernels.items():
+            op, bpp = table.get(k, ("outside the four ops", 0))
+            rec["op"] = op
+            rec["ms_per_launch"] = rec["ms_per_step"] / max(rec["launches_per_step"], 1e-9)
+            rec["bytes_per_px"] = bpp
+            if bpp:
+                rec["GBps"] = round(bpp * P * rec["launches_per_step"] / (rec["ms_per_step"] * 1e-3) / 1e9, 1)
+            rec["ms_per_step"], rec["ms_per_launch"] = round(rec["ms_per_step"], 4), round(rec["ms_per_launch"], 4)
+            rec["launches_per_step"] = round(rec["launches_per_step"], 2)
+        priced = {k: r for k, r in kernels.items() if r["bytes_per_px"]}
+        dom = max(priced, key=lambda k: priced[k]["ms_per_launch"])
+        d = priced[dom]
+        alg = d["bytes_per_px"] * P
+        ach = alg / (d["ms_per_launch"] * 1e-3) / 1e9
+        traffic = measured_traffic(dom) if (args.config == 3 and (args.mesh, H, n_local, C) == ("100k", 2048, 8, 16)) else None
         roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic(dom) if (args.mesh, H, n_local, C) == ("100k", 2048, 8, 16) else None,
-            "algorithmic_bytes": bpp[dom] * P,
-            "bytes_per_px": bpp[dom], "ms_per_launch": round(kt[dom], 4),
-            # the op is one C-ABI call = these HIP kernels back to back (names as rocprofv3 prints them in
-            # profiles/rNN/bench_step_kernel_stats.txt; their average durations add up to ms_per_launch)
-            "hip_kernels": OP_KERNELS[dom],
+            "bound": "hbm", "kernel": dom, "op": d["op"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac_traffic": round(traffic / (d["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "algorithmic_bytes": alg, "bytes_per_px": d["bytes_per_px"], "ms_per_launch": d["ms_per_launch"],
+            "launches_per_step": d["launches_per_step"],
+            "how": f"HIP events around every launch of the kernel on its launch stream, {args.kernel_steps} steps of the same workload "
+                   "right after the timed region (drtk_amd_kernel_timing_*); bytes = SURVEY 8d's per-pixel tensors this kernel streams",
         }
+        ops_ms = {}
+        for k, r in kernels.items():
+            if r["op"] not in ("outside the four ops",):
+                ops_ms[r["op"]] = round(ops_ms.get(r["op"], 0.0) + r["ms_per_step"], 4)
+        path_kernels = [k for k, r in kernels.items() if k in table]
+        t_ops = sum(kernels[k]["ms_per_step"] for k in path_kernels)
+        if textured:
+            # rasterize 8 + render 20 + interpolate(uv, C=2) 24 + uv Jacobian 32 + sampler 36 + edge fwd (interpolate C=3) 28 +
+            # edge bwd (C=3) 4+24+12 + interpolate bwd C=3 28 + sampler bwd 44 + interpolate bwd (uv) 36 + render bwd 20
+            unfused_bpp, fused_bpp = 8 + 20 + 24 + 32 + 36 + 28 + 40 + 28 + 44 + 36 + 20, 8 + 20 + 24 + 32 + 36 + (4 + 24 + 12) + 44 + 36 + 20
+        else:
+            unfused_bpp = 164 + 16 * C  # the figure of the unfused operator boundary
+            fused_bpp = sum(op_bytes_per_px(C).values())
         path = {
             "bytes_per_px": unfused_bpp, "bytes_per_px_fused_route": fused_bpp, "t_ops_ms": round(t_ops, 4),
             "achieved_GBps_ops": round(unfused_bpp * P / (t_ops * 1e-3) / 1e9, 1),
             "frac_ops": round(unfused_bpp * P / (t_ops * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "frac_ops_fused_bytes": round(fused_bpp * P / (t_ops * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "frac_step": round(unfused_bpp * P / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "ops_in_step": in_step,
-            "kernels_ms": {k: round(x, 4) for k, x in kt.items()},
-            "kernels_GBps": {k: round(bpp[k] * P / (kt[k] * 1e-3) / 1e9, 1) for k in kt},
+            "ops_ms": ops_ms,
+            "kernels": kernels,
         }
         cpu = None
         if world == 1 and args.cpu_sample_views > 0:
-            cpu = cpu_baseline(v_pix, vi, a_full, H, W, min(args.cpu_sample_views, n_local))
+            with th.no_grad():
+                v_pix = transform(v_world[None].expand(n_local, -1, -1), campos, camrot, focal, princpt).contiguous()
+            if textured:
+                cpu = cpu_baseline_textured(v_world, v_pix, vi, vt, vti, tex, (campos, camrot, focal), H, W)
+            else:
+                a_full = attr.detach().expand(n_local, -1, -1).contiguous()
+                cpu = cpu_baseline(v_pix, vi, a_full, H, W, min(args.cpu_sample_views, n_local))
+        if textured:
+            what = (f"{n_local} views/GPU x {world} GPU, {args.mesh}-tri UV-sphere scene (F={vi.shape[0]}, V={v_world.shape[0]}), {H}x{W}, "
+                    f"RGB texture {args.tex}^2 + {len(tex) - 1} mip levels and uv attributes stored in fp16 under autocast, "
+                    "transform+rasterize+render+interpolate(uv)+screen_space_uv_derivative+mipmap_grid_sample(aniso 8)+mask+"
+                    "edge_grad_estimator+loss fwd+bwd")
+            metric = "Mpixels/sec fwd+bwd, 1M-tri @ 4096x4096 textured (edge_grad + mipmap_grid_sampler, fp16 attributes); HBM BW %"
+        else:
+            what = (f"{n_local} views/GPU x {world} GPU, {args.mesh}-tri UV-sphere head mesh (F={vi.shape[0]}, V={v_world.shape[0]}), "
+                    f"{H}x{W}, C={C} attribute channels, transform+rasterize+render+interpolate+mask+edge_grad_estimator+loss fwd+bwd")
+            metric = "Mpixels/sec fwd+bwd, 100k-tri @ 2048x2048, 1/2/4/8 GPU; HBM BW %"
+        nbytes = sum(r.nbytes() for r in reducers)
         result = {
-            "metric": "Mpixels/sec fwd+bwd, 100k-tri @ 2048x2048, 1/2/4/8 GPU; HBM BW %",
+            "metric": metric,
             "value": round(mpix, 2),
             "unit": "Mpix/s",
             "n_gpus": world,
@@ -344,25 +524,20 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{n_local} views/GPU x {world} GPU, {args.mesh}-tri UV-sphere head mesh "
-                            f"(F={vi.shape[0]}, V={v_world.shape[0]}), {H}x{W}, C={C} attribute channels, "
-                            "transform+rasterize+render+interpolate+mask+edge_grad_estimator+loss fwd+bwd",
+                "workload": what, "baseline_config": f"BASELINE.json configs[{args.config - 1}]",
                 "views_per_gpu": n_local, "triangles": int(vi.shape[0]), "vertices": int(v_world.shape[0]),
                 "height": H, "width": W, "channels": C,
-                "parallelism": f"views sharded {world}-way, one fused all-reduce of {reducer.nbytes()} B shared grads"
-                               if world > 1 else "single GPU",
+                "parallelism": (f"views sharded {world}-way, no data-path collective; {nbytes} B of shared gradients all-reduced over RCCL "
+                                "per step, each shared tensor on a side stream as soon as its gradient is final") if world > 1 else "single GPU",
             },
-            "loss": round(float(loss.detach()), 6),
-            "extensions": {
-                "interpolate_masked": {
-                    "note": "same step with drtk_amd.interpolate_masked replacing interpolate + torch.where "
-                            "(identical loss and gradients); an opt-in extension, not the reference API, hence "
-                            "not the headline value",
-                    "value": round(n_total * H * W * args.steps / elapsed_fused / 1e6, 2),
-                    "ms_per_step": round(elapsed_fused / args.steps * 1e3, 4),
-                    "loss": round(float(loss_fused.detach()), 6),
-                },
-            },
+            "loss": round(loss_value, 6),
+            "all_reduce": None if comm is None else {
+                "bytes": nbytes, "collectives_per_step": len(reducers[0].params),
+                "ms_launch_to_done": round(comm[0], 4), "ms_exposed_on_main_stream": round(comm[1], 4),
+                "note": "last timed step, rank 0: side-stream time from each collective's launch to its completion (sum), and how "
+                        "long the main stream then waited for them"},
+            "graph_step": graph,
+            "extensions": ext,
             "roofline": roofline,
             "path_roofline": path,
             "cpu_baseline": cpu,

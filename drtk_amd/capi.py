@@ -72,6 +72,8 @@ EXPORTS = [
     "drtk_amd_transform_pinhole",
     "drtk_amd_transform_pinhole_backward",
     "drtk_amd_selftest_exact_div",
+    "drtk_amd_kernel_timing_begin",
+    "drtk_amd_kernel_timing_report",
 ]
 
 
@@ -468,3 +470,21 @@ def selftest_exact_div(dtype=th.float32, seed=1, count=1 << 28, device="cuda:0")
     _check(lib().drtk_amd_selftest_exact_div(ctypes.c_int(code), ctypes.c_uint64(seed), _i(count), _p(out),
                                              _stream(out, None)), "selftest_exact_div")
     return int(out.item())
+
+
+def kernel_timing_begin() -> None:
+    """Open a per-kernel timing collection: until `kernel_timing_report()` every kernel the library launches (through
+    this module or through the torch operators -- same library) is bracketed by HIP events on its launch stream."""
+    _check(lib().drtk_amd_kernel_timing_begin(), "kernel_timing_begin")
+
+
+def kernel_timing_report() -> dict:
+    """Close the collection and return {launch-site kernel name: (launches, total_ms)} in order of first launch."""
+    need = ctypes.c_size_t(0)
+    buf = ctypes.create_string_buffer(1 << 16)
+    _check(lib().drtk_amd_kernel_timing_report(buf, ctypes.c_size_t(len(buf)), ctypes.byref(need)), "kernel_timing_report")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, count, ms = line.rsplit("\t", 2)
+        out[name.strip("()")] = (int(count), float(ms))
+    return out

@@ -1,6 +1,12 @@
 // Status strings / version of the C ABI (include/drtk_amd.h).
 #include "common.hpp"
 
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
 extern "C" const char* drtk_amd_status_string(int status) {
   switch (status) {
     case DRTK_OK:
@@ -65,10 +71,43 @@ int fill_bytes_async(void* p, int value, size_t bytes, hipStream_t stream) {
   const size_t want = (n16 + kBlock - 1) / kBlock;
   const size_t cap = size_t(num_compute_units()) * 16;
   const unsigned blocks = static_cast<unsigned>(want < 1 ? 1 : (want > cap ? cap : want));
-  hipLaunchKernelGGL(fill_bytes_kernel, dim3(blocks), dim3(kBlock), 0, stream, static_cast<unsigned char*>(p), head, n16, tail,
+  DRTK_LAUNCH(fill_bytes_kernel, dim3(blocks), dim3(kBlock), 0, stream, static_cast<unsigned char*>(p), head, n16, tail,
                      b * 0x01010101u);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
+}
+
+// ---- per-kernel timing (benchmarks) ---------------------------------------------------------------------------
+std::atomic<int> g_kernel_timing_on{0};
+namespace {
+struct TimingRec {
+  const char* name; // string literal of the launch site
+  hipEvent_t e0, e1;
+};
+std::mutex g_timing_mu;
+std::vector<TimingRec> g_timing;
+thread_local int t_timing_open = -1; // index of this thread's record between its two marks
+void timing_clear_locked() {
+  for (auto& r : g_timing) {
+    if (r.e0) (void)hipEventDestroy(r.e0);
+    if (r.e1) (void)hipEventDestroy(r.e1);
+  }
+  g_timing.clear();
+}
+} // namespace
+
+void kernel_timing_mark(const char* name, hipStream_t stream, bool begin) {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  if (begin) {
+    TimingRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, stream);
+    g_timing.push_back(r);
+    t_timing_open = static_cast<int>(g_timing.size()) - 1;
+  } else if (t_timing_open >= 0 && t_timing_open < static_cast<int>(g_timing.size())) {
+    (void)hipEventRecord(g_timing[t_timing_open].e1, stream);
+    t_timing_open = -1;
+  }
 }
 
 #ifdef DRTK_AMD_ABLATION
@@ -78,6 +117,56 @@ int debug_flags() {
 }
 #endif
 } // namespace drtk_amd
+
+extern "C" int drtk_amd_kernel_timing_begin(void) {
+  std::lock_guard<std::mutex> lock(drtk_amd::g_timing_mu);
+  drtk_amd::timing_clear_locked();
+  drtk_amd::g_kernel_timing_on.store(1);
+  return DRTK_OK;
+}
+
+extern "C" int drtk_amd_kernel_timing_report(char* buf, size_t capacity, size_t* needed) {
+  using namespace drtk_amd;
+  g_kernel_timing_on.store(0);
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  // aggregate by launch site, in order of first appearance
+  std::vector<const char*> names;
+  std::vector<double> total;
+  std::vector<long> count;
+  int status = DRTK_OK;
+  for (auto& r : g_timing) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+      status = DRTK_ERR_LAUNCH;
+      (void)hipGetLastError();
+      continue;
+    }
+    size_t k = 0;
+    while (k < names.size() && names[k] != r.name && std::strcmp(names[k], r.name) != 0) ++k;
+    if (k == names.size()) {
+      names.push_back(r.name);
+      total.push_back(0.0);
+      count.push_back(0);
+    }
+    total[k] += ms;
+    count[k] += 1;
+  }
+  std::string out;
+  char line[512];
+  for (size_t k = 0; k < names.size(); ++k) {
+    std::snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", names[k], count[k], total[k]);
+    out += line;
+  }
+  timing_clear_locked();
+  if (needed) *needed = out.size() + 1;
+  if (buf && capacity > 0) {
+    const size_t n = out.size() < capacity - 1 ? out.size() : capacity - 1;
+    std::memcpy(buf, out.data(), n);
+    buf[n] = 0;
+    if (n < out.size() && status == DRTK_OK) status = DRTK_ERR_WORKSPACE_TOO_SMALL;
+  }
+  return status;
+}
 
 #ifdef DRTK_AMD_ABLATION
 // profiling build only (profiles/libdrtk_amd_ablate.so); not declared in include/drtk_amd.h, not in libdrtk_amd.so

@@ -6,6 +6,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 #include "drtk_amd.h"
@@ -132,6 +134,27 @@ int fill_bytes_async(void* p, int value, size_t bytes, hipStream_t stream);
 inline int64_t ceil_div(int64_t a, int64_t b) {
   return (a + b - 1) / b;
 }
+
+// Per-kernel timing for benchmarks (include/drtk_amd.h: drtk_amd_kernel_timing_begin / _report).  Every launch of
+// the library goes through DRTK_LAUNCH; while a collection is open the launch is bracketed by two HIP events on its
+// own stream (what is computed is unaffected), otherwise the scope object costs one relaxed atomic load.
+extern std::atomic<int> g_kernel_timing_on;
+void kernel_timing_mark(const char* name, hipStream_t stream, bool begin);
+struct KernelTimingScope {
+  hipStream_t stream;
+  bool on;
+  KernelTimingScope(const char* name, hipStream_t s) : stream(s), on(g_kernel_timing_on.load(std::memory_order_relaxed) != 0) {
+    if (on) kernel_timing_mark(name, stream, true);
+  }
+  ~KernelTimingScope() {
+    if (on) kernel_timing_mark(nullptr, stream, false);
+  }
+};
+#define DRTK_LAUNCH(kernel, grid, block, shmem, stream, ...)             \
+  do {                                                                   \
+    ::drtk_amd::KernelTimingScope drtk_timing_scope_(#kernel, stream);   \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
+  } while (0)
 
 #define DRTK_RETURN_IF_LAUNCH_FAILED()                      \
   do {                                                      \

@@ -738,19 +738,19 @@ int edge_grad_backward_impl(
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
   if (vec) {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
+    DRTK_LAUNCH((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
   } else {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
+    DRTK_LAUNCH((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   const bool vec_out = vec && (reinterpret_cast<uintptr_t>(index_img) % 16 == 0) &&
       (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0);
   if (vec_out) {
     const dim3 gridB(static_cast<unsigned>(ceil_div(HW, kBlock * 4)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((edge_gather4_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out, xcd_strip(ceil_div(16 * W, kBlock * 4)));
+    DRTK_LAUNCH((edge_gather4_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out, xcd_strip(ceil_div(16 * W, kBlock * 4)));
   } else {
     const dim3 gridB(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((edge_gather_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out);
+    DRTK_LAUNCH((edge_gather_kernel<T>), gridB, dim3(kBlock), 0, stream, v_pix, vi, index_img, gdx, gdy, V, vi_sN, (int)H, (int)W, static_cast<T>(max_dp_dr), out);
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
@@ -764,9 +764,9 @@ int launch_edge_dots(const T* img, const T* grad_output, const int32_t* index_im
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
   if (vec) {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
+    DRTK_LAUNCH((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
   } else {
-    hipLaunchKernelGGL((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
+    DRTK_LAUNCH((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
@@ -801,9 +801,9 @@ int edge_grad_backward_fused_impl(
     const dim3 grid(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
     const int strip = xcd_strip(ceil_div(int64_t(strips_x) * 4, kBlock / kWave));
     if (aligned_to(index_img, 16)) {
-      hipLaunchKernelGGL((edge_scatter_pairs_kernel<T, true>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
+      DRTK_LAUNCH((edge_scatter_pairs_kernel<T, true>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
     } else {
-      hipLaunchKernelGGL((edge_scatter_pairs_kernel<T, false>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
+      DRTK_LAUNCH((edge_scatter_pairs_kernel<T, false>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
     }
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;

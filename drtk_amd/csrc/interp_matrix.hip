@@ -177,7 +177,7 @@ extern "C" int drtk_amd_interpolation_matrix(
   if (!vi || !index_img || !bary_img || !row_pixels || !col_indices || !values) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(ceil_div(R, kBlock)));
-#define CALL hipLaunchKernelGGL((interpolation_matrix_kernel<T>), grid, dim3(kBlock), 0, s, vi, index_img, static_cast<const T*>(bary_img), row_pixels, R, vi_sN, H * W, col_indices, static_cast<T*>(values))
+#define CALL DRTK_LAUNCH((interpolation_matrix_kernel<T>), grid, dim3(kBlock), 0, s, vi, index_img, static_cast<const T*>(bary_img), row_pixels, R, vi_sN, H * W, col_indices, static_cast<T*>(values))
   DRTK_DISPATCH(dtype, CALL, CALL)
 #undef CALL
   DRTK_RETURN_IF_LAUNCH_FAILED();
@@ -199,7 +199,7 @@ extern "C" int drtk_amd_interpolation_matrix_backward(
   if (R == 0) return DRTK_OK;
   if (!grad_values || !vi || !index_img || !row_pixels) return DRTK_ERR_INVALID_ARGUMENT;
   const dim3 grid(static_cast<unsigned>(ceil_div(R, kBlock)));
-#define CALL hipLaunchKernelGGL((interpolation_matrix_backward_kernel<T>), grid, dim3(kBlock), 0, s, static_cast<const T*>(grad_values), vi, index_img, row_pixels, R, vi_sN, H * W, static_cast<T*>(bary_grad))
+#define CALL DRTK_LAUNCH((interpolation_matrix_backward_kernel<T>), grid, dim3(kBlock), 0, s, static_cast<const T*>(grad_values), vi, index_img, row_pixels, R, vi_sN, H * W, static_cast<T*>(bary_grad))
   DRTK_DISPATCH(dtype, CALL, CALL)
 #undef CALL
   DRTK_RETURN_IF_LAUNCH_FAILED();
@@ -221,7 +221,7 @@ extern "C" int drtk_amd_interpolation_normal_matrix_values(
   if (N * H * W == 0 || nnz == 0) return DRTK_OK;
   if (!pair_indices || !index_img || !bary_img) return DRTK_ERR_INVALID_ARGUMENT;
   const dim3 grid(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N));
-#define CALL hipLaunchKernelGGL((normal_matrix_values_kernel<T>), grid, dim3(kBlock), 0, s, pair_indices, index_img, static_cast<const T*>(bary_img), pair_sN, H * W, static_cast<T*>(values))
+#define CALL DRTK_LAUNCH((normal_matrix_values_kernel<T>), grid, dim3(kBlock), 0, s, pair_indices, index_img, static_cast<const T*>(bary_img), pair_sN, H * W, static_cast<T*>(values))
   DRTK_DISPATCH(dtype, CALL, CALL)
 #undef CALL
   DRTK_RETURN_IF_LAUNCH_FAILED();
@@ -247,7 +247,7 @@ extern "C" int drtk_amd_interpolation_normal_matrix_values_backward(
   }
   if (!grad_values || !pair_indices || !index_img || !bary_img) return DRTK_ERR_INVALID_ARGUMENT;
   const dim3 grid(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N));
-#define CALL hipLaunchKernelGGL((normal_matrix_values_backward_kernel<T>), grid, dim3(kBlock), 0, s, static_cast<const T*>(grad_values), pair_indices, index_img, static_cast<const T*>(bary_img), pair_sN, H * W, static_cast<T*>(bary_grad))
+#define CALL DRTK_LAUNCH((normal_matrix_values_backward_kernel<T>), grid, dim3(kBlock), 0, s, static_cast<const T*>(grad_values), pair_indices, index_img, static_cast<const T*>(bary_img), pair_sN, H * W, static_cast<T*>(bary_grad))
   DRTK_DISPATCH(dtype, CALL, CALL)
 #undef CALL
   DRTK_RETURN_IF_LAUNCH_FAILED();

@@ -468,7 +468,7 @@ int interpolate_impl(
   const bool cvec = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(attrs) % (4 * sizeof(T)) == 0);
   const dim3 block(kBlock);
 #define LAUNCH(VEC, CV)                                                                         \
-  hipLaunchKernelGGL(                                                                           \
+  DRTK_LAUNCH(                                                                           \
       (interpolate_kernel<T, VEC, CV>),                                                         \
       dim3(static_cast<unsigned>(ceil_div(HW / VEC, kBlock)), static_cast<unsigned>(N)), block, \
       0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out, zero_background, \
@@ -506,7 +506,7 @@ int interpolate_backward_impl(
   const dim3 block(kBlock);
   const int strip = xcd_strip(int64_t(tiles_x) * (16 / kTileRows));
 #define LAUNCH(HV, HB, CV, CH)                                                                  \
-  hipLaunchKernelGGL(                                                                           \
+  DRTK_LAUNCH(                                                                           \
       (interpolate_backward_kernel<T, HV, HB, CV, CH>), grid, block, 0, stream, grad_out, attrs, \
       vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad,  \
       debug_flags(), strip)
@@ -515,7 +515,7 @@ int interpolate_backward_impl(
   const bool wide = sizeof(T) == 4 && attr_grad && bary_grad && cvec && (C % 16 == 0) && !DRTK_DBG(debug_flags(), 128);
   if (wide) {
     if constexpr (sizeof(T) == 4) {
-      hipLaunchKernelGGL(
+      DRTK_LAUNCH(
           (interpolate_backward_wide_kernel<T>), grid, block, 0, stream, grad_out, attrs, vi, index_img, bary_img,
           V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip);
     }

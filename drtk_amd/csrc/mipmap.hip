@@ -789,7 +789,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid_dim(static_cast<unsigned>(ceil_div(count, kBlock)));
 #define LAUNCH(T, MODE)                                                                                   \
-  hipLaunchKernelGGL(                                                                                     \
+  DRTK_LAUNCH(                                                                                     \
       (mipmap_forward_kernel<T, MODE>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grid), \
       static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, force_max_aniso != 0,  \
       clip_grad != 0, static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
@@ -828,7 +828,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   if (!grid || !vt_dxdy_img || !grad_grid || (C > 0 && !grad_out)) return DRTK_ERR_INVALID_ARGUMENT;
   if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileW));
-    hipLaunchKernelGGL(
+    DRTK_LAUNCH(
         (mipmap_backward_tiled_kernel<float>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)),
         dim3(kBlock), sizeof(float) * kWinLevels * C * kWin * kWin, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid),
         static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, padding_mode, align_corners != 0,
@@ -838,7 +838,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   }
   const dim3 grid_dim(static_cast<unsigned>(ceil_div(count, kBlock)));
 #define LAUNCH(T, MODE)                                                                                       \
-  hipLaunchKernelGGL(                                                                                         \
+  DRTK_LAUNCH(                                                                                         \
       (mipmap_backward_kernel<T, MODE>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grad_out), \
       static_cast<const T*>(grid), static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, \
       align_corners != 0, force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid),                       \

@@ -945,18 +945,18 @@ int rasterize_impl(
   const int64_t total = N * F;
   const dim3 tri_grid(static_cast<unsigned>(ceil_div(F > 0 ? F : 1, kBlock)), static_cast<unsigned>(N));
   if (total > 0) {
-    hipLaunchKernelGGL(
+    DRTK_LAUNCH(
         bin_count_kernel<T>, tri_grid, dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN, (int)H,
         (int)W, L.tile_shift, L.tiles_x, (int)L.tiles_per_view, tile_count, big_count, big_list,
         tri_range, view_stats);
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
-  hipLaunchKernelGGL(
+  DRTK_LAUNCH(
       bin_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_count, tile_offset, (int)L.num_tiles,
       L.tile_shift, items, queue);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   if (total > 0) {
-    hipLaunchKernelGGL(
+    DRTK_LAUNCH(
         bin_fill_kernel, tri_grid, dim3(kBlock), 0, stream, tri_range, (int)F, L.tiles_x,
         (int)L.tiles_per_view, tile_offset, tile_cursor, pairs);
     DRTK_RETURN_IF_LAUNCH_FAILED();
@@ -965,12 +965,12 @@ int rasterize_impl(
   const int64_t resident = int64_t(num_compute_units()) * 4;
   const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(L.max_items, resident));
   if (L.tile_shift == 6) {
-    hipLaunchKernelGGL(
+    DRTK_LAUNCH(
         (tile_raster_kernel<T, 6>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
         (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,
         big_list, tri_range, items, queue, depth_img, index_img, debug_flags());
   } else {
-    hipLaunchKernelGGL(
+    DRTK_LAUNCH(
         (tile_raster_kernel<T, 5>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
         (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,
         big_list, tri_range, items, queue, depth_img, index_img, debug_flags());
@@ -1039,9 +1039,9 @@ extern "C" int drtk_amd_selftest_exact_div(
   if (fill_bytes_async(d_mismatches, 0, sizeof(uint64_t), s) != DRTK_OK) return DRTK_ERR_LAUNCH;
   const unsigned blocks = 4096;
   if (dtype == DRTK_F32) {
-    hipLaunchKernelGGL((exact_div_selftest_kernel<float>), dim3(blocks), dim3(kBlock), 0, s, seed, (long long)count, (unsigned long long*)d_mismatches);
+    DRTK_LAUNCH((exact_div_selftest_kernel<float>), dim3(blocks), dim3(kBlock), 0, s, seed, (long long)count, (unsigned long long*)d_mismatches);
   } else if (dtype == DRTK_F64) {
-    hipLaunchKernelGGL((exact_div_selftest_kernel<double>), dim3(blocks), dim3(kBlock), 0, s, seed, (long long)count, (unsigned long long*)d_mismatches);
+    DRTK_LAUNCH((exact_div_selftest_kernel<double>), dim3(blocks), dim3(kBlock), 0, s, seed, (long long)count, (unsigned long long*)d_mismatches);
   } else {
     return DRTK_ERR_INVALID_ARGUMENT;
   }

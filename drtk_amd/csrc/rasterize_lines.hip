@@ -165,13 +165,13 @@ int rasterize_lines_dispatch(
   if (N * F > 0) {
     const dim3 grid(static_cast<unsigned>(ceil_div(F, kBlock / kWave)), static_cast<unsigned>(N));
     if (dtype == DRTK_F32) {
-      hipLaunchKernelGGL((rasterize_lines_kernel<float>), grid, dim3(kBlock), 0, stream, static_cast<const float*>(v), vi, (int)F, V, vi_sN, (int)H, (int)W, packed);
+      DRTK_LAUNCH((rasterize_lines_kernel<float>), grid, dim3(kBlock), 0, stream, static_cast<const float*>(v), vi, (int)F, V, vi_sN, (int)H, (int)W, packed);
     } else {
-      hipLaunchKernelGGL((rasterize_lines_kernel<double>), grid, dim3(kBlock), 0, stream, static_cast<const double*>(v), vi, (int)F, V, vi_sN, (int)H, (int)W, packed);
+      DRTK_LAUNCH((rasterize_lines_kernel<double>), grid, dim3(kBlock), 0, stream, static_cast<const double*>(v), vi, (int)F, V, vi_sN, (int)H, (int)W, packed);
     }
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
-  hipLaunchKernelGGL(unpack_lines_kernel, dim3(static_cast<unsigned>(ceil_div(count, kBlock))), dim3(kBlock), 0, stream, packed, count, depth_img, index_img);
+  DRTK_LAUNCH(unpack_lines_kernel, dim3(static_cast<unsigned>(ceil_div(count, kBlock))), dim3(kBlock), 0, stream, packed, count, depth_img, index_img);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }

@@ -300,10 +300,10 @@ int render_impl(
       (reinterpret_cast<uintptr_t>(bary_img) % (4 * sizeof(T)) == 0);
   if (vec) {
     dim3 grid(static_cast<unsigned>(ceil_div(HW / 4, kBlock)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((render_kernel<T, 4>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img, xcd_strip(ceil_div(16 * W, kBlock * 4)));
+    DRTK_LAUNCH((render_kernel<T, 4>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img, xcd_strip(ceil_div(16 * W, kBlock * 4)));
   } else {
     dim3 grid(static_cast<unsigned>(ceil_div(HW, kBlock)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((render_kernel<T, 1>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img, xcd_strip(ceil_div(16 * W, kBlock)));
+    DRTK_LAUNCH((render_kernel<T, 1>), grid, dim3(kBlock), 0, stream, v, vi, index_img, V, vi_sN, (int)H, (int)W, depth_img, bary_img, xcd_strip(ceil_div(16 * W, kBlock)));
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
@@ -321,7 +321,7 @@ int render_backward_impl(
   if (N * HW == 0) return DRTK_OK;
   const int tiles_x = static_cast<int>(ceil_div(W, kWave)), tiles_y = static_cast<int>(ceil_div(H, kTileRows));
   dim3 grid(static_cast<unsigned>(int64_t(tiles_x) * tiles_y), static_cast<unsigned>(N));
-  hipLaunchKernelGGL((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, tiles_x, grad_v, xcd_strip(int64_t(tiles_x) * (16 / kTileRows)));
+  DRTK_LAUNCH((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, tiles_x, grad_v, xcd_strip(int64_t(tiles_x) * (16 / kTileRows)));
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }

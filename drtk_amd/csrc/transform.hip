@@ -109,7 +109,7 @@ int transform_impl(const T* v, int64_t v_sN, const T* campos, const T* camrot, c
                    int64_t N, int64_t V, T* v_pix, T* v_cam, hipStream_t stream) {
   if (N * V == 0) return DRTK_OK;
   const dim3 grid(static_cast<unsigned>(ceil_div(V, kBlock)), static_cast<unsigned>(N));
-  hipLaunchKernelGGL((transform_kernel<T>), grid, dim3(kBlock), 0, stream, v, v_sN, campos, camrot, focal, princpt, (int)V, v_pix, v_cam);
+  DRTK_LAUNCH((transform_kernel<T>), grid, dim3(kBlock), 0, stream, v, v_sN, campos, camrot, focal, princpt, (int)V, v_pix, v_cam);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }
@@ -120,10 +120,10 @@ int transform_backward_impl(const T* v, int64_t v_sN, const T* campos, const T* 
   if (V == 0 || N == 0) return DRTK_OK;
   if (v_sN == 0) {
     const dim3 grid(static_cast<unsigned>(ceil_div(V, kBlock)), 1);
-    hipLaunchKernelGGL((transform_backward_kernel<T, true>), grid, dim3(kBlock), 0, stream, v, campos, camrot, focal, princpt, grad_v_pix, (int)N, (int)V, grad_v);
+    DRTK_LAUNCH((transform_backward_kernel<T, true>), grid, dim3(kBlock), 0, stream, v, campos, camrot, focal, princpt, grad_v_pix, (int)N, (int)V, grad_v);
   } else {
     const dim3 grid(static_cast<unsigned>(ceil_div(V, kBlock)), static_cast<unsigned>(N));
-    hipLaunchKernelGGL((transform_backward_kernel<T, false>), grid, dim3(kBlock), 0, stream, v, campos, camrot, focal, princpt, grad_v_pix, (int)N, (int)V, grad_v);
+    DRTK_LAUNCH((transform_backward_kernel<T, false>), grid, dim3(kBlock), 0, stream, v, campos, camrot, focal, princpt, grad_v_pix, (int)N, (int)V, grad_v);
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;

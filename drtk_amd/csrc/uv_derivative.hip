@@ -119,13 +119,13 @@ extern "C" int drtk_amd_screen_space_uv_derivative(
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N));
   if (dtype == DRTK_F32) {
-    hipLaunchKernelGGL(
+    DRTK_LAUNCH(
         (uv_derivative_kernel<float>), grid, dim3(kBlock), 0, s, static_cast<const float*>(v), v_sN,
         static_cast<const float*>(vt), vt_sN, vi, vti, index_img, static_cast<const float*>(bary_img), mask,
         static_cast<const float*>(campos), static_cast<const float*>(camrot), static_cast<const float*>(focal), H * W,
         static_cast<float*>(out), xcd_strip(ceil_div(16 * W, kBlock)));
   } else {
-    hipLaunchKernelGGL(
+    DRTK_LAUNCH(
         (uv_derivative_kernel<double>), grid, dim3(kBlock), 0, s, static_cast<const double*>(v), v_sN,
         static_cast<const double*>(vt), vt_sN, vi, vti, index_img, static_cast<const double*>(bary_img), mask,
         static_cast<const double*>(campos), static_cast<const double*>(camrot), static_cast<const double*>(focal),

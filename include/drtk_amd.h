@@ -269,6 +269,17 @@ int drtk_amd_transform_pinhole_backward(
 int drtk_amd_selftest_exact_div(
     drtk_dtype_t dtype, uint64_t seed, int64_t count, uint64_t* d_mismatches, drtk_stream_t stream);
 
+/* Per-kernel timing for benchmarks (bench.py's `roofline`): between _begin and _report every kernel the library
+ * launches -- from any entry point above, on any stream -- is bracketed by a pair of HIP events recorded on the
+ * stream it is launched on.  Results are unaffected; outside a collection a launch pays one atomic load.  Do not
+ * open a collection while a stream is being captured into a graph (event records would become graph nodes).
+ * _report closes the collection, waits for the recorded events and writes one line per launch site in order of
+ * first launch, "<kernel as spelled at the launch site>\t<launches>\t<total milliseconds>\n", NUL-terminated, into
+ * buf[0..capacity); *needed (optional) receives the size the whole report takes, and a report that did not fit
+ * returns DRTK_ERR_WORKSPACE_TOO_SMALL.  Process-global, serialised by a mutex. */
+int drtk_amd_kernel_timing_begin(void);
+int drtk_amd_kernel_timing_report(char* buf, size_t capacity, size_t* needed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,12 +64,40 @@ def _worker(rank, world, port, out_dir):
     v_world = v_world.clone().requires_grad_(True)
     attr = attr.clone().requires_grad_(True)
     views = ddist.shard_views(N, rank, world)
-    loss = _local_step(make_ops(OracleBackend(1)), v_world, attr, vi, cams, views, H, W)
+    ops = make_ops(OracleBackend(1))
+    out = {"views": list(views)}
+    # (a) overlapped: hooks launch each segment's all-reduce as its gradient becomes final; (b) everything after the
+    # backward pass in one call; (c) overlapped, with `.grad` replaced behind the reducer's back (set_to_none) and a
+    # second step on the same reducer
+    for tag, overlap in (("", True), ("_late", False)):
+        red = ddist.SharedGradReducer([v_world, attr], overlap=overlap)
+        assert red.nbytes() == 4 * (v_world.numel() + attr.numel())
+        assert v_world.grad.data_ptr() == red.flat.data_ptr()
+        order = []
+        if overlap:
+            launch = red._launch
+            red._launch = lambda i, launch=launch, order=order: (order.append(i), launch(i))[1]
+        loss = _local_step(ops, v_world, attr, vi, cams, views, H, W)
+        if overlap:
+            assert order[:2] == [1, 0], order  # attributes first (final after interpolate backward), vertices last
+            assert set(red._pending) == {0, 1}  # both collectives were launched from inside the backward pass
+        else:
+            assert not red._pending
+        red.finish()
+        out.update({"v" + tag: v_world.grad.clone(), "a" + tag: attr.grad.clone(), "loss": loss})
+        for h in red._handles:
+            h.remove()
     red = ddist.SharedGradReducer([v_world, attr])
-    assert red.nbytes() == 4 * (v_world.numel() + attr.numel())
-    red.all_reduce()
+    for step in range(2):
+        if step == 0:
+            red.zero_grad()
+        else:
+            v_world.grad, attr.grad = None, None  # as optimizer.zero_grad(set_to_none=True) would
+        _local_step(ops, v_world, attr, vi, cams, views, H, W)
+        red.all_reduce()
+        out.update({f"v_step{step}": v_world.grad.clone(), f"a_step{step}": attr.grad.clone()})
     ddist.barrier_and_sync()
-    th.save({"v": v_world.grad, "a": attr.grad, "loss": loss, "views": list(views)}, os.path.join(out_dir, f"r{rank}.pt"))
+    th.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     th.distributed.destroy_process_group()
 
 
@@ -94,6 +122,10 @@ def test_two_ranks_match_single_process(tmp_path):
     assert res[0]["views"] == [0, 1] and res[1]["views"] == [2, 3]
     # every rank ends up with the same, summed gradients
     assert th.equal(res[0]["v"], res[1]["v"]) and th.equal(res[0]["a"], res[1]["a"])
+    # overlapped == reduced after the backward pass == a later step on a reducer whose .grad views had been dropped
+    for r in res:
+        for k in ("v", "a"):
+            assert th.equal(r[k], r[k + "_late"]) and th.equal(r[k], r[k + "_step0"]) and th.equal(r[k], r[k + "_step1"]), k
 
     th.set_num_threads(1)
     N, H, W, C, v_world, vi, cams, attr = _scene()

@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--mesh", "10k", "--res", "512", "--views", "2", "--channels", "3", "--steps", "3", "--warmup", "1", "--kernel-reps", "2"]
+SMALL = ["--mesh", "10k", "--res", "512", "--views", "2", "--channels", "3", "--steps", "3", "--warmup", "1", "--kernel-steps", "2"]
 TOP = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
        "dtype", "data", "config", "roofline", "cpu_baseline"}
 
@@ -30,7 +30,7 @@ def _free_port():
 def _run(cmd, extra_env=None):
     env = dict(os.environ)
     env.update(extra_env or {})
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert r.returncode == 0, f"{' '.join(cmd)} exited {r.returncode}\n{r.stderr[-3000:]}"
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}:\n{r.stdout[-2000:]}"
@@ -47,9 +47,21 @@ def _check_common(d, n_gpus):
     px = n_gpus * d["config"]["views_per_gpu"] * d["config"]["height"] * d["config"]["width"]
     assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
     rf = d["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf)
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "frac_traffic"} <= set(rf)
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+    # ONE HIP kernel is priced: the one with the largest per-launch time among the kernels that stream per-pixel tensors
+    ks = d["path_roofline"]["kernels"]
+    priced = {k: r for k, r in ks.items() if r["bytes_per_px"]}
+    assert rf["kernel"] == max(priced, key=lambda k: priced[k]["ms_per_launch"]) and rf["ms_per_launch"] == priced[rf["kernel"]]["ms_per_launch"]
+    P = d["config"]["views_per_gpu"] * d["config"]["height"] * d["config"]["width"]
+    assert rf["algorithmic_bytes"] == rf["bytes_per_px"] * P
+    assert abs(rf["achieved"] - rf["algorithmic_bytes"] / (rf["ms_per_launch"] * 1e-3) / 1e9) < 1.0
+    # every library kernel of the step was timed, each at least once per step, and their sum is t_ops
+    for k in ("tile_raster_kernel", "render_kernel", "interpolate_kernel", "edge_dots_kernel", "edge_scatter_pairs_kernel", "render_backward_kernel"):
+        assert k in ks and ks[k]["launches_per_step"] >= 1 and ks[k]["ms_per_step"] > 0, k
+    assert abs(d["path_roofline"]["t_ops_ms"] - sum(r["ms_per_step"] for r in ks.values() if r["op"] != "outside the four ops")) < 1e-2
+    assert d["path_roofline"]["t_ops_ms"] < d["ms_per_step"] * 1.05
 
 
 def test_single_process_line_carries_roofline_and_cpu_baseline():
@@ -58,6 +70,30 @@ def test_single_process_line_carries_roofline_and_cpu_baseline():
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb)
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mpix/s"
+    # the captured-graph replay of the same step is reported beside the eager headline, with the same loss
+    g = d["graph_step"]
+    assert "error" not in g, g
+    assert g["ms_per_step"] > 0 and abs(g["loss"] - d["loss"]) <= 1e-5 * max(1.0, abs(d["loss"]))
+
+
+def test_gpus_flag_must_match_the_process_group():
+    """`python bench.py --gpus 4` without a launcher used to run on ONE GPU and label the line n_gpus = 1 under the
+    multi-GPU metric: now it refuses and prints the launch line (it must not spawn or re-exec ranks itself)."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", *SMALL], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0 and "torch.distributed.run" in r.stderr and "--nproc-per-node 4" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_textured_workload_line():
+    """`--workload textured` (BASELINE configs[4] in small): same contract, its own metric string, fp16-stored leaves."""
+    d = _run([sys.executable, "bench.py", "--workload", "textured", "--mesh", "10k", "--res", "512", "--tex", "512", "--views", "2",
+              "--steps", "3", "--warmup", "1", "--kernel-steps", "2", "--cpu-sample-views", "1"])
+    assert TOP <= set(d) and "textured" in d["metric"] and "fp16" in d["config"]["workload"]
+    ks = d["path_roofline"]["kernels"]
+    for k in ("uv_derivative_kernel", "mipmap_forward_kernel", "mipmap_backward_tiled_kernel", "tile_raster_kernel", "edge_dots_kernel"):
+        assert k in ks and ks[k]["ms_per_step"] > 0, k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert "error" not in d["graph_step"]
 
 
 def test_two_ranks_under_torch_distributed_run():
@@ -66,4 +102,7 @@ def test_two_ranks_under_torch_distributed_run():
     d = _run(cmd, {"DRTK_DIST_BACKEND": "gloo", "DRTK_FORCE_DEVICE": "0"})
     _check_common(d, 2)
     assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
-    assert "sharded 2-way" in d["config"]["parallelism"] and "all-reduce" in d["config"]["parallelism"]
+    assert "sharded 2-way" in d["config"]["parallelism"] and "all-reduced" in d["config"]["parallelism"]
+    ar = d["all_reduce"]
+    assert ar["bytes"] == 4 * d["config"]["vertices"] * (3 + d["config"]["channels"]) and ar["collectives_per_step"] == 2
+    assert ar["ms_launch_to_done"] > 0 and ar["ms_exposed_on_main_stream"] >= 0
