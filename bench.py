@@ -350,6 +350,8 @@ def main():
     leaves = [p for r in reducers for p in r.params]
 
     def step(fused_mask=False, reduce=True):
+        for r in reducers:
+            r.enabled = reduce  # off: this rank steps alone (no collective may be entered, not even from a gradient hook)
         if reduce:
             for r in reducers:
                 r.zero_grad()

@@ -151,7 +151,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backward_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ grad_depth_img, const T* __restrict__ grad_bary_img, int64_t V,
-    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ grad_v, int strip) {
+    int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ grad_v, int strip, int dbg) {
   constexpr int kWaves = kBlock / kWave;
   __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
   __shared__ int32_t s_vid[kWaves][3 * kRunPad];
@@ -208,7 +208,11 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backwar
     for (int j = 0; j < 9; ++j) g[j] = T(0);
     int32_t vid[3] = {0, 0, 0};
 
-    if (tr != -1) {
+    if (tr != -1 && DRTK_DBG(dbg, 4)) {
+      vid[0] = cur[0], vid[1] = cur[1], vid[2] = cur[2];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) g[j] = T(1);
+    } else if (tr != -1) {
       RenderPix<T> r;
       render_pix<T, false>(v_n, cur[0], cur[1], cur[2], x, y, r);
       vid[0] = r.vi0;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backwar
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       s_vid[wave][k * kRunPad + lane] = vid[k];
-      s_slot[wave][k * kRunPad + lane] = (tr != -1 && !dup) ? table_slot(t_keys[wave], vid[k]) : -1;
+      s_slot[wave][k * kRunPad + lane] = DRTK_DBG(dbg, 2) ? (lane & 31) : (tr != -1 && !dup) ? table_slot(t_keys[wave], vid[k]) : -1;
     }
     if (pass + 1 < kTileRows / kWaves) {
       vn[0] = vn[1] = vn[2] = 0;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backwar
     unsigned long long heads, cov;
     run_masks(tr, heads, cov);
     wave_lds_sync();
-    if (cov != 0) {
+    if (cov != 0 && !DRTK_DBG(dbg, 1)) {
       const T* sv = s_val[wave];
       scatter_runs<T>(
           heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals[wave], 4, grad_v_n, 3, 0,
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backwar
             using V4 = typename Vec4<T>::type;
             const V4 q = *reinterpret_cast<const V4*>(sv + (k * 3 + c) * kRunPad + 4 * g4);
             x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
-          });
+          }, dbg);
     }
     wave_lds_sync();
   }
@@ -321,7 +325,7 @@ int render_backward_impl(
   if (N * HW == 0) return DRTK_OK;
   const int tiles_x = static_cast<int>(ceil_div(W, kWave)), tiles_y = static_cast<int>(ceil_div(H, kTileRows));
   dim3 grid(static_cast<unsigned>(int64_t(tiles_x) * tiles_y), static_cast<unsigned>(N));
-  DRTK_LAUNCH((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, tiles_x, grad_v, xcd_strip(int64_t(tiles_x) * (16 / kTileRows)));
+  DRTK_LAUNCH((render_backward_kernel<T>), grid, dim3(kBlock), 0, stream, v, vi, index_img, grad_depth_img, grad_bary_img, V, vi_sN, (int)H, (int)W, tiles_x, grad_v, xcd_strip(int64_t(tiles_x) * (16 / kTileRows)), debug_flags());
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }

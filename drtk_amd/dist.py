@@ -86,6 +86,7 @@ class SharedGradReducer:
         self._handles = []
         self._finished = False
         self._wait_events = None
+        self.enabled = True  # False: hooks and finish() do nothing (a rank stepping on its own, e.g. for profiling)
         if overlap:
             for i, p in enumerate(self.params):
                 self._handles.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._launch(i)))
@@ -95,7 +96,7 @@ class SharedGradReducer:
         return self.flat.numel() * self.flat.element_size()
 
     def _active(self) -> bool:
-        return dist.is_initialized() and dist.get_world_size() > 1
+        return self.enabled and dist.is_initialized() and dist.get_world_size() > 1
 
     def zero_grad(self) -> None:
         """Zero the flat buffer and (re-)attach every `.grad` as a view of its segment."""
