@@ -534,16 +534,12 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
     const T* __restrict__ v_pix, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ bary_img, const T* __restrict__ gdx, const T* __restrict__ gdy, int64_t V, int64_t vi_sN,
     int H, int W, int strips_x, T M, T* __restrict__ grad_v_pix, int strip) {
-  using V4 = typename Vec4<T>::type;
   constexpr int kWaves = kBlock / kWave;
   constexpr int kRows = 4;
   constexpr int kCap = kWave * 4 * 2 * 2; // pairs of two rows, both axes: the most one list build can hold
   __shared__ uint16_t s_list[kWaves][kCap];
-  __shared__ __attribute__((aligned(16))) T s_val[kWaves][12 * kRunPad];
-  __shared__ int32_t s_vid[kWaves][6 * kRunPad];
-  __shared__ int32_t s_slot[kWaves][6 * kRunPad];
   __shared__ int32_t t_keys[kWaves][kTableSlots];
-  __shared__ T t_vals[kWaves][kTableSlots * 4];
+  __shared__ TableAcc t_vals[kWaves][kTableSlots * 4];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -563,7 +559,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
   T* grad_n = grad_v_pix + int64_t(n) * V * 3;
 
   table_init(t_keys[wave]);
-  for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = T(0);
+  for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = 0;
 
   // index rows y_base .. y_base+kRows of this lane's 4 pixels, one batch
   int32_t row[kRows + 1][4];
@@ -678,42 +674,33 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
         // a side takes part if its pixel is foreground and it received something
         const bool a_on = ia >= 0 && (ga != T(0) || za != T(0));
         const bool b_on = ib >= 0 && (gb != T(0) || zb != T(0));
-        const bool a_tab = a_on && va[0] != va[1] && va[0] != va[2] && va[1] != va[2];
-        const bool b_tab = b_on && vb[0] != vb[1] && vb[0] != vb[2] && vb[1] != vb[2];
-        // staging rows: corner slot ks = 0..2 (A's vertices), 3..5 (B's); two components per corner:
-        // c = 0 the pair's axis (x or y), c = 1 z
+        // twelve terms per pair: corner slots A0..A2, B0..B2, two components each -- the pair's axis (x or y) and z
+        T g[12];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          s_val[wave][(k * 2 + 0) * kRunPad + lane] = a_on ? ga * Ba[k] : T(0);
-          s_val[wave][(k * 2 + 1) * kRunPad + lane] = a_on ? za * Ba[k] : T(0);
-          s_val[wave][((3 + k) * 2 + 0) * kRunPad + lane] = b_on ? gb * Bb[k] : T(0);
-          s_val[wave][((3 + k) * 2 + 1) * kRunPad + lane] = b_on ? zb * Bb[k] : T(0);
-          s_vid[wave][k * kRunPad + lane] = va[k];
-          s_vid[wave][(3 + k) * kRunPad + lane] = vb[k];
-          s_slot[wave][k * kRunPad + lane] = a_on ? (a_tab ? table_slot(t_keys[wave], va[k]) : -1) : -2;
-          s_slot[wave][(3 + k) * kRunPad + lane] = b_on ? (b_tab ? table_slot(t_keys[wave], vb[k]) : -1) : -2;
+          g[2 * k + 0] = a_on ? ga * Ba[k] : T(0);
+          g[2 * k + 1] = a_on ? za * Ba[k] : T(0);
+          g[6 + 2 * k + 0] = b_on ? gb * Bb[k] : T(0);
+          g[6 + 2 * k + 1] = b_on ? zb * Bb[k] : T(0);
         }
-        // a run = consecutive lanes with the same two triangles and the same participation
+        // a run = consecutive lanes with the same two triangles and the same participation; its sums end up in its
+        // last lane (segscatter.hpp: run_sums_rows16), which alone touches the vertex table
         const int32_t key_a = a_on ? ia : -1, key_b = b_on ? ib : -1;
-        const int32_t prev_a = __shfl_up(key_a, 1), prev_b = __shfl_up(key_b, 1);
-        const unsigned long long heads = __ballot(lane == 0 || key_a != prev_a || key_b != prev_b);
-        const unsigned long long cov = __ballot(a_on || b_on);
-        wave_lds_sync();
-        if (cov != 0) {
-          const T* sv = s_val[wave];
+        int dist;
+        bool tail;
+        const int32_t left_a = __shfl_up(key_a, 1), left_b = __shfl_up(key_b, 1); // both BEFORE the ||: a shuffle under a
+        run_rows16_heads(key_a != left_a || key_b != left_b, dist, tail);           // short-circuit runs with lanes switched off
+        if (__ballot(a_on || b_on) != 0) {
+          run_sums_rows16<T, 12>(g, dist);
           // components {axis, z}: x,z = 0 + c*2 ; y,z = 1 + c*1
-          scatter_runs<T>(
-              heads, cov, s_slot[wave], s_vid[wave], 12, 2, t_vals[wave], 4, grad_n, 3, 0,
-              [sv](int k, int cc, int g4, T* x) {
-                const V4 q = *reinterpret_cast<const V4*>(sv + (k * 2 + cc) * kRunPad + 4 * g4);
-                x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
-              },
-              0, axis == 0 ? 0 : 1, axis == 0 ? 2 : 1);
+          const int c_off = axis == 0 ? 0 : 1, c_step = axis == 0 ? 2 : 1;
+          if (tail && a_on) table_add<T, 3, 2>(t_keys[wave], t_vals[wave], 4, va, g, grad_n, 3, c_off, c_step);
+          if (tail && b_on) table_add<T, 3, 2>(t_keys[wave], t_vals[wave], 4, vb, g + 6, grad_n, 3, c_off, c_step);
         }
-        wave_lds_sync();
       }
     }
   }
+  wave_lds_sync();
   table_flush<T>(t_keys[wave], t_vals[wave], 4, 3, grad_n, 3, 0);
 }
 

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void normal_matrix_values_kernel(
   if (cov == 0) return;
   const T* sv = s_val[wave];
   scatter_runs<T>(
-      heads, cov, nullptr, s_dst[wave], 9, 1, static_cast<T*>(nullptr), 0, values, 1, 0,
+      heads, cov, nullptr, s_dst[wave], 9, 1, static_cast<TableAcc*>(nullptr), 0, values, 1, 0,
       [sv](int k, int, int g4, T* x) {
         const V4 q = *reinterpret_cast<const V4*>(sv + k * kRunPad + 4 * g4);
         x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;

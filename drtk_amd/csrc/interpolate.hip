@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   __shared__ int32_t s_vid[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
   __shared__ int32_t s_slot[HAS_VERT ? kWaves : 1][HAS_VERT ? 3 * kRunPad : 1];
   __shared__ int32_t t_keys[TABLE ? kWaves : 1][TABLE ? kTableSlots : 1];
-  __shared__ T t_vals[TABLE ? kWaves : 1][TABLE ? kTableSlots * CHUNK : 1];
+  __shared__ TableAcc t_vals[TABLE ? kWaves : 1][TABLE ? kTableSlots * CHUNK : 1];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
     const int CC = min(CHUNK, C - c0);
     if constexpr (TABLE) {
       wave_lds_sync(); // previous chunk flushed, keys initialised
-      for (int i = lane; i < kTableSlots * CHUNK; i += kWave) t_vals[wave][i] = T(0);
+      for (int i = lane; i < kTableSlots * CHUNK; i += kWave) t_vals[wave][i] = 0;
       wave_lds_sync();
     }
     // software pipeline over the 4 row passes: the index of pass p+1 is requested at the top of
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
         const T* sg = s_g[wave];
         const T* sb = s_b[wave];
         scatter_runs<T>(
-            heads, cov, nullptr, s_vid[wave], 3 * CH, CH, static_cast<T*>(nullptr), 0, attr_grad_n, C, c0,
+            heads, cov, nullptr, s_vid[wave], 3 * CH, CH, static_cast<TableAcc*>(nullptr), 0, attr_grad_n, C, c0,
             [sg, sb](int k, int c, int g4, T* xv) {
               const V4 a = *reinterpret_cast<const V4*>(sg + c * kRunPad + 4 * g4);
               const V4 b = *reinterpret_cast<const V4*>(sb + k * kRunPad + 4 * g4);

@@ -146,18 +146,18 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
   }
 }
 
-// Backward: a workgroup owns a 64 x 16 pixel tile; each of its 4 waves walks 4 adjacent rows of 64 pixels.
+// Backward: a workgroup owns a 64 x 16 pixel tile; each of its 4 waves walks 4 adjacent rows of 64 pixels.  Lane = pixel:
+// the nine per-pixel terms stay in registers, a segmented scan over the 16-lane rows leaves each run's sums in its
+// last lane (segscatter.hpp: run_sums_rows16), and only those lanes update the wave's vertex table -- so every vertex
+// costs one global atomic per component per 64 x 4 pixel tile.  No LDS staging, no barrier inside the loop.
 template <typename T>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backward_kernel(
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) void render_backward_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ grad_depth_img, const T* __restrict__ grad_bary_img, int64_t V,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ grad_v, int strip, int dbg) {
   constexpr int kWaves = kBlock / kWave;
-  __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
-  __shared__ int32_t s_vid[kWaves][3 * kRunPad];
-  __shared__ int32_t s_slot[kWaves][3 * kRunPad];
   __shared__ int32_t t_keys[kWaves][kTableSlots];
-  __shared__ T t_vals[kWaves][kTableSlots * 4];
+  __shared__ TableAcc t_vals[kWaves][kTableSlots * 4];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -171,21 +171,25 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backwar
   T* grad_v_n = grad_v + int64_t(n) * V * 3;
 
   table_init(t_keys[wave]);
-  for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = T(0);
+  for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = 0;
   wave_lds_sync();
 
   // software pipeline over the 4 rows: index of row p+1 is requested at the top of row p, its
-  // triangle's vertex ids before phase 2 -- both dependent gathers fly under the current row.
+  // triangle's vertex ids before the reduction -- both dependent gathers fly under the current row.
   auto load_tr = [&](int pass) -> int32_t {
     const int yy = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
     return (x < W && yy < H) ? index_img[int64_t(n) * HW + int64_t(yy) * W + x] : -1;
   };
+  auto load_face = [&](int32_t t, int32_t (&f)[3]) {
+    f[0] = f[1] = f[2] = 0;
+    if (t != -1) {
+      const int32_t* face = vi_n + int64_t(t) * 3;
+      f[0] = face[0], f[1] = face[1], f[2] = face[2];
+    }
+  };
   int32_t tr_next = load_tr(0);
-  int32_t vn[3] = {0, 0, 0};
-  if (tr_next != -1) {
-    const int32_t* face = vi_n + int64_t(tr_next) * 3;
-    vn[0] = face[0], vn[1] = face[1], vn[2] = face[2];
-  }
+  int32_t vn[3];
+  load_face(tr_next, vn);
 #pragma unroll 1
   for (int pass = 0; pass < kTileRows / kWaves; ++pass) {
     const int y = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
@@ -194,30 +198,19 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backwar
     const int32_t cur[3] = {vn[0], vn[1], vn[2]};
     if (pass + 1 < kTileRows / kWaves) tr_next = load_tr(pass + 1);
     if (__ballot(tr != -1) == 0) { // whole row segment is background: nothing to do but keep the pipeline fed
-      if (pass + 1 < kTileRows / kWaves) {
-        vn[0] = vn[1] = vn[2] = 0;
-        if (tr_next != -1) {
-          const int32_t* face = vi_n + int64_t(tr_next) * 3;
-          vn[0] = face[0], vn[1] = face[1], vn[2] = face[2];
-        }
-      }
+      if (pass + 1 < kTileRows / kWaves) load_face(tr_next, vn);
       continue;
     }
     T g[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) g[j] = T(0);
-    int32_t vid[3] = {0, 0, 0};
 
     if (tr != -1 && DRTK_DBG(dbg, 4)) {
-      vid[0] = cur[0], vid[1] = cur[1], vid[2] = cur[2];
 #pragma unroll
       for (int j = 0; j < 9; ++j) g[j] = T(1);
     } else if (tr != -1) {
       RenderPix<T> r;
       render_pix<T, false>(v_n, cur[0], cur[1], cur[2], x, y, r);
-      vid[0] = r.vi0;
-      vid[1] = r.vi1;
-      vid[2] = r.vi2;
       const bool den_clamped = r.den != r.den_raw;
       const bool dinv_clamped = r.depth_inverse_eps != r.depth_inverse;
 
@@ -259,37 +252,19 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 6 : 4) void render_backwar
       g[6] = dL_v02x;
       g[7] = dL_v02y;
     }
+    if (pass + 1 < kTileRows / kWaves) load_face(tr_next, vn);
 
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s_val[wave][j * kRunPad + lane] = g[j];
-    const bool dup = vid[0] == vid[1] || vid[0] == vid[2] || vid[1] == vid[2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      s_vid[wave][k * kRunPad + lane] = vid[k];
-      s_slot[wave][k * kRunPad + lane] = DRTK_DBG(dbg, 2) ? (lane & 31) : (tr != -1 && !dup) ? table_slot(t_keys[wave], vid[k]) : -1;
-    }
-    if (pass + 1 < kTileRows / kWaves) {
-      vn[0] = vn[1] = vn[2] = 0;
-      if (tr_next != -1) {
-        const int32_t* face = vi_n + int64_t(tr_next) * 3;
-        vn[0] = face[0], vn[1] = face[1], vn[2] = face[2];
+    int dist;
+    bool tail;
+    run_rows16(tr, dist, tail);
+    if (!DRTK_DBG(dbg, 1)) {
+      run_sums_rows16<T, 9>(g, dist);
+      if (tail && tr != -1 && !DRTK_DBG(dbg, 32)) {
+        table_add<T, 3, 3>(t_keys[wave], t_vals[wave], 4, cur, g, grad_v_n, 3);
       }
     }
-    unsigned long long heads, cov;
-    run_masks(tr, heads, cov);
-    wave_lds_sync();
-    if (cov != 0 && !DRTK_DBG(dbg, 1)) {
-      const T* sv = s_val[wave];
-      scatter_runs<T>(
-          heads, cov, s_slot[wave], s_vid[wave], 9, 3, t_vals[wave], 4, grad_v_n, 3, 0,
-          [sv](int k, int c, int g4, T* x) {
-            using V4 = typename Vec4<T>::type;
-            const V4 q = *reinterpret_cast<const V4*>(sv + (k * 3 + c) * kRunPad + 4 * g4);
-            x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
-          }, dbg);
-    }
-    wave_lds_sync();
   }
+  wave_lds_sync();
   table_flush<T>(t_keys[wave], t_vals[wave], 4, 3, grad_v_n, 3, 0);
 }
 

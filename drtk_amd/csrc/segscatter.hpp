@@ -80,13 +80,20 @@ __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
   __hip_atomic_fetch_add((LdsPtr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// The vertex tables accumulate in DOUBLE whatever T is.  Measured on MI355X (profiles/micro/lds_atomics.hip, every CU
+// busy): ds_add_f32 retires 0.33 lanes per clock per CU -- three clocks per LANE, with or without return, distinct
+// addresses or not -- while ds_add_f64 retires 6.9 (ds_add_u32: 11; a plain read-add-write: 6.9).  The f32 atomic was
+// the floor of every C <= 4 scatter (render backward: 0.08 of 0.26 ms; edge_scatter_pairs: most of its 0.29 ms).  A
+// double accumulator costs 8 instead of 4 bytes of LDS per entry and rounds once, at the flush, instead of at every add.
+using TableAcc = double;
+
 template <typename T, typename Val4Fn>
 __device__ __forceinline__ void scatter_runs(
     unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
-    int CC, T* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0,
+    int CC, TableAcc* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0,
     int c_off = 0, int c_step = 1) {
   const int lane = lane_id();
-  using LdsPtr = __attribute__((address_space(3))) T*;
+  using LdsPtr = __attribute__((address_space(3))) TableAcc*;
   // `exclusive`: no two lanes of one call target the same table entry (one run at a time, and the
   // three corners of a triangle are distinct vertices -- phase 1 sends triangles with repeated
   // vertex ids to the global fallback), so a plain read-modify-write is race free.
@@ -100,9 +107,9 @@ __device__ __forceinline__ void scatter_runs(
     if (s >= 0) {
       if (exclusive) {
         LdsPtr q = (LdsPtr)(vals + s * stride + c);
-        *q = *q + acc;
+        *q = *q + static_cast<TableAcc>(acc);
       } else {
-        lds_atomic_add(vals + s * stride + c, acc);
+        lds_atomic_add(vals + s * stride + c, static_cast<TableAcc>(acc));
       }
     }
     if (s < 0) { // table full for this vertex: direct global atomic (rare)
@@ -182,13 +189,13 @@ __device__ __forceinline__ void scatter_runs(
 // Wave-wide: add every occupied entry of the wave's table to dst_n[key * C_total + c_base + c], c < CC.
 template <typename T>
 __device__ __forceinline__ void table_flush(
-    const int32_t* keys, const T* vals, int stride, int CC, T* __restrict__ dst_n, int C_total,
+    const int32_t* keys, const TableAcc* vals, int stride, int CC, T* __restrict__ dst_n, int C_total,
     int c_base) {
   for (int e = lane_id(); e < kTableSlots * CC; e += kWave) {
     const int s = e / CC, c = e - s * CC;
     const int32_t key = keys[s];
     if (key >= 0) {
-      const T x = vals[s * stride + c];
+      const T x = static_cast<T>(vals[s * stride + c]);
       if (x != T(0)) atomic_add_global(dst_n + int64_t(key) * C_total + c_base + c, x);
     }
   }
@@ -201,6 +208,97 @@ __device__ __forceinline__ void run_masks(int32_t tr, unsigned long long& heads,
   const int32_t prev = __shfl_up(tr, 1);
   heads = __ballot(lane == 0 || tr != prev);
   cov = __ballot(tr != -1);
+}
+
+// ---- run reduction in registers (C <= 4 scatters: render backward, the v_pix routes) ---------------------------------
+// A wave holds one pixel per lane and J values per pixel; pixels of one triangle that are adjacent in the row form a
+// run, and what the vertex table needs is the SUM of each value over each run.  Instead of staging the values in LDS
+// and flipping the wave to (corner, channel) lanes (scatter_runs above), the sums are formed where the values are: a
+// segmented Hillis-Steele scan over the 16-lane DPP rows -- four steps of `x += row_shr:d(x)` gated by "lane - d is
+// still in my run" -- leaves every run's total in its last lane, and only those tail lanes touch the table.  Runs are
+// cut at the DPP row boundaries (lanes 0, 16, 32, 48 always start a run): a row-crossing run is flushed in pieces,
+// which the table merges again.  Per 64 pixels: 3 J VALU per step and J table updates, no LDS staging, no barrier.
+template <int D>
+__device__ __forceinline__ float dpp_row_shr(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 | D, 0xF, 0xF, true));
+}
+template <int D>
+__device__ __forceinline__ double dpp_row_shr(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(u & 0xFFFFFFFFull), 0x110 | D, 0xF, 0xF, true);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(u >> 32), 0x110 | D, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// Run structure of a wave whose lane l holds triangle id `tr` of pixel l (-1 = background / out of range), with runs cut
+// at the 16-lane row boundaries: `dist` = this lane's distance from the first lane of its run (0..15), `tail` = this
+// lane is the last of its run.
+__device__ __forceinline__ void run_rows16_heads(bool differs_from_left, int& dist, bool& tail) {
+  const int lane = lane_id();
+  const unsigned long long heads = __ballot(differs_from_left) | 0x0001000100010001ull;
+  const unsigned long long upto = heads & (~0ull >> (63 - lane)); // heads at or below this lane (bit of the row start is set)
+  dist = lane - (63 - __builtin_clzll(upto));
+  tail = lane == kWave - 1 || ((heads >> (lane + 1)) & 1ull);
+}
+__device__ __forceinline__ void run_rows16(int32_t tr, int& dist, bool& tail) {
+  run_rows16_heads(tr != __shfl_up(tr, 1), dist, tail);
+}
+
+template <typename T, int J>
+__device__ __forceinline__ void run_sums_rows16(T (&g)[J], int dist) {
+#define DRTK_SCAN_STEP(D)                       \
+  {                                             \
+    const bool take = dist >= D;                \
+    _Pragma("unroll") for (int j = 0; j < J; ++j) { \
+      const T t = dpp_row_shr<D>(g[j]);         \
+      g[j] += take ? t : T(0);                  \
+    }                                           \
+  }
+  DRTK_SCAN_STEP(1)
+  DRTK_SCAN_STEP(2)
+  DRTK_SCAN_STEP(4)
+  DRTK_SCAN_STEP(8)
+#undef DRTK_SCAN_STEP
+}
+
+// Tail lanes only: add `CC` components of corner `vid` into the wave's vertex table (LDS atomics: neighbouring
+// triangles share vertices, so two tail lanes of one instruction may hit the same entry), or straight into
+// dst_n[vid * C_total + c] when the table has no room for the vertex.
+// First-probe lookup of K vertices at once: the K hash slots are read in one batch (one LDS round trip instead of K
+// dependent ones); a vertex found there -- the common case after the first pixels of a tile -- is done, the others go
+// through table_slot's probe-and-insert loop.
+template <int K>
+__device__ __forceinline__ void table_slots(int32_t* keys, const int32_t (&vid)[K], int (&slot)[K]) {
+  uint32_t h[K];
+  int32_t cur[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    h[k] = (static_cast<uint32_t>(vid[k]) * 2654435761u) >> 26;
+    cur[k] = keys[h[k]];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) slot[k] = cur[k] == vid[k] ? static_cast<int>(h[k]) : table_slot(keys, vid[k]);
+}
+
+// Tail lanes only: add `CC` components of each of the K corners `vid[k]` (values x[k * CC + c]) into the wave's vertex
+// table (LDS atomics: neighbouring triangles share vertices, so two tail lanes of one instruction may hit the same
+// entry), or straight into dst_n[vid * C_total + c] when the table has no room for the vertex.
+template <typename T, int K, int CC>
+__device__ __forceinline__ void table_add(
+    int32_t* keys, TableAcc* vals, int stride, const int32_t (&vid)[K], const T* x, T* __restrict__ dst_n, int C_total,
+    int c_off = 0, int c_step = 1) { // value c of a corner goes to component c_off + c * c_step of the vertex
+  int slot[K];
+  table_slots<K>(keys, vid, slot);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (slot[k] >= 0) {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) lds_atomic_add(vals + slot[k] * stride + c_off + c * c_step, static_cast<TableAcc>(x[k * CC + c]));
+    } else {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) atomic_add_global(dst_n + int64_t(vid[k]) * C_total + c_off + c * c_step, x[k * CC + c]);
+    }
+  }
 }
 
 } // namespace drtk_amd
