@@ -31,7 +31,7 @@ OPS = os.path.join(PKG, "drtk_amd_torch_ops.so")
 # No fast-math, no FMA contraction: coverage/depth/classification are exact float decisions.
 HIP_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-    "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", f"-I{INC}", f"-I{CSRC}",
+    "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", f"-I{INC}", f"-I{CSRC}",
 ]
 
 

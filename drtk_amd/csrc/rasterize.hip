@@ -27,6 +27,32 @@
 
 #include "common.hpp"
 
+#ifdef DRTK_AMD_ABLATION
+// Phase clocks of the profiling build (this translation unit only: device globals do not link across units without
+// -fgpu-rdc): DRTK_PHASE(i) adds the shader clocks since the calling thread's previous mark to g_phase_clocks[i];
+// drtk_amd_debug_read_phases() copies them out and zeroes them.  Call from ONE thread per workgroup.
+namespace drtk_amd {
+__device__ unsigned long long g_phase_clocks[16];
+}
+extern "C" int drtk_amd_debug_read_phases(unsigned long long* out) {
+  if (hipDeviceSynchronize() != hipSuccess) return DRTK_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(drtk_amd::g_phase_clocks), 16 * sizeof(unsigned long long)) != hipSuccess) return DRTK_ERR_LAUNCH;
+  const unsigned long long zero[16] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(drtk_amd::g_phase_clocks), zero, sizeof(zero)) != hipSuccess) return DRTK_ERR_LAUNCH;
+  return DRTK_OK;
+}
+#define DRTK_PHASE_INIT() unsigned long long drtk_phase_t_ = __builtin_readcyclecounter()
+#define DRTK_PHASE(i)                                                   \
+  do {                                                                  \
+    const unsigned long long now_ = __builtin_readcyclecounter();       \
+    atomicAdd(&::drtk_amd::g_phase_clocks[i], now_ - drtk_phase_t_);    \
+    drtk_phase_t_ = __builtin_readcyclecounter();                       \
+  } while (0)
+#else
+#define DRTK_PHASE_INIT() do { } while (0)
+#define DRTK_PHASE(i) do { } while (0)
+#endif
+
 namespace drtk_amd {
 namespace {
 
@@ -89,6 +115,13 @@ __device__ __forceinline__ T exact_div(T n, T d, T r, bool range_ok) {
   return n / d;
 }
 
+// The two Markstein corrections of exact_div on their own (valid under exact_div's guard, which the caller tests).
+template <typename T>
+__device__ __forceinline__ T markstein2(T n, T d, T r, T q0) {
+  const T q1 = fma_t(fma_t(-d, q0, n), r, q0);
+  return fma_t(fma_t(-d, q1, n), r, q1);
+}
+
 // Correctly rounded 1 / x (float, x normal, result normal): hardware v_rcp_f32 (<= 1 ulp) plus one
 // Markstein correction y' = fma(y, fma(-x, y, 1), y).  The correction is exact-rounding for every
 // faithful y except when x's significand is all ones (classical exception of the reciprocal
@@ -105,6 +138,22 @@ __device__ __forceinline__ float exact_rcp(float x) {
   return 1.0f / x;
 }
 __device__ __forceinline__ double exact_rcp(double x) {
+  return 1.0 / x;
+}
+// exact_rcp's guard and its fast form, separately (the raster loop tests the guard once per pass for the whole wave)
+__device__ __forceinline__ bool fast_rcp_ok(float x) {
+  const uint32_t bits = __float_as_uint(x);
+  const float ax = __uint_as_float(bits & 0x7FFFFFFFu);
+  return ((bits & 0x7FFFFFu) != 0x7FFFFFu) & (ax >= 0x1p-100f) & (ax <= 0x1p100f);
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+  const float y = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(y, __builtin_fmaf(-x, y, 1.0f), y);
+}
+__device__ __forceinline__ bool fast_rcp_ok(double) {
+  return true;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
   return 1.0 / x;
 }
 
@@ -603,6 +652,7 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(
   }
 }
 
+
 // ---- pass 4: per-tile rasterization with the z-buffer in LDS -----------------------------------
 // Wave-uniform plane equations of one triangle (broadcast out of the lane that set it up).
 template <typename T>
@@ -693,17 +743,35 @@ __device__ __forceinline__ void raster_lanes(
         T b0 = ((py - u.ay[0]) * u.dx[0] - ex[0]) * u.s[0];
         T b1 = ((py - u.ay[1]) * u.dx[1] - ex[1]) * u.s[1];
         T b2 = ((py - u.ay[2]) * u.dx[2] - ex[2]) * u.s[2];
-        if (!((b0 >= T(0)) && (b1 >= T(0)) && (b2 >= T(0)))) continue;
-        if ((!(u.tl & 1) && b0 == T(0)) || (!(u.tl & 2) && b1 == T(0)) || (!(u.tl & 4) && b2 == T(0))) continue;
+        // coverage + top-left rule (:133-145) as ONE predicate: inside or on an edge, and not on an edge that is not
+        // top/left (the three rule bits are wave-uniform)
+        const bool inside = (b0 >= T(0)) & (b1 >= T(0)) & (b2 >= T(0));
+        const bool on_excluded_edge = (!(u.tl & 1) & (b0 == T(0))) | (!(u.tl & 2) & (b1 == T(0))) | (!(u.tl & 4) & (b2 == T(0)));
+        if (!inside | on_excluded_edge) continue;
         if (DRTK_DBG(dbg, 4)) {
           atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], id);
           continue;
         }
-        b0 = exact_div(b0, u.abs_denom, u.rdenom, div_ok); // == b0 / abs_denom, rasterize_kernel.cu:148
-        b1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
-        b2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
-        const T depth_inverse = u.dinv0 * b0 + u.dinv1 * b1 + u.dinv2 * b2;
-        const float depth = static_cast<float>(exact_rcp(epsclamp(depth_inverse))); // == 1 / epsclamp(..), :153
+        // b_k / abs_denom (:148), 1 / epsclamp(depth_inverse) (:153): the correctly rounded fast forms are evaluated
+        // unconditionally; whether any lane needs the IEEE fallback (operands outside the guarded range: denormal
+        // quotients, an all-ones significand) is ONE wave-uniform test per pass instead of a divergent branch per
+        // division -- the fallback itself is exact_div / exact_rcp as before
+        const T q0 = b0 * u.rdenom, q1 = b1 * u.rdenom, q2 = b2 * u.rdenom;
+        const bool fast_ok = div_ok & ((q0 >= DivRange<T>::tiny()) | (b0 == T(0))) & ((q1 >= DivRange<T>::tiny()) | (b1 == T(0))) &
+            ((q2 >= DivRange<T>::tiny()) | (b2 == T(0)));
+        T d0 = markstein2(b0, u.abs_denom, u.rdenom, q0);
+        T d1 = markstein2(b1, u.abs_denom, u.rdenom, q1);
+        T d2 = markstein2(b2, u.abs_denom, u.rdenom, q2);
+        if (__ballot(!fast_ok) != 0) {
+          d0 = exact_div(b0, u.abs_denom, u.rdenom, div_ok);
+          d1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
+          d2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
+        }
+        const T depth_inverse = u.dinv0 * d0 + u.dinv1 * d1 + u.dinv2 * d2;
+        const T di = epsclamp(depth_inverse);
+        T rd = fast_rcp(di);
+        if (__ballot(!fast_rcp_ok(di)) != 0) rd = exact_rcp(di);
+        const float depth = static_cast<float>(rd);
         const unsigned long long packed = (static_cast<unsigned long long>(__float_as_uint(depth)) << 32) | id;
         atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], packed);
       }
@@ -732,9 +800,11 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
 
   const int tid = threadIdx.x;
   const int n_items = queue[1];
+  DRTK_PHASE_INIT();
   for (;;) {
     if (tid == 0) s_item = atomicAdd(&queue[0], 1);
     __syncthreads();
+    if (tid == 0) DRTK_PHASE(0); // queue pop
     const int item_index = s_item;
     if (item_index >= n_items) break;
     const uint32_t item = items[item_index];
@@ -751,6 +821,7 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
       const int rows = y1 - y0 + 1;
       for (int i = tid; i < (ss << TILE_SHIFT); i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
       __syncthreads();
+      if (tid == 0) DRTK_PHASE(1); // clear
 
       const T* v_n = v + int64_t(n) * V * 3;
       const int32_t* vi_n = vi + int64_t(n) * vi_sN;
@@ -799,6 +870,7 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
           }
           if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
         }
+        if (tid == 0) DRTK_PHASE(2 + 4 * phase); // wave 0's share of the group: 2 = first group, 6 = second
         if (phase == 1) break;
 
         // big triangles (more than kMaxSmallTiles tiles): per-view list, filtered by tile range; drawn
@@ -824,7 +896,9 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
           }
           if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
         }
+        if (tid == 0) DRTK_PHASE(3); // big triangles
         __syncthreads();
+        if (tid == 0) DRTK_PHASE(4); // wave 0 waiting for the other waves' first group
         for (int bi = wave; bi < nb * nb; bi += kRasterBlock / kWave) {
           const int bx = bi % nb, by = bi / nb;
           uint32_t m = static_cast<uint32_t>(zbuf[(((by << 3) + (lane >> 3)) << TILE_SHIFT) + (bx << 3) + (lane & 7)] >> 32);
@@ -833,8 +907,10 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
           if (lane == 0) s_zmax[bi] = m;
         }
         __syncthreads();
+        if (tid == 0) DRTK_PHASE(5); // block-farthest reduction
       }
       __syncthreads();
+      if (tid == 0) DRTK_PHASE(7); // wave 0 waiting for the other waves' second group
 
       // unpack + store (rasterize_kernel.cu:402-415)
       const int64_t img_base = int64_t(n) * H * W;
@@ -869,7 +945,9 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
         }
       }
     }
+    if (tid == 0) DRTK_PHASE(8); // unpack + store (issue)
     __syncthreads(); // zbuf and s_item are reused by the next item
+    if (tid == 0) DRTK_PHASE(9); // waiting for the other waves' stores
   }
 }
 
