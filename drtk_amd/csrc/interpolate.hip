@@ -406,7 +406,9 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
       }
       wave_lds_sync();
       // 4. phase 2: run sums per (corner, channel) lane -> one 64-byte atomic request per corner and run
-      //    (a per-vertex LDS table in front of the atomics was measured slower here: 1.01 vs 0.83 ms)
+      //    (a per-vertex LDS table in front of the atomics was measured slower here, twice: 1.01 vs 0.83 ms in round 1;
+      //    1.07 vs 0.65 ms in round 2 with a float table and slots looked up at run heads only -- the flush it saves is
+      //    0.11 ms, but the table's bookkeeping takes the kernel from 126 to 171 VGPRs, i.e. from 4 to 2 waves per SIMD)
       if (cov != 0 && !DRTK_DBG(dbg, 1)) {
         const T* sg = s_g[wave];
         const T* sb = s_b[wave];

@@ -87,13 +87,15 @@ __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
 // double accumulator costs 8 instead of 4 bytes of LDS per entry and rounds once, at the flush, instead of at every add.
 using TableAcc = double;
 
-template <typename T, typename Val4Fn>
+// A = type of the table entries: TableAcc where entries are updated with LDS atomics (J <= 32), or T itself where the
+// J > 32 path's plain read-modify-write applies (see `exclusive` below).
+template <typename T, typename A = TableAcc, typename Val4Fn>
 __device__ __forceinline__ void scatter_runs(
     unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
-    int CC, TableAcc* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0,
+    int CC, A* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0,
     int c_off = 0, int c_step = 1) {
   const int lane = lane_id();
-  using LdsPtr = __attribute__((address_space(3))) TableAcc*;
+  using LdsPtr = __attribute__((address_space(3))) A*;
   // `exclusive`: no two lanes of one call target the same table entry (one run at a time, and the
   // three corners of a triangle are distinct vertices -- phase 1 sends triangles with repeated
   // vertex ids to the global fallback), so a plain read-modify-write is race free.
@@ -107,9 +109,9 @@ __device__ __forceinline__ void scatter_runs(
     if (s >= 0) {
       if (exclusive) {
         LdsPtr q = (LdsPtr)(vals + s * stride + c);
-        *q = *q + static_cast<TableAcc>(acc);
+        *q = *q + static_cast<A>(acc);
       } else {
-        lds_atomic_add(vals + s * stride + c, static_cast<TableAcc>(acc));
+        lds_atomic_add(vals + s * stride + c, static_cast<A>(acc));
       }
     }
     if (s < 0) { // table full for this vertex: direct global atomic (rare)
@@ -187,9 +189,9 @@ __device__ __forceinline__ void scatter_runs(
 }
 
 // Wave-wide: add every occupied entry of the wave's table to dst_n[key * C_total + c_base + c], c < CC.
-template <typename T>
+template <typename T, typename A = TableAcc>
 __device__ __forceinline__ void table_flush(
-    const int32_t* keys, const TableAcc* vals, int stride, int CC, T* __restrict__ dst_n, int C_total,
+    const int32_t* keys, const A* vals, int stride, int CC, T* __restrict__ dst_n, int C_total,
     int c_base) {
   for (int e = lane_id(); e < kTableSlots * CC; e += kWave) {
     const int s = e / CC, c = e - s * CC;
