@@ -536,7 +536,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 
 constexpr int kTileW = 16;  // pixel tile
 constexpr int kWin = 32;    // texel window side
-constexpr int kWinLevels = 3;
+constexpr int kWinLevels = 2;
 // `dbg` (diagnostics, profiles/kernel_bench.py --flags): 1 = no texture-gradient accumulation, 2 = no texel reads,
 // 4 = no flush.  Where the 6.0 ms of the bench shape go (finer timing-only variants, r01): the global-atomic fallback for
 // corners outside the windows ~1.5 ms, the four LDS adds ~0.8 ms, the flush 0.5 ms, texel reads 0.2 ms, everything else
@@ -556,19 +556,20 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
   __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels];
-  // windows [level][channel][kWin * kWin], C channels: dynamic LDS sized by the launch (C = 3: 36 KB -> 4 workgroups/CU)
+  // windows [level][channel][kWin * kWin], C channels, accumulated in DOUBLE whatever T is: ds_add_f32 retires one lane
+  // every three clocks on MI355X, ds_add_f64 twenty times as many (profiles/micro/lds_atomics.hip) -- the float windows
+  // were this kernel's floor.  Dynamic LDS sized by the launch (C = 3: 72 KB -> 2 workgroups/CU).
   extern __shared__ __attribute__((aligned(16))) unsigned char s_win_raw[];
-  T* const s_win = reinterpret_cast<T*>(s_win_raw);
+  double* const s_win = reinterpret_cast<double*>(s_win_raw);
   const int win_lstride = C * kWin * kWin;
   stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
   const int tid = threadIdx.x;
   if (tid == 0) s_ref = kMaxLevels;
   if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
   {
-    using V4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
-    V4* w4 = reinterpret_cast<V4*>(s_win);
-    const V4 z = {T(0), T(0), T(0), T(0)};
-    for (int i = tid; i < kWinLevels * win_lstride / 4; i += kBlock) w4[i] = z;
+    double2* w2 = reinterpret_cast<double2*>(s_win);
+    const double2 z = {0.0, 0.0};
+    for (int i = tid; i < kWinLevels * win_lstride / 2; i += kBlock) w2[i] = z;
   }
   __syncthreads();
 
@@ -668,11 +669,11 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
           if (gOut != T(0)) { // a zero upstream gradient (masked background) adds nothing
             if (DRTK_DBG(dbg, 1)) {
             } else if (cell >= 0) {
-              T* wp = s_win + l * win_lstride + c * (kWin * kWin) + cell;
-              if (q.o_nw >= 0) lds_add(wp, q.nw * gOut);
-              if (q.o_ne >= 0) lds_add(wp + 1, q.ne * gOut);
-              if (q.o_sw >= 0) lds_add(wp + kWin, q.sw * gOut);
-              if (q.o_se >= 0) lds_add(wp + kWin + 1, q.se * gOut);
+              double* wp = s_win + l * win_lstride + c * (kWin * kWin) + cell;
+              if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * gOut));
+              if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * gOut));
+              if (q.o_sw >= 0) lds_add(wp + kWin, static_cast<double>(q.sw * gOut));
+              if (q.o_se >= 0) lds_add(wp + kWin + 1, static_cast<double>(q.se * gOut));
             } else {
               const GlobalPtr<T> gp = ginp + c * plane;
               if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * gOut);
@@ -733,16 +734,15 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
     const int64_t plane = int64_t(h) * w;
     const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
     for (int c = 0; c < C; ++c) {
-      // four cells per lane and step (one 16-byte LDS read); a row of 32 cells = 8 consecutive lanes
-      using V4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
-      const V4* win4 = reinterpret_cast<const V4*>(s_win + l * win_lstride + c * (kWin * kWin));
-      for (int i4 = tid; i4 < kWin * kWin / 4; i4 += kBlock) {
-        const V4 q = win4[i4];
-        const T vals[4] = {q.x, q.y, q.z, q.w};
-        const int i = i4 * 4;
+      // two cells per lane and step (one 16-byte LDS read); a row of 32 cells = 16 consecutive lanes
+      const double2* win2 = reinterpret_cast<const double2*>(s_win + l * win_lstride + c * (kWin * kWin));
+      for (int i2 = tid; i2 < kWin * kWin / 2; i2 += kBlock) {
+        const double2 q = win2[i2];
+        const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
+        const int i = i2 * 2;
         const int gx = s_ox[l] + (i & (kWin - 1)), gy = s_oy[l] + i / kWin;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
           if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
         }
       }
@@ -830,7 +830,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileW));
     DRTK_LAUNCH(
         (mipmap_backward_tiled_kernel<float>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)),
-        dim3(kBlock), sizeof(float) * kWinLevels * C * kWin * kWin, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid),
+        dim3(kBlock), sizeof(double) * kWinLevels * C * kWin * kWin, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid),
         static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, padding_mode, align_corners != 0,
         force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), xcd_strip(tiles_x), debug_flags());
     DRTK_RETURN_IF_LAUNCH_FAILED();

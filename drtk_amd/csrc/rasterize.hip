@@ -42,11 +42,13 @@ extern "C" int drtk_amd_debug_read_phases(unsigned long long* out) {
   return DRTK_OK;
 }
 #define DRTK_PHASE_INIT() unsigned long long drtk_phase_t_ = __builtin_readcyclecounter()
-#define DRTK_PHASE(i)                                                   \
-  do {                                                                  \
-    const unsigned long long now_ = __builtin_readcyclecounter();       \
-    atomicAdd(&::drtk_amd::g_phase_clocks[i], now_ - drtk_phase_t_);    \
-    drtk_phase_t_ = __builtin_readcyclecounter();                       \
+#define DRTK_PHASE(i)                                                     \
+  do {                                                                    \
+    if (dbg & 256) { /* only when asked for: the counter updates themselves slow the kernel 2x */ \
+      const unsigned long long now_ = __builtin_readcyclecounter();       \
+      atomicAdd(&::drtk_amd::g_phase_clocks[i], now_ - drtk_phase_t_);    \
+      drtk_phase_t_ = __builtin_readcyclecounter();                       \
+    }                                                                     \
   } while (0)
 #else
 #define DRTK_PHASE_INIT() do { } while (0)
@@ -157,13 +159,34 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return 1.0 / x;
 }
 
+// Hierarchical-z bound.  Exactly, depth = 1 / sum_k(b_k / z_k) with b_k >= 0, sum b_k = 1, so depth >= min z.
+// As evaluated (:148-153) the b_k are rounded quotients of rounded edge functions and need not sum
+// to one: each edge function and the denominator carry an absolute error <= 8 eps L^2 (L = extent of
+// the triangle in pixels, +2 for the pixel itself), hence sum b_k <= 1 + 40 eps L^2 / |den|, and the
+// three products, two additions, the reciprocal and the cast to float add < 1e-6 relative.
+// Returns the f32 bits of a rigorous lower bound of every depth the triangle can produce, 0 if there is none.
+template <typename T>
+__device__ __forceinline__ uint32_t z_lower_bound_bits(T min_x, T max_x, T min_y, T max_y, T abs_denom, T zmin) {
+  const T ext = (max_x - min_x > max_y - min_y ? max_x - min_x : max_y - min_y) + T(2);
+  const T eps = sizeof(T) == 4 ? T(5.97e-8) : T(1.12e-16);
+  const T delta = T(40) * eps * ext * ext / abs_denom + T(2e-6);
+  if (!(delta < T(0.25))) return 0u;
+  // ... and depth = 1 / epsclamp(depth_inverse) never exceeds 1 / eps (1e8 in f32, 1e16 in f64): geometry
+  // beyond that comes out AT 1 / eps, below its own min z, so the bound is the smaller of the two.
+  const T cap = (T(1) / Eps<T>::value()) * (T(1) - T(2e-6));
+  const T zb = zmin * (T(1) - delta);
+  const float lo = static_cast<float>(zb < cap ? zb : cap);
+  const uint32_t bits = __float_as_uint(lo);
+  return (lo > 0.0f && bits > 8u) ? bits - 8u : 0u; // 8 ulps below, against the rounding of `lo` itself
+}
+
 // Culling + bounding box only (used by the binning passes).  Returns false if the triangle is
 // dropped by the reference (:81 degenerate indices, :96 near plane, :97-98 off canvas, :107 zero
 // area).  On success the pixel bbox (already clamped to the canvas) is returned.
 template <typename T>
 __device__ __forceinline__ bool tri_bbox(
     const T* __restrict__ v_n, const int32_t* __restrict__ vi_face, int H, int W, int& bx0,
-    int& by0, int& bx1, int& by1, bool& positive, float& z_mean) {
+    int& by0, int& bx1, int& by1, bool& positive, float& z_mean, uint32_t& z_lo_bits) {
   const int32_t vi_0 = static_cast<int32_t>(static_cast<uint32_t>(vi_face[0]) & 0x0FFFFFFFu);
   const int32_t vi_1 = vi_face[1];
   const int32_t vi_2 = vi_face[2];
@@ -179,6 +202,7 @@ __device__ __forceinline__ bool tri_bbox(
   const T den = v01x * v02y - v01y * v02x;
   if (den == T(0)) return false;
   positive = den > T(0);
+  z_lo_bits = z_lower_bound_bits<T>(min_x, max_x, min_y, max_y, den > T(0) ? den : -den, min3(p0z, p1z, p2z));
   z_mean = static_cast<float>((p0z + p1z + p2z) * T(1.0 / 3.0));
   bx0 = max(0, trunc_i32(min_x));
   by0 = max(0, trunc_i32(min_y));
@@ -229,27 +253,7 @@ __device__ __forceinline__ bool tri_setup(
   s.tl0 = pos ? (v12y < T(0) || (v12y == T(0) && v12x > T(0))) : (v12y > T(0) || (v12y == T(0) && v12x < T(0)));
   s.tl1 = pos ? (v02y > T(0) || (v02y == T(0) && v02x < T(0))) : (v02y < T(0) || (v02y == T(0) && v02x > T(0)));
   s.tl2 = pos ? (v01y < T(0) || (v01y == T(0) && v01x > T(0))) : (v01y > T(0) || (v01y == T(0) && v01x < T(0)));
-  // Hierarchical-z bound.  Exactly, depth = 1 / sum_k(b_k / z_k) with b_k >= 0, sum b_k = 1, so depth >= min z.
-  // As evaluated (:148-153) the b_k are rounded quotients of rounded edge functions and need not sum
-  // to one: each edge function and the denominator carry an absolute error <= 8 eps L^2 (L = extent of
-  // the triangle in pixels, +2 for the pixel itself), hence sum b_k <= 1 + 40 eps L^2 / |den|, and the
-  // three products, two additions, the reciprocal and the cast to float add < 1e-6 relative.
-  {
-    const T ext = (max_x - min_x > max_y - min_y ? max_x - min_x : max_y - min_y) + T(2);
-    const T eps = sizeof(T) == 4 ? T(5.97e-8) : T(1.12e-16);
-    const T delta = T(40) * eps * ext * ext / s.abs_denom + T(2e-6);
-    const T zmin = min3(p0z, p1z, p2z);
-    s.z_lo_bits = 0;
-    if (delta < T(0.25)) {
-      // ... and depth = 1 / epsclamp(depth_inverse) never exceeds 1 / eps (1e8 in f32, 1e16 in f64): geometry
-      // beyond that comes out AT 1 / eps, below its own min z, so the bound is the smaller of the two.
-      const T cap = (T(1) / Eps<T>::value()) * (T(1) - T(2e-6));
-      const T zb = zmin * (T(1) - delta);
-      const float lo = static_cast<float>(zb < cap ? zb : cap);
-      const uint32_t bits = __float_as_uint(lo);
-      s.z_lo_bits = (lo > 0.0f && bits > 8u) ? bits - 8u : 0u; // 8 ulps below, against the rounding of `lo` itself
-    }
-  }
+  s.z_lo_bits = 0; // the bound comes from the binning pass's record (tri_pre), see tile_raster_kernel
   return true;
 }
 
@@ -287,7 +291,7 @@ struct BinLayout {
   int tiles_x, tiles_y;
   int64_t tiles_per_view, num_tiles; // per view / total
   size_t off_count, off_cursor, off_big_count, off_view_stats, off_queue, zero_bytes; // zero-filled prefix
-  size_t off_offset, off_range, off_big_list, off_pairs, off_items, total_bytes;
+  size_t off_offset, off_range, off_pre, off_big_list, off_pairs, off_items, total_bytes;
   int64_t max_items;
 };
 
@@ -327,6 +331,8 @@ inline BinLayout make_layout(int64_t N, int64_t F, int64_t H, int64_t W) {
   o += align_up(sizeof(int32_t) * (L.num_tiles + 1), 256);
   L.off_range = o;
   o += align_up(sizeof(uint2) * N * F, 256);
+  L.off_pre = o;
+  o += align_up(sizeof(uint4) * N * F, 256);
   L.off_big_list = o;
   o += align_up(sizeof(int32_t) * N * F, 256);
   L.off_pairs = o;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN, int H,
     int W, int tile_shift, int tiles_x, int tiles_per_view, unsigned long long* __restrict__ tile_count,
     int32_t* __restrict__ big_count, int32_t* __restrict__ big_list,
-    uint2* __restrict__ tri_range, float* __restrict__ view_stats) {
+    uint2* __restrict__ tri_range, uint4* __restrict__ tri_pre, float* __restrict__ view_stats) {
   const int n = blockIdx.y;
   const int f = blockIdx.x * kBlock + threadIdx.x;
   const bool in_range = f < F;
@@ -423,8 +429,16 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(
   int tx0 = 0, ty0 = 0, tw = 0, ntiles = 0;
   bool positive = false;
   float z_mean = 0.0f;
+  uint32_t z_lo_bits = 0;
   if (in_range &&
-      tri_bbox<T>(v + int64_t(n) * V * 3, vi + int64_t(n) * vi_sN + int64_t(f) * 3, H, W, bx0, by0, bx1, by1, positive, z_mean)) {
+      tri_bbox<T>(v + int64_t(n) * V * 3, vi + int64_t(n) * vi_sN + int64_t(f) * 3, H, W, bx0, by0, bx1, by1, positive, z_mean, z_lo_bits)) {
+    // The raster pass's pre-reject record: clamped pixel bbox (16 bits per coordinate) + depth lower bound.  With it
+    // a hidden triangle is dropped after ONE 16-byte load -- no index / vertex gathers, no set-up.  Canvases beyond
+    // 65535 pixels a side: .w = 0, "no record" (the raster pass then sets the triangle up and tests it as before).
+    const bool fits = bx1 < 65536 && by1 < 65536;
+    tri_pre[int64_t(n) * F + f] = make_uint4(
+        static_cast<uint32_t>(bx0) | (static_cast<uint32_t>(bx1) << 16), static_cast<uint32_t>(by0) | (static_cast<uint32_t>(by1) << 16),
+        fits ? z_lo_bits : 0u, fits ? 1u : 0u);
     tx0 = bx0 >> tile_shift;
     ty0 = by0 >> tile_shift;
     const int tx1 = bx1 >> tile_shift, ty1 = by1 >> tile_shift;
@@ -789,7 +803,7 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
     int H, int W, int tiles_x, int tiles_per_view, const int32_t* __restrict__ tile_offset,
     const unsigned long long* __restrict__ tile_count, const float* __restrict__ view_stats,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ big_count,
-    const int32_t* __restrict__ big_list, const uint2* __restrict__ tri_range,
+    const int32_t* __restrict__ big_list, const uint2* __restrict__ tri_range, const uint4* __restrict__ tri_pre,
     const uint32_t* __restrict__ items, int32_t* __restrict__ queue, float* __restrict__ depth_img,
     int32_t* __restrict__ index_img, int dbg) {
   constexpr int TILE = 1 << TILE_SHIFT;
@@ -840,18 +854,33 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
       const float* st = view_stats + 4 * n;
       const bool pos_first = st[0] * st[3] <= st[2] * st[1]; // mean z of positive <= mean z of negative
       for (int phase = 0; phase < 2; ++phase) {
+        if (phase == 1 && DRTK_DBG(dbg, 64)) break; // timing only: the second (mostly hidden) group is not drawn at all
         const bool take_pos = (phase == 0) == pos_first;
         const int g_begin = take_pos ? begin : begin + n_pos, g_end = take_pos ? begin + n_pos : end_all;
-        auto accept = [&](const TriSetup<T>& s) -> bool {
-          if (!(s.bb_min_x <= x1 && s.bb_max_x >= x0 && s.bb_min_y <= y1 && s.bb_max_y >= y0)) return false;
-          if (phase == 0 || s.z_lo_bits == 0 || DRTK_DBG(dbg, 16)) return true;
-          const int cx0 = (max(s.bb_min_x, x0) - x0) >> 3, cx1 = (min(s.bb_max_x, x1) - x0) >> 3;
-          const int cy0 = (max(s.bb_min_y, y0) - y0) >> 3, cy1 = (min(s.bb_max_y, y1) - y0) >> 3;
+        // the test on a triangle's pre-reject record (bin_count: clamped pixel bbox + depth lower bound): does its bbox
+        // touch this item's rectangle, and (second group) can it still win a pixel of the 8x8 blocks it touches
+        auto accept = [&](int bx_min, int by_min, int bx_max, int by_max, uint32_t z_lo_bits) -> bool {
+          if (!(bx_min <= x1 && bx_max >= x0 && by_min <= y1 && by_max >= y0)) return false;
+          if (phase == 0 || z_lo_bits == 0 || DRTK_DBG(dbg, 16)) return true;
+          const int cx0 = (max(bx_min, x0) - x0) >> 3, cx1 = (min(bx_max, x1) - x0) >> 3;
+          const int cy0 = (max(by_min, y0) - y0) >> 3, cy1 = (min(by_max, y1) - y0) >> 3;
           if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 16) return true;
           uint32_t far = 0;
           for (int by = cy0; by <= cy1; ++by)
             for (int bx = cx0; bx <= cx1; ++bx) far = max(far, s_zmax[by * nb + bx]);
-          return !(s.z_lo_bits > far);
+          return !(z_lo_bits > far);
+        };
+        const uint4* pre_n = tri_pre + int64_t(n) * F;
+        // triangle f of this view: rejected on its record alone (one 16-byte load), else set up
+        auto fetch = [&](int f, TriSetup<T>& s) -> bool {
+          const uint4 pre = pre_n[f];
+          if (pre.w != 0u &&
+              !accept(static_cast<int>(pre.x & 0xFFFFu), static_cast<int>(pre.y & 0xFFFFu), static_cast<int>(pre.x >> 16),
+                      static_cast<int>(pre.y >> 16), pre.z))
+            return false;
+          if (!tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s)) return false;
+          // canvases beyond 65535 pixels a side have no record: bbox test on the set-up triangle, no depth bound
+          return pre.w != 0u || accept(s.bb_min_x, s.bb_min_y, s.bb_max_x, s.bb_max_y, 0u);
         };
         // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively;
         // the group is cut into equal parts, one per wave, so that the waves reach the barrier together
@@ -865,8 +894,7 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
           TriSetup<T> s = {};
           if (i < end && !DRTK_DBG(dbg, 8)) {
             f = pairs[i];
-            valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
-            valid = valid && accept(s);
+            valid = fetch(f, s);
           }
           if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
         }
@@ -889,10 +917,7 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
             f = big_n[i];
             const uint2 r = range_n[f];
             const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = (r.y & ~kFacingBit) >> 16;
-            if (tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1) {
-              valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
-              valid = valid && accept(s);
-            }
+            if (tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1) valid = fetch(f, s);
           }
           if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
         }
@@ -1014,6 +1039,7 @@ int rasterize_impl(
   auto* big_count = reinterpret_cast<int32_t*>(ws + L.off_big_count);
   auto* tile_offset = reinterpret_cast<int32_t*>(ws + L.off_offset);
   auto* tri_range = reinterpret_cast<uint2*>(ws + L.off_range);
+  auto* tri_pre = reinterpret_cast<uint4*>(ws + L.off_pre);
   auto* big_list = reinterpret_cast<int32_t*>(ws + L.off_big_list);
   auto* pairs = reinterpret_cast<int32_t*>(ws + L.off_pairs);
   auto* items = reinterpret_cast<uint32_t*>(ws + L.off_items);
@@ -1026,7 +1052,7 @@ int rasterize_impl(
     DRTK_LAUNCH(
         bin_count_kernel<T>, tri_grid, dim3(kBlock), 0, stream, v, vi, (int)F, V, vi_sN, (int)H,
         (int)W, L.tile_shift, L.tiles_x, (int)L.tiles_per_view, tile_count, big_count, big_list,
-        tri_range, view_stats);
+        tri_range, tri_pre, view_stats);
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   DRTK_LAUNCH(
@@ -1046,12 +1072,12 @@ int rasterize_impl(
     DRTK_LAUNCH(
         (tile_raster_kernel<T, 6>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
         (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,
-        big_list, tri_range, items, queue, depth_img, index_img, debug_flags());
+        big_list, tri_range, tri_pre, items, queue, depth_img, index_img, debug_flags());
   } else {
     DRTK_LAUNCH(
         (tile_raster_kernel<T, 5>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
         (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,
-        big_list, tri_range, items, queue, depth_img, index_img, debug_flags());
+        big_list, tri_range, tri_pre, items, queue, depth_img, index_img, debug_flags());
   }
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;

@@ -22,6 +22,7 @@ ap.add_argument("--views", type=int, default=8)
 a = ap.parse_args()
 capi.use_profiling_library(os.path.join(ROOT, "profiles", "libdrtk_amd_ablate.so"))
 L = capi.lib()
+L.drtk_amd_debug_set_flags(256)  # switch the phase clocks on
 nl, no = S.MESH_SIZES[a.mesh]
 v, vi = S.sphere_views(a.views, nl, no, a.res, a.res, lobes=0.05, device="cuda:0")
 buf = (ctypes.c_ulonglong * 16)()
