@@ -44,7 +44,7 @@ extern "C" int drtk_amd_debug_read_phases(unsigned long long* out) {
 #define DRTK_PHASE_INIT() unsigned long long drtk_phase_t_ = __builtin_readcyclecounter()
 #define DRTK_PHASE(i)                                                     \
   do {                                                                    \
-    if (dbg & 256) { /* only when asked for: the counter updates themselves slow the kernel 2x */ \
+    if (DRTK_DBG(dbg, 256)) { /* only when asked for: the counter updates themselves slow the kernel 2x */ \
       const unsigned long long now_ = __builtin_readcyclecounter();       \
       atomicAdd(&::drtk_amd::g_phase_clocks[i], now_ - drtk_phase_t_);    \
       drtk_phase_t_ = __builtin_readcyclecounter();                       \

@@ -22,6 +22,7 @@ Fixtures:
   refpy_step_spheres_f32      the SURVEY 8d step on the spheres scene through drtk.rasterize / render / interpolate /
                               edge_grad_estimator + autograd: no hook; with a v_pix_img_hook that rescales the
                               gradient (and what the hook saw); partial requires_grad patterns.
+  refpy_sparse_<scene>        drtk.interpolation_matrix / interpolation_normal_matrix incl. the module's own A^T A pattern builder
   refpy_two_triangles         test/two_triangles.py (the reference's only script-level test) at 64x64: iteration-0
                               tensors and the loss at iterations 0, 1, 50, 100, 200 of its Adam loop.
 """
@@ -245,6 +246,39 @@ def gen_two_triangles(drtk):
     save("refpy_two_triangles", {"out_" + k: x for k, x in rec.items()})
 
 
+# ------------------------------------------------------------------------------------------------ sparse operators
+def gen_sparse(drtk):
+    """drtk.interpolation_matrix / interpolation_normal_matrix through the reference's wrappers and its module --
+    including the A^T A PATTERN builder (interpolate_module.cpp:28-262: host code in the module's anonymous namespace,
+    unreachable from the kernel-level build of round 1, which is why the pattern was only pinned through a property
+    then) and the LRU structure cache.  Shared and per-view topology, with gradients wrt bary_img."""
+    for scene, tag in (("spheres_f32", "spheres_f32"), ("ragged_f32", "ragged_f32"), ("tutorial3_f64", "tutorial3_f64")):
+        sc = load_fixture(scene)
+        vi, index, bary = sc["in_vi"], sc["out_index_img"], sc["out_render_bary"]
+        V = sc["in_v"].shape[1]
+        b = bary.clone().requires_grad_(True)
+        A = drtk.interpolation_matrix(vi, index, b, V)
+        g = th.Generator().manual_seed(31)
+        gA = th.rand(A.values().shape, generator=g, dtype=th.float64).to(bary.dtype)
+        (A.values() * gA).sum().backward()
+        arrs = dict(in_gA=gA, out_A_crow=A.crow_indices().to(th.int32), out_A_col=A.col_indices().to(th.int32), out_A_values=A.values().detach(),
+                    out_A_bary_grad=b.grad.clone())
+        b2 = bary.clone().requires_grad_(True)
+        M = drtk.interpolation_normal_matrix(vi, index, b2, V)
+        gM = th.rand(M.values().shape, generator=g, dtype=th.float64).to(bary.dtype)
+        (M.values() * gM).sum().backward()
+        arrs.update(in_gM=gM, out_M_crow=M.crow_indices().to(th.int32), out_M_col=M.col_indices().to(th.int32), out_M_values=M.values().detach(),
+                    out_M_bary_grad=b2.grad.clone())
+        # the reference's own identity: M == A^T A
+        err = (A.detach().to_dense().double().T @ A.detach().to_dense().double() - M.detach().to_dense().double()).abs().max().item()
+        assert err < (1e-4 if bary.dtype == th.float32 else 1e-11), err
+        # second call on the same topology goes through the module's structure cache: same pattern
+        M2 = drtk.interpolation_normal_matrix(vi, index, bary, V)
+        assert th.equal(M2.crow_indices(), M.crow_indices()) and th.equal(M2.col_indices(), M.col_indices())
+        print(f"  sparse {tag}: A {tuple(A.shape)} nnz {A.values().numel()}, A^T A nnz {M.values().numel()}, |A^T A - M| = {err:.1e}")
+        save(f"refpy_sparse_{tag}", arrs)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs /root/reference (build container only)")
@@ -253,6 +287,7 @@ def main():
     gen_transform(drtk)
     gen_step(drtk)
     gen_two_triangles(drtk)
+    gen_sparse(drtk)
 
 
 if __name__ == "__main__":

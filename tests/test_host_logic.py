@@ -283,10 +283,12 @@ def test_only_the_cpu_baseline_leg_and_the_smoke_check_use_the_oracle():
                 bad.append(f"{os.path.basename(path)}:{no}: {line.strip()}")
         return bad
 
-    assert offending(os.path.join(ROOT, "bench.py"), {"cpu_baseline", "_cpu_backend"}) == []  # the leg and its loader
+    # the leg (one function per workload) and its loader
+    assert offending(os.path.join(ROOT, "bench.py"), {"cpu_baseline", "cpu_baseline_textured", "_cpu_backend"}) == []
     bench_src = open(os.path.join(ROOT, "bench.py")).read()
     assert len(re.findall(r"_cpu_backend\(", bench_src)) == 2  # its definition + the one call in cpu_baseline()
-    assert len(re.findall(r"cpu_baseline\(", bench_src)) == 2   # its definition + the one call, rank 0 at N = 1
+    assert len(re.findall(r"\bcpu_baseline\(", bench_src)) == 2   # its definition + the one call, rank 0 at N = 1
+    assert len(re.findall(r"\bcpu_baseline_textured\(", bench_src)) == 2
     assert offending(os.path.join(ROOT, "__graft_entry__.py"), {"build", "smoke"}) == []
     for dirpath, dirnames, files in os.walk(os.path.join(ROOT, "profiles")):
         dirnames[:] = [d for d in dirnames if d != "__pycache__"]

@@ -233,3 +233,61 @@ def test_hip_two_triangles_follows_the_reference_script():
             band = 1e-4 if it <= 1 else 2e-2
             assert abs(float(loss.detach()) - want[it]) <= band * want[it], (it, float(loss.detach()), want[it])
         optim.step()
+
+
+# ---------------------------------------------------------------------------------------------- sparse operators
+SPARSE = ["spheres_f32", "ragged_f32", "tutorial3_f64"]
+
+
+@pytest.mark.parametrize("name", SPARSE)
+def test_oracle_normal_matrix_pattern_equals_the_reference_modules_own(name):
+    """CPU: the A^T A PATTERN (CSR rows / columns) the oracle restates from interpolate_module.cpp:167-241 against the
+    pattern the reference's own module builds (fixture from its Python wrapper + module + CPU kernels); the values of
+    both sparse operators and their bary gradients from the oracle's kernels through that pattern."""
+    import oracle as O
+
+    i, _ = load_golden(name)
+    sc_o = load_golden(name)[1]
+    _, r = load_golden("refpy_sparse_" + name)
+    gi, _ = load_golden("refpy_sparse_" + name)
+    vi, index, bary = i["vi"], sc_o["index_img"], sc_o["render_bary"]
+    V = i["v"].shape[1]
+    vib = (vi[None].expand(index.shape[0], -1, -1) if vi.ndim == 2 else vi).contiguous()
+    crow, col, pair = O.normal_matrix_structure(vib, V)
+    assert th.equal(crow.int(), r["M_crow"]) and th.equal(col.int(), r["M_col"])
+    vals = O.normal_matrix_values(pair, index, bary, col.numel())
+    tol = 1e-5 if bary.dtype == th.float32 else 1e-12
+    assert float((vals.double() - r["M_values"].double()).abs().max()) <= tol * max(1.0, float(r["M_values"].abs().max()))
+    bg = O.normal_matrix_values_backward(gi["gM"], pair, index, bary)
+    assert float((bg.double() - r["M_bary_grad"].double()).abs().max()) <= tol * max(1.0, float(r["M_bary_grad"].abs().max()))
+    a_crow, a_col, a_vals, rows = O.interpolation_matrix(vib, index, bary)
+    assert th.equal(a_crow.int(), r["A_crow"]) and th.equal(a_col.int(), r["A_col"]) and th.equal(a_vals, r["A_values"])
+    assert th.equal(O.interpolation_matrix_backward(gi["gA"], vib, index, bary, rows), r["A_bary_grad"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("package", ["drtk_amd", "drtk"])
+@pytest.mark.parametrize("name", SPARSE)
+def test_hip_sparse_operators_match_the_reference_python_stack(name, package):
+    """GPU: drtk_amd.interpolation_matrix / interpolation_normal_matrix (device-built pattern, structure cache, value
+    kernels, autograd) against the reference's own stack."""
+    import importlib
+
+    ops = importlib.import_module(package)
+    i, o = load_golden(name)
+    gi, r = load_golden("refpy_sparse_" + name)
+    vi, index = i["vi"].to(DEV), o["index_img"].to(DEV)
+    V = i["v"].shape[1]
+    for rep in range(2):  # the second round goes through the structure cache
+        b = o["render_bary"].to(DEV).clone().requires_grad_(True)
+        A = ops.interpolation_matrix(vi, index, b, V)
+        assert th.equal(A.crow_indices().cpu().int(), r["A_crow"]) and th.equal(A.col_indices().cpu().int(), r["A_col"])
+        assert th.equal(A.values().detach().cpu(), r["A_values"])
+        (A.values() * gi["gA"].to(DEV)).sum().backward()
+        assert th.equal(b.grad.cpu(), r["A_bary_grad"])
+        b2 = o["render_bary"].to(DEV).clone().requires_grad_(True)
+        M = ops.interpolation_normal_matrix(vi, index, b2, V)
+        assert th.equal(M.crow_indices().cpu().int(), r["M_crow"]) and th.equal(M.col_indices().cpu().int(), r["M_col"])
+        close(M.values(), r["M_values"], "normal matrix values")
+        (M.values() * gi["gM"].to(DEV)).sum().backward()
+        close(b2.grad, r["M_bary_grad"], "normal matrix bary gradient")
