@@ -281,6 +281,110 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_kernel(
   }
 }
 
+// Backward for C <= 4 (the v_pix route of edge_grad_estimator with a hook, uv attributes, RGB attributes): lane = pixel
+// like render backward; the 3 * CN products grad_out[c] * bary[k] stay in registers, a segmented scan over the 16-lane
+// rows leaves each run's sums in its last lane (segscatter.hpp: run_sums_rows16), which alone updates the wave's vertex
+// table (double accumulators) -- no LDS staging, no lane flip, no barrier in the loop.  The bary gradient is the
+// reference's per-pixel dot products (interpolate_kernel.cu:238-246, channels ascending).
+template <typename T, bool HAS_VERT, bool HAS_BARY, int CN>
+__global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
+    const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
+    const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int64_t vi_sN, int H, int W,
+    int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad, int strip) {
+  constexpr int kWaves = kBlock / kWave;
+  constexpr int kPasses = kTileRows / kWaves;
+  __shared__ int32_t t_keys[HAS_VERT ? kWaves : 1][HAS_VERT ? kTableSlots : 1];
+  __shared__ TableAcc t_vals[HAS_VERT ? kWaves : 1][HAS_VERT ? kTableSlots * 4 : 1];
+
+  const int64_t HW = int64_t(H) * W;
+  const int n = blockIdx.y;
+  const int tile = tile_index(strip);
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int wave = threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int x = txi * kWave + lane;
+  const T* attrs_n = attrs + int64_t(n) * V * CN;
+  const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+  T* attr_grad_n = HAS_VERT ? attr_grad + int64_t(n) * V * CN : nullptr;
+  const T* go_n = grad_out + int64_t(n) * CN * HW;
+  const T* bary_n = bary_img + int64_t(n) * 3 * HW;
+
+  if constexpr (HAS_VERT) {
+    table_init(t_keys[wave]);
+    for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = 0;
+    wave_lds_sync();
+  }
+  auto load_tr = [&](int ps) -> int32_t {
+    const int yy = tyi * kTileRows + wave * kPasses + ps;
+    return (x < W && yy < H) ? index_img[int64_t(n) * HW + int64_t(yy) * W + x] : -1;
+  };
+  auto load_face = [&](int32_t t, int32_t (&f)[3]) {
+    f[0] = f[1] = f[2] = 0;
+    if (t != -1) {
+      const int32_t* face = vi_n + int64_t(t) * 3;
+      f[0] = face[0], f[1] = face[1], f[2] = face[2];
+    }
+  };
+  int32_t tr_next = load_tr(0);
+  int32_t vn[3];
+  load_face(tr_next, vn);
+#pragma unroll 1
+  for (int ps = 0; ps < kPasses; ++ps) {
+    const int y = tyi * kTileRows + wave * kPasses + ps;
+    const bool in_range = x < W && y < H;
+    const int64_t pix = int64_t(y) * W + x;
+    const int32_t tr = tr_next;
+    const bool covered = tr != -1;
+    const int32_t cur[3] = {vn[0], vn[1], vn[2]};
+    if (ps + 1 < kPasses) tr_next = load_tr(ps + 1);
+    T g[CN], B[3] = {T(0), T(0), T(0)};
+#pragma unroll
+    for (int c = 0; c < CN; ++c) g[c] = T(0);
+    if (covered) {
+#pragma unroll
+      for (int c = 0; c < CN; ++c) g[c] = go_n[int64_t(c) * HW + pix];
+      if constexpr (HAS_VERT) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) B[k] = bary_n[int64_t(k) * HW + pix];
+      }
+    }
+    if constexpr (HAS_BARY) {
+      T bg[3] = {T(0), T(0), T(0)};
+      if (covered) {
+#pragma unroll
+        for (int c = 0; c < CN; ++c) { // interpolate_kernel.cu:238-246 accumulation order
+#pragma unroll
+          for (int k = 0; k < 3; ++k) bg[k] += g[c] * attrs_n[int64_t(cur[k]) * CN + c];
+        }
+      }
+      if (in_range) {
+        T* bgp = bary_grad + int64_t(n) * 3 * HW + pix;
+        bgp[0] = bg[0], bgp[HW] = bg[1], bgp[2 * HW] = bg[2];
+      }
+    }
+    if (ps + 1 < kPasses) load_face(tr_next, vn);
+    if constexpr (HAS_VERT) {
+      int dist;
+      bool tail;
+      run_rows16(tr, dist, tail);
+      if (__ballot(covered) != 0) {
+        T p[3 * CN];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+          for (int c = 0; c < CN; ++c) p[k * CN + c] = g[c] * B[k];
+        }
+        run_sums_rows16<T, 3 * CN>(p, dist);
+        if (tail && covered) table_add<T, 3, CN>(t_keys[wave], t_vals[wave], 4, cur, p, attr_grad_n, CN);
+      }
+    }
+  }
+  if constexpr (HAS_VERT) {
+    wave_lds_sync();
+    table_flush<T>(t_keys[wave], t_vals[wave], 4, CN, attr_grad_n, CN, 0);
+  }
+}
+
 // Backward, wide-channel fast path (vertex + bary gradients, C % 16 == 0, 16-byte aligned rows).
 //
 // Same tiling and phase structure as interpolate_backward_kernel<.., 16>, but written so that no
@@ -521,6 +625,27 @@ int interpolate_backward_impl(
           (interpolate_backward_wide_kernel<T>), grid, block, 0, stream, grad_out, attrs, vi, index_img, bary_img,
           V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip);
     }
+  } else if (small_c && !DRTK_DBG(debug_flags(), 128)) {
+#define SMALL(HV, HB, CN)                                                                                                   \
+  DRTK_LAUNCH(                                                                                                              \
+      (interpolate_backward_small_kernel<T, HV, HB, CN>), grid, block, 0, stream, grad_out, attrs, vi, index_img, bary_img, \
+      V, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, strip)
+#define SMALL_C(HV, HB)          \
+  switch (C) {                   \
+    case 1: SMALL(HV, HB, 1); break; \
+    case 2: SMALL(HV, HB, 2); break; \
+    case 3: SMALL(HV, HB, 3); break; \
+    default: SMALL(HV, HB, 4); break; \
+  }
+    if (attr_grad && bary_grad) {
+      SMALL_C(true, true)
+    } else if (attr_grad) {
+      SMALL_C(true, false)
+    } else {
+      SMALL_C(false, true)
+    }
+#undef SMALL_C
+#undef SMALL
   } else if (attr_grad && bary_grad) {
     if (small_c) {
       if (cvec) LAUNCH(true, true, 4, 4); else LAUNCH(true, true, 1, 4);
