@@ -101,6 +101,30 @@ def save(name, inputs, outputs):
     print(f"  {path}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def frozen_inputs(fixture, generated):
+    """Scene inputs are DATA: once a fixture exists its `in_*` arrays are the scene (the projected spheres come out of
+    float64 sin / cos / matmul, which this torch build does not reproduce bit for bit from run to run -- 1e-14 jitter in
+    `spheres_f64`'s vertices made that fixture the one file a regeneration could not reproduce byte for byte).  With
+    `--fresh` the inputs are generated anew."""
+    path = os.path.join(OUT, fixture + ".npz")
+    if "--fresh" in sys.argv or not os.path.isfile(path):
+        return generated
+    z = np.load(path)
+    out = dict(generated)
+    for k in z.files:
+        if not k.startswith("in_"):
+            continue
+        a = z[k]
+        name = k[3:]
+        if name in generated and isinstance(generated[name], th.Tensor):
+            t = th.from_numpy(np.ascontiguousarray(a))
+            assert t.shape == generated[name].shape and t.dtype == generated[name].dtype, (fixture, name)
+            assert float((t.double() - generated[name].double()).abs().max()) <= 1e-9 * max(1.0, float(t.double().abs().max())), \
+                f"{fixture}: stored input {name} is not the scene the generator describes"
+            out[name] = t
+    return out
+
+
 def two_triangles_trajectory(ops):
     """The reference's only 'test' (test/two_triangles.py:14-92) at 64x64 on CPU: GT render,
     perturbed start, Adam.  Records iteration-0 tensors and the loss at a few iterations."""
@@ -151,7 +175,7 @@ def main():
         for dtype, tag in ((th.float32, "f32"), (th.float64, "f64")):
             if dtype == th.float64 and name not in ("tutorial3", "spheres", "edge_cases"):
                 continue
-            sc = fn(dtype)
+            sc = frozen_inputs(f"{name}_{tag}", fn(dtype))
             outs = run_scene(B, Bfast, sc)
             nd = int((outs["index_img"] != outs["index_img_fast"]).sum())
             print(f"{name}/{tag}: covered {(outs['index_img'] >= 0).sum().item()} px, "

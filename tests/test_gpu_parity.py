@@ -1389,3 +1389,42 @@ def test_partial_use_of_outputs_and_inputs_through_autograd():
     seen = []
     rel(edge("v_only", hook=lambda gr: seen.append(tuple(gr.shape))), e_full, "edge_grad_estimator: hook (unfused) route vs fused route")
     assert seen == [(N, 3, H, W)]
+
+
+def test_kernel_timing_brackets_every_launch_and_changes_nothing():
+    """drtk_amd_kernel_timing_begin / _report (what bench.py's `roofline` is made of): every kernel launched between the
+    two calls -- through the C ABI or through the torch operators and autograd -- is reported with its launch count and a
+    positive time, results are bit-identical with and without a collection open, and a closed collection reports nothing."""
+    import drtk_amd
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    H, W, N, C = 128, 192, 2, 16
+    v, vi = S.sphere_views(N, 20, 24, H, W, device=DEV)
+    attr = S.random_attributes(N, v.shape[1], C, shared=False, device=DEV)
+
+    def step():
+        vv = v.clone().requires_grad_(True)
+        aa = attr.clone().requires_grad_(True)
+        loss, index = S.fwd_bwd_step(vv, vi, aa, H, W, ops=drtk_amd)
+        return float(loss.detach()), index, vv.grad, aa.grad
+
+    ref = step()
+    capi.kernel_timing_begin()
+    for _ in range(3):
+        got = step()
+    capi.render(v, vi, got[1])  # a direct C-ABI call is timed too
+    th.cuda.synchronize()
+    rep = capi.kernel_timing_report()
+    assert got[0] == ref[0] and th.equal(got[1], ref[1])
+    close(got[2], ref[2], "v.grad under timing", atol=1e-7, rtol=1e-5)  # atomics order only
+    close(got[3], ref[3], "attr.grad under timing", atol=1e-7, rtol=1e-5)
+    names = {k.split("<")[0]: v for k, v in rep.items()}
+    for k, launches in (("bin_count_kernel", 3), ("bin_scan_kernel", 3), ("bin_fill_kernel", 3), ("tile_raster_kernel", 3), ("render_kernel", 4),
+                        ("interpolate_kernel", 3), ("edge_dots_kernel", 3), ("edge_scatter_pairs_kernel", 3),
+                        ("interpolate_backward_wide_kernel", 3), ("render_backward_kernel", 3)):
+        assert k in names, (k, sorted(names))
+        assert names[k][0] == launches and 0 < names[k][1] < 100.0, (k, names[k])
+    assert names["fill_bytes_kernel"][0] >= 9
+    step()
+    assert capi.kernel_timing_report() == {}  # nothing is collected outside begin ... report
