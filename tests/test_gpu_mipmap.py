@@ -464,3 +464,26 @@ def test_inconsistent_shapes_and_dtypes_are_rejected_by_the_sampler_and_the_spar
         with pytest.raises(RuntimeError, match=pattern):
             fn()
     assert tuple(m(tex(), grid, jac).shape) == (N, C, H, W)
+
+
+def test_kernel_gives_the_hand_derived_known_answers():
+    """Adaptive tap count, level selection / clipping, clip_grad and degenerate footprints of the HIP sampler against
+    answers derived on paper from the CUDA source (tests/mipmap_known_answers.py) -- through the C ABI and through
+    drtk_amd.mipmap_grid_sample."""
+    import drtk_amd
+    import mipmap_known_answers as K
+    from drtk_amd import capi
+
+    def via_capi(levels, grid, jac, max_aniso, padding, interp, align, force, clip):
+        return capi.mipmap_grid_sampler_2d([dev(t) for t in levels], dev(grid), dev(jac), max_aniso, padding, interp, align, force, clip).cpu()
+
+    def via_python_api(levels, grid, jac, max_aniso, padding, interp, align, force, clip):
+        assert padding == 1 and interp == 0
+        return drtk_amd.mipmap_grid_sample([dev(t) for t in levels], dev(grid), dev(jac), max_aniso, padding_mode="border",
+                                           align_corners=align, force_max_aniso=force, clip_grad=clip).cpu()
+
+    for dt in (th.float32, th.float64):
+        K.run_A(via_capi, dt)
+        K.run_B(via_capi, dt)
+    K.run_A(via_python_api)
+    K.run_B(via_python_api)

@@ -89,3 +89,17 @@ def test_uv_derivative_restatement_matches_reference_composite(tag):
     tol = (1e-6 if tag == "f32" else 1e-13) * max(1.0, float(ref.abs().max()))
     assert (got - ref).abs().max() <= tol
     assert float(ref[~mask].abs().sum()) == 0.0 and float(ref[mask].abs().min()) >= 0.0
+
+
+def test_restatement_gives_the_hand_derived_known_answers():
+    """The decisions the reference's PyTorch model cannot pin (it equals the CUDA kernel only for force_max_aniso=True,
+    clip_grad=False): adaptive tap count, level selection and its clipping, clip_grad, degenerate footprints -- against
+    numbers worked out on paper from mipmap_grid_sampler_kernel.cu:455-507 (tests/mipmap_known_answers.py)."""
+    import mipmap_known_answers as K
+    import torch as th
+
+    import oracle as O
+
+    for dt in (th.float32, th.float64):
+        K.run_A(O.mipmap_grid_sampler_2d, dt)
+        K.run_B(O.mipmap_grid_sampler_2d, dt)
