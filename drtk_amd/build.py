@@ -91,6 +91,23 @@ def build_ablation(force=False, verbose=True):
     return ABLATE_LIB
 
 
+def build_variant(out, defines, verbose=True):
+    """A/B helper for kernel work: the library compiled with extra -D switches into `out` (profiles/kernel_bench.py --lib)."""
+    objs, cmds = [], []
+    for s in KERNEL_SRCS:
+        o = os.path.join(CSRC, s + ".variant.o")
+        objs.append(o)
+        cmds.append([HIPCC, *HIP_FLAGS, *[f"-D{d}" for d in defines], "-c", os.path.join(CSRC, s), "-o", o])
+    with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
+        list(ex.map(_run, cmds))
+    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs])
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print(f"[drtk_amd] built {out} with {defines}")
+    return out
+
+
 def build_torch_ops(force=False, verbose=True):
     import torch
     from torch.utils import cpp_extension as ce
@@ -165,6 +182,9 @@ def dry_run():
 if __name__ == "__main__":
     if "--dry-run" in sys.argv:
         dry_run()
+    elif "--variant" in sys.argv:  # python drtk_amd/build.py --variant out.so DEFINE[=value] ...
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
     elif "--ablation" in sys.argv:
         build_ablation(force="--force" in sys.argv)
     else:

@@ -538,8 +538,12 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
   constexpr int kRows = 4;
   constexpr int kCap = kWave * 4 * 2 * 2; // pairs of two rows, both axes: the most one list build can hold
   __shared__ uint16_t s_list[kWaves][kCap];
-  __shared__ int32_t t_keys[kWaves][kTableSlots];
-  __shared__ TableAcc t_vals[kWaves][kTableSlots * 4];
+#ifndef DRTK_EDGE_SLOTS
+#define DRTK_EDGE_SLOTS 64 // A/B on one box (build.py --variant): 128 slots 0.810-0.815 ms, 64 slots 0.812-0.814 -- no difference
+#endif
+  constexpr int kSlots = DRTK_EDGE_SLOTS;
+  __shared__ int32_t t_keys[kWaves][kSlots];
+  __shared__ TableAcc t_vals[kWaves][kSlots * 4];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -558,8 +562,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
   const T* bary_n = bary_img + int64_t(n) * 3 * HW;
   T* grad_n = grad_v_pix + int64_t(n) * V * 3;
 
-  table_init(t_keys[wave]);
-  for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = 0;
+  table_init<kSlots>(t_keys[wave]);
+  for (int i = lane; i < kSlots * 4; i += kWave) t_vals[wave][i] = 0;
 
   // index rows y_base .. y_base+kRows of this lane's 4 pixels, one batch
   int32_t row[kRows + 1][4];
@@ -694,14 +698,14 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
           run_sums_rows16<T, 12>(g, dist);
           // components {axis, z}: x,z = 0 + c*2 ; y,z = 1 + c*1
           const int c_off = axis == 0 ? 0 : 1, c_step = axis == 0 ? 2 : 1;
-          if (tail && a_on) table_add<T, 3, 2>(t_keys[wave], t_vals[wave], 4, va, g, grad_n, 3, c_off, c_step);
-          if (tail && b_on) table_add<T, 3, 2>(t_keys[wave], t_vals[wave], 4, vb, g + 6, grad_n, 3, c_off, c_step);
+          if (tail && a_on) table_add<T, 3, 2, kSlots>(t_keys[wave], t_vals[wave], 4, va, g, grad_n, 3, c_off, c_step);
+          if (tail && b_on) table_add<T, 3, 2, kSlots>(t_keys[wave], t_vals[wave], 4, vb, g + 6, grad_n, 3, c_off, c_step);
         }
       }
     }
   }
   wave_lds_sync();
-  table_flush<T>(t_keys[wave], t_vals[wave], 4, 3, grad_n, 3, 0);
+  table_flush<T, TableAcc, kSlots>(t_keys[wave], t_vals[wave], 4, 3, grad_n, 3, 0);
 }
 
 constexpr int kStripRows = 2; // rows per wave

@@ -293,8 +293,9 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
     int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad, int strip) {
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPasses = kTileRows / kWaves;
-  __shared__ int32_t t_keys[HAS_VERT ? kWaves : 1][HAS_VERT ? kTableSlots : 1];
-  __shared__ TableAcc t_vals[HAS_VERT ? kWaves : 1][HAS_VERT ? kTableSlots * 4 : 1];
+  constexpr int kSlots = kTableSlots;
+  __shared__ int32_t t_keys[HAS_VERT ? kWaves : 1][HAS_VERT ? kSlots : 1];
+  __shared__ TableAcc t_vals[HAS_VERT ? kWaves : 1][HAS_VERT ? kSlots * 4 : 1];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -310,8 +311,8 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
   const T* bary_n = bary_img + int64_t(n) * 3 * HW;
 
   if constexpr (HAS_VERT) {
-    table_init(t_keys[wave]);
-    for (int i = lane; i < kTableSlots * 4; i += kWave) t_vals[wave][i] = 0;
+    table_init<kSlots>(t_keys[wave]);
+    for (int i = lane; i < kSlots * 4; i += kWave) t_vals[wave][i] = 0;
     wave_lds_sync();
   }
   auto load_tr = [&](int ps) -> int32_t {
@@ -375,13 +376,13 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
           for (int c = 0; c < CN; ++c) p[k * CN + c] = g[c] * B[k];
         }
         run_sums_rows16<T, 3 * CN>(p, dist);
-        if (tail && covered) table_add<T, 3, CN>(t_keys[wave], t_vals[wave], 4, cur, p, attr_grad_n, CN);
+        if (tail && covered) table_add<T, 3, CN, kSlots>(t_keys[wave], t_vals[wave], 4, cur, p, attr_grad_n, CN);
       }
     }
   }
   if constexpr (HAS_VERT) {
     wave_lds_sync();
-    table_flush<T>(t_keys[wave], t_vals[wave], 4, CN, attr_grad_n, CN, 0);
+    table_flush<T, TableAcc, kSlots>(t_keys[wave], t_vals[wave], 4, CN, attr_grad_n, CN, 0);
   }
 }
 

@@ -27,7 +27,12 @@
 namespace drtk_amd {
 
 constexpr int kRunPad = kWave + 4; // LDS row stride: rows stay 16-byte aligned (ds_read_b128), +4 staggers banks
-constexpr int kTableSlots = 64;    // vertices per wave-tile table (power of two)
+constexpr int kTableSlots = 64;    // vertices per wave-tile table (power of two).  The table functions take the size as a
+                                   // template argument; 128 slots were A/B-tested on ONE box (profiles/kernel_bench.py
+                                   // --lib, build.py --variant) for edge_scatter_pairs: 0.810-0.815 vs 0.812-0.814 ms --
+                                   // no difference (a first comparison across two gpurun boxes had shown 4 %: boxes
+                                   // differ by that much, so kernel variants are only ever compared within one call)
+constexpr int log2_of(int n) { return n <= 1 ? 0 : 1 + log2_of(n / 2); }
 constexpr int kTileRows = 16;      // a workgroup (4 waves) covers 64 x 16 pixels: 4 adjacent rows per wave
 constexpr int kTableProbes = 6;
 
@@ -45,14 +50,16 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int SLOTS = kTableSlots>
 __device__ __forceinline__ void table_init(int32_t* keys) { // wave-private table
-  for (int i = lane_id(); i < kTableSlots; i += kWave) keys[i] = -1;
+  for (int i = lane_id(); i < SLOTS; i += kWave) keys[i] = -1;
 }
 
 // Slot of vertex `vid` in the tile table (inserting it if needed); -1 if the table is full along
 // its probe sequence.  Safe under concurrent calls from the lanes of the owning wave.
+template <int SLOTS = kTableSlots>
 __device__ __forceinline__ int table_slot(int32_t* keys, int32_t vid) {
-  uint32_t h = (static_cast<uint32_t>(vid) * 2654435761u) >> 26; // 6 bits
+  uint32_t h = (static_cast<uint32_t>(vid) * 2654435761u) >> (32 - log2_of(SLOTS));
   for (int probe = 0; probe < kTableProbes; ++probe) {
     const int32_t cur = keys[h];
     if (cur == vid) return static_cast<int>(h);
@@ -60,7 +67,7 @@ __device__ __forceinline__ int table_slot(int32_t* keys, int32_t vid) {
       const int32_t old = atomicCAS(&keys[h], -1, vid);
       if (old == -1 || old == vid) return static_cast<int>(h);
     }
-    h = (h + 1) & (kTableSlots - 1);
+    h = (h + 1) & (SLOTS - 1);
   }
   return -1;
 }
@@ -189,11 +196,11 @@ __device__ __forceinline__ void scatter_runs(
 }
 
 // Wave-wide: add every occupied entry of the wave's table to dst_n[key * C_total + c_base + c], c < CC.
-template <typename T, typename A = TableAcc>
+template <typename T, typename A = TableAcc, int SLOTS = kTableSlots>
 __device__ __forceinline__ void table_flush(
     const int32_t* keys, const A* vals, int stride, int CC, T* __restrict__ dst_n, int C_total,
     int c_base) {
-  for (int e = lane_id(); e < kTableSlots * CC; e += kWave) {
+  for (int e = lane_id(); e < SLOTS * CC; e += kWave) {
     const int s = e / CC, c = e - s * CC;
     const int32_t key = keys[s];
     if (key >= 0) {
@@ -269,28 +276,28 @@ __device__ __forceinline__ void run_sums_rows16(T (&g)[J], int dist) {
 // First-probe lookup of K vertices at once: the K hash slots are read in one batch (one LDS round trip instead of K
 // dependent ones); a vertex found there -- the common case after the first pixels of a tile -- is done, the others go
 // through table_slot's probe-and-insert loop.
-template <int K>
+template <int K, int SLOTS = kTableSlots>
 __device__ __forceinline__ void table_slots(int32_t* keys, const int32_t (&vid)[K], int (&slot)[K]) {
   uint32_t h[K];
   int32_t cur[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    h[k] = (static_cast<uint32_t>(vid[k]) * 2654435761u) >> 26;
+    h[k] = (static_cast<uint32_t>(vid[k]) * 2654435761u) >> (32 - log2_of(SLOTS));
     cur[k] = keys[h[k]];
   }
 #pragma unroll
-  for (int k = 0; k < K; ++k) slot[k] = cur[k] == vid[k] ? static_cast<int>(h[k]) : table_slot(keys, vid[k]);
+  for (int k = 0; k < K; ++k) slot[k] = cur[k] == vid[k] ? static_cast<int>(h[k]) : table_slot<SLOTS>(keys, vid[k]);
 }
 
 // Tail lanes only: add `CC` components of each of the K corners `vid[k]` (values x[k * CC + c]) into the wave's vertex
 // table (LDS atomics: neighbouring triangles share vertices, so two tail lanes of one instruction may hit the same
 // entry), or straight into dst_n[vid * C_total + c] when the table has no room for the vertex.
-template <typename T, int K, int CC>
+template <typename T, int K, int CC, int SLOTS = kTableSlots>
 __device__ __forceinline__ void table_add(
     int32_t* keys, TableAcc* vals, int stride, const int32_t (&vid)[K], const T* x, T* __restrict__ dst_n, int C_total,
     int c_off = 0, int c_step = 1) { // value c of a corner goes to component c_off + c * c_step of the vertex
   int slot[K];
-  table_slots<K>(keys, vid, slot);
+  table_slots<K, SLOTS>(keys, vid, slot);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (slot[k] >= 0) {

@@ -24,9 +24,12 @@ ap.add_argument("--uvscale", type=float, default=1.0)
 ap.add_argument("--flags", default="0", help="comma list of ablation masks to time every kernel under; anything but 0 "
                 "needs the ablation build (python drtk_amd/build.py --ablation -> profiles/libdrtk_amd_ablate.so): the "
                 "product library has no such switches")
+ap.add_argument("--lib", default="", help="A/B a kernel variant: path of another build of the library (e.g. one compiled with a -D switch)")
 a = ap.parse_args()
+if a.lib:
+    capi.use_profiling_library(os.path.abspath(a.lib))
 ABLATE = a.flags != "0" or bool(os.environ.get("DRTK_ABLATE"))
-if ABLATE:
+if ABLATE and not a.lib:
     _path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdrtk_amd_ablate.so")
     assert os.path.isfile(_path), f"{_path} missing: run `python drtk_amd/build.py --ablation`"
     capi.use_profiling_library(_path)
