@@ -163,7 +163,9 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) void render_backwar
   const int n = blockIdx.y;
   const int tile = tile_index(strip);
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-  const int wave = threadIdx.x / kWave;
+  // wave-uniform by construction: saying so (readfirstlane) lets the row base pointers live in SGPRs and the loads take
+  // a 32-bit lane offset instead of a 64-bit address computed per lane
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int lane = threadIdx.x & (kWave - 1);
   const int x = txi * kWave + lane;
   const T* v_n = v + int64_t(n) * V * 3;

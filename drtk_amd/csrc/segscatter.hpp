@@ -253,15 +253,28 @@ __device__ __forceinline__ void run_rows16(int32_t tr, int& dist, bool& tail) {
   run_rows16_heads(tr != __shfl_up(tr, 1), dist, tail);
 }
 
+template <int D>
+__device__ __forceinline__ int dpp_row_shl_i32(int x) { // lane l <- lane l + D of its 16-lane row, 0 beyond the row
+  return __builtin_amdgcn_update_dpp(0, x, 0x100 | D, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float masked(float x, int m) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
+}
+__device__ __forceinline__ double masked(double x, int m) {
+  const unsigned long long mm = (static_cast<unsigned long long>(static_cast<unsigned>(m)) << 32) | static_cast<unsigned>(m);
+  return __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, x) & mm);
+}
+
+// Step D of the scan adds lane l - D's value to lane l iff l - D is still in l's run (dist[l] >= D).  The gate is
+// applied on the SOURCE side -- lane s is zeroed unless dist[s + D] >= D, a mask that is itself one row_shl of the
+// predicate and is shared by all J values -- so that the add can take its operand straight through DPP
+// (v_and + v_add_f32_dpp: 2 instructions per value and step instead of mov_dpp + cndmask + add).
 template <typename T, int J>
 __device__ __forceinline__ void run_sums_rows16(T (&g)[J], int dist) {
-#define DRTK_SCAN_STEP(D)                       \
-  {                                             \
-    const bool take = dist >= D;                \
-    _Pragma("unroll") for (int j = 0; j < J; ++j) { \
-      const T t = dpp_row_shr<D>(g[j]);         \
-      g[j] += take ? t : T(0);                  \
-    }                                           \
+#define DRTK_SCAN_STEP(D)                                                      \
+  {                                                                            \
+    const int m = dpp_row_shl_i32<D>(dist >= D ? -1 : 0);                      \
+    _Pragma("unroll") for (int j = 0; j < J; ++j) g[j] += dpp_row_shr<D>(masked(g[j], m)); \
   }
   DRTK_SCAN_STEP(1)
   DRTK_SCAN_STEP(2)
@@ -270,9 +283,6 @@ __device__ __forceinline__ void run_sums_rows16(T (&g)[J], int dist) {
 #undef DRTK_SCAN_STEP
 }
 
-// Tail lanes only: add `CC` components of corner `vid` into the wave's vertex table (LDS atomics: neighbouring
-// triangles share vertices, so two tail lanes of one instruction may hit the same entry), or straight into
-// dst_n[vid * C_total + c] when the table has no room for the vertex.
 // First-probe lookup of K vertices at once: the K hash slots are read in one batch (one LDS round trip instead of K
 // dependent ones); a vertex found there -- the common case after the first pixels of a tile -- is done, the others go
 // through table_slot's probe-and-insert loop.
