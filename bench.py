@@ -105,6 +105,7 @@ def kernel_table(C):
         "edge_scatter_pairs_kernel": ("edge_grad_backward_fused", 16), # index 4 + bary 12 read
         "interpolate_backward_wide_kernel": ("interpolate_backward", 4 * C + 28),   # grad_out 4C, index, bary read; bary_grad 12 written
         "interpolate_backward_kernel": ("interpolate_backward", 4 * C + 28),
+        "interpolate_backward_small_kernel": ("interpolate_backward", 4 * C + 28),   # C <= 4
         "render_backward_kernel": ("render_backward", 20),             # index 4, grad_depth 4, grad_bary 12 read
         "fill_bytes_kernel": ("zero-fill of gradients / workspaces", 0),
     }
@@ -441,6 +442,8 @@ def main():
         table = dict(kernel_table(C), **(TEXTURED_KERNELS if textured else {}))
         P = n_local * H * W
         kernels = {}
+        unknown = [site_name(x) for x in sites if site_name(x) not in table and not site_name(x).startswith("transform")]
+        assert not unknown, f"bench.py's kernel table does not know {unknown}: their time would be missing from t_ops"
         for site, (count, total_ms) in sites.items():
             k = site_name(site)
             rec = kernels.setdefault(k, {"launches_per_step": 0.0, "ms_per_step": 0.0})
