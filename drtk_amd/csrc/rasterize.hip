@@ -691,7 +691,7 @@ __device__ __forceinline__ double bcast(double x, int lane) {
 
 // Rasterize the triangles held one-per-lane (`valid` lanes; setup `s`, id `f`) into the LDS tile:
 // the wave walks the valid lanes, broadcasts one triangle at a time into SGPRs and covers its
-// bbox ∩ tile with 64-pixel stamps whose shape (sw x 64/sw, sw = pow2 >= bbox width) follows the
+// bbox ∩ tile with 64-pixel stamps whose shape (bw x floor(64 / bw), bw = the clipped bbox's width) follows the
 // bbox, so slivers and blobs both keep most lanes inside the box.  Coverage, depth and the packed
 // atomicMin are the reference's (rasterize_kernel.cu:117-161), evaluated per lane = per pixel.
 template <typename T, int TILE_SHIFT>
@@ -743,15 +743,19 @@ __device__ __forceinline__ void raster_lanes(
     const int bw = bcast(bx1, j) - ubx0 + 1;
     const unsigned long long id = static_cast<uint32_t>(bcast(f, j));
     // stamp shape
-    const int sw_log = bw <= 1 ? 0 : (32 - __builtin_clz(bw - 1)); // ceil(log2(bw)), <= TILE_SHIFT <= 6
-    const int lx = lane & ((1 << sw_log) - 1), ly = lane >> sw_log;
-    const int sh = kWave >> sw_log;
+    // stamp = bw x floor(64 / bw) pixels: exactly as wide as the clipped bbox (bw <= 64), so a 9-wide bbox gets 7 rows
+    // per pass instead of the 4 of a 16-wide power-of-two stamp.  lane -> (lx, ly) by one multiplication with 1 / bw:
+    // (lane + 1/2) / bw is never within 1 / (2 bw) >= 1/128 of an integer, far beyond the reciprocal's rounding
+    const float rbw = __builtin_amdgcn_rcpf(static_cast<float>(bw));
+    const int ly = static_cast<int>((static_cast<float>(lane) + 0.5f) * rbw);
+    const int lx = lane - ly * bw;
+    const int sh = __builtin_amdgcn_readfirstlane(static_cast<int>(64.5f * rbw)); // floor(64 / bw)
     const int x = ubx0 + lx;
     const T px = static_cast<T>(x);
     T ex[3]; // -(px - ax) * dy part, constant over rows
 #pragma unroll
     for (int k = 0; k < 3; ++k) ex[k] = (px - u.ax[k]) * u.dy[k];
-    if (lx < bw && !DRTK_DBG(dbg, 2)) {
+    if (ly < sh && !DRTK_DBG(dbg, 2)) {
       for (int y = uby0 + ly; y <= uby1; y += sh) {
         const T py = static_cast<T>(y);
         T b0 = ((py - u.ay[0]) * u.dx[0] - ex[0]) * u.s[0];
