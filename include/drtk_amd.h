@@ -56,7 +56,7 @@ extern "C" {
 #endif
 
 #define DRTK_AMD_VERSION_MAJOR 0
-#define DRTK_AMD_VERSION_MINOR 1
+#define DRTK_AMD_VERSION_MINOR 2
 
 typedef enum { DRTK_F32 = 0, DRTK_F64 = 1 } drtk_dtype_t;
 
