@@ -513,7 +513,12 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
       // 4. phase 2: run sums per (corner, channel) lane -> one 64-byte atomic request per corner and run
       //    (a per-vertex LDS table in front of the atomics was measured slower here, twice: 1.01 vs 0.83 ms in round 1;
       //    1.07 vs 0.65 ms in round 2 with a float table and slots looked up at run heads only -- the flush it saves is
-      //    0.11 ms, but the table's bookkeeping takes the kernel from 126 to 171 VGPRs, i.e. from 4 to 2 waves per SIMD)
+      //    0.11 ms, but the table's bookkeeping takes the kernel from 126 to 171 VGPRs, i.e. from 4 to 2 waves per SIMD.
+      //    A per-wave cache keyed by TRIANGLE instead -- the run loop is scalar, so the lookup is one v_cmp + s_ff1 on a
+      //    VGPR of keys and costs no registers (128 VGPRs, 4 waves kept) -- merges the rows of the wave's 64 x 4 pixels
+      //    and was also slower: 0.666 vs 0.654 ms with 16 float entries updated by read-add-write (the LDS round trip
+      //    sits on every run's critical path), 0.692 with 8, 0.74 with 16 double entries and fire-and-forget ds_add_f64
+      //    (51 KB of LDS per workgroup: 3 waves per SIMD))
       if (cov != 0 && !DRTK_DBG(dbg, 1)) {
         const T* sg = s_g[wave];
         const T* sb = s_b[wave];

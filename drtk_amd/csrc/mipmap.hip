@@ -160,24 +160,34 @@ struct Taps {
   T u, v, du, dv, a;
   int d1, n;
 };
+// the pixel's uv and uv Jacobian: one 8- and one 16-byte load (float)
 template <typename T>
-__device__ __forceinline__ Taps<T> setup_taps(
-    const T* __restrict__ grid, const T* __restrict__ vt, int64_t index, int inp_H, int inp_W, int mipmaps,
-    int max_aniso, bool force_max_aniso, bool clip_grad) {
-  Taps<T> t;
-  T dudx, dvdx, dudy, dvdy;
+struct PixelUV {
+  T u, v, dudx, dvdx, dudy, dvdy;
+};
+template <typename T>
+__device__ __forceinline__ PixelUV<T> load_pixel_uv(const T* __restrict__ grid, const T* __restrict__ vt, int64_t index) {
+  PixelUV<T> p;
   if constexpr (sizeof(T) == 4) {
     const float2 g = *reinterpret_cast<const float2*>(grid + index * 2);
     const float4 j = *reinterpret_cast<const float4*>(vt + index * 4);
-    t.u = g.x, t.v = g.y;
-    dudx = j.x, dvdx = j.y, dudy = j.z, dvdy = j.w;
+    p.u = g.x, p.v = g.y;
+    p.dudx = j.x, p.dvdx = j.y, p.dudy = j.z, p.dvdy = j.w;
   } else {
     const double2 g = *reinterpret_cast<const double2*>(grid + index * 2);
     const double2 j0 = *reinterpret_cast<const double2*>(vt + index * 4);
     const double2 j1 = *reinterpret_cast<const double2*>(vt + index * 4 + 2);
-    t.u = g.x, t.v = g.y;
-    dudx = j0.x, dvdx = j0.y, dudy = j1.x, dvdy = j1.y;
+    p.u = g.x, p.v = g.y;
+    p.dudx = j0.x, p.dvdx = j0.y, p.dudy = j1.x, p.dvdy = j1.y;
   }
+  return p;
+}
+template <typename T>
+__device__ __forceinline__ Taps<T> setup_taps(
+    const PixelUV<T>& uv, int inp_H, int inp_W, int mipmaps, int max_aniso, bool force_max_aniso, bool clip_grad) {
+  Taps<T> t;
+  t.u = uv.u, t.v = uv.v;
+  T dudx = uv.dudx, dvdx = uv.dvdx, dudy = uv.dudy, dvdy = uv.dvdy;
   // footprint lengths (:455-456, written with pow there): sqrt(a*a + b*b + 1e-12) with IEEE multiply and
   // sqrt -- the tap count below is a discontinuous function of them, so they are evaluated in the one
   // form that is bit-reproducible everywhere
@@ -212,6 +222,12 @@ __device__ __forceinline__ Taps<T> setup_taps(
     t.du = dudy, t.dv = dvdy;
   }
   return t;
+}
+template <typename T>
+__device__ __forceinline__ Taps<T> setup_taps(
+    const T* __restrict__ grid, const T* __restrict__ vt, int64_t index, int inp_H, int inp_W, int mipmaps,
+    int max_aniso, bool force_max_aniso, bool clip_grad) {
+  return setup_taps<T>(load_pixel_uv<T>(grid, vt, index), inp_H, inp_W, mipmaps, max_aniso, force_max_aniso, clip_grad);
 }
 
 // Bilinear corner geometry of one (tap, level): offsets (or -1 when out of bounds) and weights.
@@ -279,6 +295,24 @@ __device__ __forceinline__ void stage_levels(const LevelTable& lv, int mipmaps, 
   __syncthreads();
 }
 
+// Tap i of n sits at u + du * f, f = (i + 1.0) / (n + 1.0) * 2.0 - 1.0 in double (mipmap_grid_sampler_kernel.cu:497-499):
+// a double division per tap and pixel.  The workgroup computes the table of f for n <= 8 once -- with the same device
+// arithmetic, so the values are the same -- and the taps read it from LDS; larger n (max_aniso > 8) divide as before.
+#ifndef DRTK_MIP_TAPTAB
+#define DRTK_MIP_TAPTAB 8
+#endif
+constexpr int kTapTab = DRTK_MIP_TAPTAB;
+static_assert(kTapTab * kTapTab <= kBlock, "one table entry per thread");
+__device__ __forceinline__ void stage_tap_table(double* s_f) { // call before a __syncthreads()
+  if (threadIdx.x < kTapTab * kTapTab) {
+    const int i = threadIdx.x % kTapTab, n = threadIdx.x / kTapTab + 1;
+    s_f[threadIdx.x] = (i + 1.0) / (n + 1.0) * 2.0 - 1.0;
+  }
+}
+__device__ __forceinline__ double tap_f(const double* s_f, int i, int n) {
+  return n <= kTapTab ? s_f[(n - 1) * kTapTab + i] : (i + 1.0) / (n + 1.0) * 2.0 - 1.0;
+}
+
 template <typename T>
 using GlobalPtr = __attribute__((address_space(1))) T*;
 
@@ -311,13 +345,17 @@ using Pair = typename PairOf<T>::type;
 
 constexpr int kChBlock = 4; // channels accumulated in registers per sweep over the taps
 
-template <typename T, int MODE>
+// PAD: the padding mode as a compile-time constant (see mipmap_backward_tiled_kernel).
+template <typename T, int MODE, int PAD>
 __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grid, const T* __restrict__ vt, int64_t count, int C,
-    int64_t HW, int max_aniso, int padding, bool force_max_aniso, bool clip_grad, T* __restrict__ out, int strip) {
+    int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, T* __restrict__ out, int strip) {
+  constexpr int padding = PAD;
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  __shared__ double s_f[kTapTab * kTapTab];
+  stage_tap_table(s_f);
   stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
   const int64_t index = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
   if (index >= count) return;
@@ -328,24 +366,57 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
   T* out_px = out + n * C * HW + (index - n * HW);
   const T alpha_1 = t.a / t.n;
   const T alpha_2 = static_cast<T>((1.0 - t.a) / t.n);
+  // the pixel's two levels: sizes and base pointers once, not per tap (the level pointers come back from LDS as generic
+  // pointers: pin them to the global address space, otherwise every texel access is a flat_load)
+  int lv_h[2], lv_w[2];
+  GlobalPtr<const T> lv_base[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int d = s < n_lv ? t.d1 + s : 0;
+    lv_h[s] = s_h[d], lv_w[s] = s_w[d];
+    lv_base[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * C * (int64_t(lv_h[s]) * lv_w[s]));
+  }
 
   for (int c0 = 0; c0 < C; c0 += kChBlock) {
     T acc[kChBlock];
 #pragma unroll
     for (int cc = 0; cc < kChBlock; ++cc) acc[cc] = T(0);
     for (int i = 0; i < t.n; ++i) {
-      const double f = (i + 1.0) / (t.n + 1.0) * 2.0 - 1.0;
+      const double f = tap_f(s_f, i, t.n);
       const T x = t.u + static_cast<T>(t.du * f), y = t.v + static_cast<T>(t.dv * f);
-      for (int s = 0; s < n_lv; ++s) {
-        const int d = t.d1 + s;
-        const int h = s_h[d], w = s_w[d];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s >= n_lv) break;
+        const int h = lv_h[s], w = lv_w[s];
         const int64_t plane = int64_t(h) * w;
-        // the level pointers come back from LDS as generic pointers: pin them to the global address
-        // space, otherwise every texel access is a flat_load / flat_atomic
-        const GlobalPtr<const T> base = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + (n * C + c0) * plane);
+        const GlobalPtr<const T> base = lv_base[s] + c0 * plane;
         const T alpha = s == 0 ? alpha_2 : alpha_1;
+        // A level whose weight is exactly zero -- the second level of every magnified pixel (a == 0) -- contributes
+        // +-0 * texel to every channel: skipped, texels are taken to be finite (as in the backward pass).
+        if (alpha == T(0)) continue;
         if constexpr (MODE == 0) {
           const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
+          if ((q.o_nw | q.o_ne | q.o_sw | q.o_se) >= 0) {
+            // interior tap: two 8-byte loads and four products per channel, no per-corner branch
+            Pair<T> top[kChBlock], bot[kChBlock];
+#pragma unroll
+            for (int cc = 0; cc < kChBlock; ++cc) {
+              if (c0 + cc < C) {
+                top[cc] = *(GlobalPtr<const Pair<T>>)(base + cc * plane + q.o_nw);
+                bot[cc] = *(GlobalPtr<const Pair<T>>)(base + cc * plane + q.o_sw);
+              }
+            }
+#pragma unroll
+            for (int cc = 0; cc < kChBlock; ++cc) {
+              if (c0 + cc < C) {
+                acc[cc] += top[cc].x * q.nw * alpha;
+                acc[cc] += top[cc].y * q.ne * alpha;
+                acc[cc] += bot[cc].x * q.sw * alpha;
+                acc[cc] += bot[cc].y * q.se * alpha;
+              }
+            }
+            continue;
+          }
 #pragma unroll
           for (int cc = 0; cc < kChBlock; ++cc) {
             if (c0 + cc < C) {
@@ -523,20 +594,55 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
 // ds_add_f32 and flushed once, row-major, so the global atomics are coalesced and each touched texel costs
 // one request per tile instead of one per tap.  Corners outside the window, or on other levels, go to
 // global memory directly, so any uv field is handled.
+// Wave-wide min / max of an int, every lane active: four DPP steps leave each 16-lane row's result in all of its lanes,
+// four v_readlane + scalar min / max join the rows (a __shfl_xor ladder is six dependent ds_bpermute round trips).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
+  v = min(v, dpp_i32<0xB1>(v));  // quad_perm [1,0,3,2]
+  v = min(v, dpp_i32<0x4E>(v));  // quad_perm [2,3,0,1]
+  v = min(v, dpp_i32<0x141>(v)); // row_half_mirror
+  v = min(v, dpp_i32<0x140>(v)); // row_mirror
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
+  v = max(v, dpp_i32<0xB1>(v));
+  v = max(v, dpp_i32<0x4E>(v));
+  v = max(v, dpp_i32<0x141>(v));
+  v = max(v, dpp_i32<0x140>(v));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 constexpr int kTileW = 16;  // pixel tile
-constexpr int kWin = 32;    // texel window side
+#ifndef DRTK_MIP_WIN
+#define DRTK_MIP_WIN 32
+#endif
+#ifndef DRTK_MIP_WINB
+#define DRTK_MIP_WINB DRTK_MIP_WIN
+#endif
+constexpr int kWin = DRTK_MIP_WIN;   // texel window side on the tile's finest level
+constexpr int kWinB = DRTK_MIP_WINB; // ... and on the next one (even: the flush reads cells in pairs)
 constexpr int kWinLevels = 2;
+#ifndef DRTK_MIP_WINPAD
+#define DRTK_MIP_WINPAD 0
+#endif
+// Extra cells per window row and per channel plane (even: the flush reads cells in 16-byte pairs).  A 32-cell row is 256
+// bytes, one sweep of the 64 LDS banks, so the south corners of a tap share the banks of its north corners and so do the
+// pixel rows of a wave -- SQ_LDS_BANK_CONFLICT + SQ_LDS_ADDR_CONFLICT are more than half of this kernel's LDS-active
+// cycles -- but the LDS pipe is only ~11 % busy and padding the strides to 34 cells bought nothing: 2.23 vs 2.17 ms on the
+// textured benchmark, 4.65 vs 4.58 and 11.9 vs 11.8 ms on the minified scenes of profiles/kernel_bench.py.  Neither did
+// walking the 4C cells of a tap in a per-lane rotated order, which removes the same-address meetings of neighbouring
+// pixels on a magnified texture (2.16 vs 2.23 ms).  Kept as a switch for the next look at this kernel.
+constexpr int kWinPad = DRTK_MIP_WINPAD;
+__host__ __device__ constexpr int win_side(int l) { return l == 0 ? kWin : kWinB; }
+__host__ __device__ constexpr int win_stride(int l) { return win_side(l) + kWinPad; }
+__host__ __device__ constexpr int win_cells(int l) { return win_side(l) * win_stride(l) + kWinPad; } // per channel (the channels of a cell in different banks, too)
+__host__ __device__ constexpr int win_cells_before(int l) { return l == 0 ? 0 : win_cells(0) + (l - 1) * win_cells(1); } // per channel
+constexpr int kWinCells = win_cells_before(kWinLevels);
 // `dbg` (diagnostics, profiles/kernel_bench.py --flags): 1 = no texture-gradient accumulation, 2 = no texel reads,
 // 4 = no flush.  Where the 6.0 ms of the bench shape go (finer timing-only variants, r01): the global-atomic fallback for
 // corners outside the windows ~1.5 ms, the four LDS adds ~0.8 ms, the flush 0.5 ms, texel reads 0.2 ms, everything else
@@ -547,11 +653,16 @@ constexpr int kWinLevels = 2;
 // Measured dead end: the same LDS split 2048 / 768 / 256 cells over the levels with every window shaped like its tile's
 // bounding box -- 1-4 % (6.06 -> 6.02 ms at 1 texel/px, 11.5 -> 11.0 at 4), one outlier pixel stretches the box.
 
-template <typename T>
+// PAD / ALIGN: padding mode and align_corners as compile-time constants (the coordinate pipeline of every tap branches on
+// them: SQ counters of the runtime-parameter version showed 490 scalar and 950 vector instructions per wave).
+template <typename T, int PAD, bool ALIGN>
 __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid,
-    const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso, int padding, bool align_corners,
+    const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, int strip, int dbg) {
+  constexpr int padding = PAD;
+  constexpr bool align_corners = ALIGN;
+  __shared__ double s_f[kTapTab * kTapTab];
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
@@ -561,18 +672,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   // were this kernel's floor.  Dynamic LDS sized by the launch (C = 3: 72 KB -> 2 workgroups/CU).
   extern __shared__ __attribute__((aligned(16))) unsigned char s_win_raw[];
   double* const s_win = reinterpret_cast<double*>(s_win_raw);
-  const int win_lstride = C * kWin * kWin;
-  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
   const int tid = threadIdx.x;
-  if (tid == 0) s_ref = kMaxLevels;
-  if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
-  {
-    double2* w2 = reinterpret_cast<double2*>(s_win);
-    const double2 z = {0.0, 0.0};
-    for (int i = tid; i < kWinLevels * win_lstride / 2; i += kBlock) w2[i] = z;
-  }
-  __syncthreads();
-
   const int n = blockIdx.y;
   const int tile = tile_index(strip);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -580,38 +680,92 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   const bool valid = px < W && py < H;
   const int64_t HW = int64_t(H) * W;
   const int64_t index = int64_t(n) * HW + int64_t(py) * W + px;
+  // the pixel's upstream gradient, all channels in one batch of loads (C <= 4 here)
+  T go[4] = {T(0), T(0), T(0), T(0)};
+  if (valid) {
+    const T* gout_px = grad_out + int64_t(n) * C * HW + (int64_t(py) * W + px);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < C) go[c] = gout_px[int64_t(c) * HW];
+    }
+  }
+  // (uv and Jacobian are requested in the same batch: one memory round trip for everything the pixel reads but texels)
+  PixelUV<T> uv = {};
+  if (valid) uv = load_pixel_uv<T>(grid, vt, index);
+  // A pixel whose upstream gradient is zero in every channel (the masked background of a render) adds nothing to the
+  // texture and has a zero grid gradient: it skips its tap set-up, and a tile of such pixels -- 44 % of the tiles of the
+  // textured benchmark -- leaves here, before any window is touched.
+  const bool has_go = go[0] != T(0) || go[1] != T(0) || go[2] != T(0) || go[3] != T(0);
+  if (!__syncthreads_or(has_go)) {
+    if (valid) grad_grid[index * 2 + 0] = T(0), grad_grid[index * 2 + 1] = T(0);
+    return;
+  }
+  stage_tap_table(s_f);
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
+  if (tid == 0) s_ref = kMaxLevels;
+  if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
+  {
+    double2* w2 = reinterpret_cast<double2*>(s_win);
+    const double2 z = {0.0, 0.0};
+    for (int i = tid; i < C * kWinCells / 2; i += kBlock) w2[i] = z;
+  }
+  __syncthreads();
+
   Taps<T> t = {};
-  if (valid) t = setup_taps<T>(grid, vt, index, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+  if (has_go) t = setup_taps<T>(uv, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
   const int n_lv = mipmaps > 1 ? 2 : 1;
+  const T alpha_1 = has_go ? t.a / t.n : T(0);
+  const T alpha_2 = has_go ? static_cast<T>((1.0 - t.a) / t.n) : T(0);
+  // A (pixel, level) whose weighted upstream gradient is zero in every channel adds nothing anywhere (every term is
+  // +-0 * finite): the masked background of a silhouette tile, and the second level of a magnified pixel (a == 0).
+  // Such pairs neither place the windows -- a background pixel's uv is (0, 0) on level 0, far from the tile's texels
+  // -- nor run their taps.
+  bool live[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const T alpha = s == 0 ? alpha_2 : alpha_1;
+    live[s] = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) live[s] = live[s] || (go[c] * alpha != T(0));
+    live[s] = live[s] && s < n_lv;
+  }
   {
     // one LDS atomic per wave, not per lane: same-address LDS atomics are served one lane at a time
-    const int d_min = wave_min_i32(valid ? t.d1 : kMaxLevels);
+    const int d_min = wave_min_i32(live[0] ? t.d1 : live[1] ? t.d1 + 1 : kMaxLevels);
     if ((tid & (kWave - 1)) == 0) atomicMin(&s_ref, d_min);
   }
   __syncthreads();
   const int ref = s_ref;
   auto tap_xy = [&](int i, T& x, T& y) {
-    const double f = (i + 1.0) / (t.n + 1.0) * 2.0 - 1.0;
+    const double f = tap_f(s_f, i, t.n);
     x = t.u + static_cast<T>(t.du * f);
     y = t.v + static_cast<T>(t.dv * f);
   };
   // window origins: the taps of a pixel are collinear, so their extreme texels are those of the first and
-  // the last tap
+  // the last tap.  ANY origin is correct -- a corner is windowed iff its exact cell lies inside, tested below -- so the
+  // origin comes from a short form of the coordinate pipeline: unnormalise, clamp to the level, floor (the exact
+  // north-west texel for zeros / border padding; under reflection padding taps beyond the border miss the window).
+  auto texel_floor = [&](T coord, int size) -> int {
+    T unused;
+    const T c = unnormalize(coord, size, align_corners, &unused);
+    const T lo = padding == 0 ? T(-1) : T(0);
+    return static_cast<int>(floor(fmin(fmax(c, lo), static_cast<T>(size - 1)))); // fmax(NaN, lo) = lo
+  };
   {
     int lo_x[kWinLevels], lo_y[kWinLevels];
 #pragma unroll
     for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX;
-    if (valid) {
+    if (live[0] || live[1]) {
       for (int e = 0; e < 2; ++e) {
         T x, y;
         tap_xy(e == 0 ? 0 : t.n - 1, x, y);
         for (int s = 0; s < n_lv; ++s) {
           const int l = t.d1 + s - ref;
-          if (l < kWinLevels) {
-            const Quad<T> q = bilinear_quad<T>(x, y, s_h[t.d1 + s], s_w[t.d1 + s], padding, align_corners);
+          if (l < kWinLevels && live[s]) {
+            const int ox = texel_floor(x, s_w[t.d1 + s]), oy = texel_floor(y, s_h[t.d1 + s]);
 #pragma unroll
             for (int k = 0; k < kWinLevels; ++k) {
-              if (k == l) lo_x[k] = min(lo_x[k], q.ix_nw), lo_y[k] = min(lo_y[k], q.iy_nw);
+              if (k == l) lo_x[k] = min(lo_x[k], ox), lo_y[k] = min(lo_y[k], oy);
             }
           }
         }
@@ -629,77 +783,153 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   __syncthreads();
 
   if (valid) {
-    // the pixel's upstream gradient, all channels in one batch of loads (C <= 4 here)
-    T go[4] = {T(0), T(0), T(0), T(0)};
-    {
-      const T* gout_px = grad_out + int64_t(n) * C * HW + (int64_t(py) * W + px);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c < C) go[c] = gout_px[int64_t(c) * HW];
-      }
-    }
-    const T alpha_1 = t.a / t.n;
-    const T alpha_2 = static_cast<T>((1.0 - t.a) / t.n);
     T acc_x = T(0), acc_y = T(0);
-    for (int i = 0; i < t.n; ++i) {
+    // the pixel's two levels: sizes and base pointers once, not per tap
+    int lv_h[2], lv_w[2], lv_plane[2];
+    GlobalPtr<const T> lv_inp[2];
+    GlobalPtr<T> lv_ginp[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int d = live[s] ? t.d1 + s : 0;
+      lv_h[s] = s_h[d], lv_w[s] = s_w[d];
+      lv_plane[s] = lv_h[s] * lv_w[s]; // < 2^31, checked by fill_table()
+      lv_inp[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * C * lv_plane[s]);
+      lv_ginp[s] = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * lv_plane[s]);
+    }
+    for (int i = 0; (live[0] || live[1]) && i < t.n; ++i) {
       T x, y;
       tap_xy(i, x, y);
-      for (int s = 0; s < n_lv; ++s) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (!live[s]) continue;
         const int d = t.d1 + s;
-        const int h = s_h[d], w = s_w[d];
-        const int64_t plane = int64_t(h) * w;
-        const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * C * plane);
-        const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+        const int h = lv_h[s], w = lv_w[s];
+        const int64_t plane = lv_plane[s];
+        const GlobalPtr<const T> inp = lv_inp[s];
+        const GlobalPtr<T> ginp = lv_ginp[s];
         const T alpha = s == 0 ? alpha_2 : alpha_1;
         const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
         const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
         // window cell of the north-west corner (the other three are +1 in x / y), or -1 if not windowed
         const int l = d - ref;
         int cell = -1;
+        const int side = win_side(l), stride = win_stride(l), chan = win_cells(l);
         if (l < kWinLevels) {
           const int wx = q.ix_nw - s_ox[l], wy = q.iy_nw - s_oy[l];
-          if (wx >= 0 && wx < kWin - 1 && wy >= 0 && wy < kWin - 1) cell = wy * kWin + wx;
+          if (wx >= 0 && wx < side - 1 && wy >= 0 && wy < side - 1) cell = wy * stride + wx;
         }
-        T gix = T(0), giy = T(0);
+        T g[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (c >= C) break;
-          const GlobalPtr<const T> p = inp + c * plane;
-          const T gOut = go[c] * alpha;
-          if (gOut != T(0)) { // a zero upstream gradient (masked background) adds nothing
-            if (DRTK_DBG(dbg, 1)) {
-            } else if (cell >= 0) {
-              double* wp = s_win + l * win_lstride + c * (kWin * kWin) + cell;
-              if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * gOut));
-              if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * gOut));
-              if (q.o_sw >= 0) lds_add(wp + kWin, static_cast<double>(q.sw * gOut));
-              if (q.o_se >= 0) lds_add(wp + kWin + 1, static_cast<double>(q.se * gOut));
-            } else {
-              const GlobalPtr<T> gp = ginp + c * plane;
-              if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * gOut);
-              if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * gOut);
-              if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * gOut);
-              if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gOut);
+        for (int c = 0; c < 4; ++c) g[c] = c < C ? go[c] * alpha : T(0);
+        T gix = T(0), giy = T(0);
+        // Interior taps -- all four corners inside the level, i.e. nearly all of them -- take a straight-line path: the
+        // per-corner validity tests of the general form below each cost a divergent branch (the general form compiled to
+        // 234 exec-mask regions), while here a tap is 2C 8-byte texel loads, 4C adds and the grid-gradient products with no
+        // branch but window / fallback.  A channel whose weighted gradient is zero adds +-0 (the general form skips it).
+        if ((q.o_nw | q.o_ne | q.o_sw | q.o_se) >= 0) {
+          Pair<T> top[4], bot[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            top[c] = bot[c] = Pair<T>{T(0), T(0)};
+            if (c < C && !DRTK_DBG(dbg, 2)) {
+              top[c] = *(GlobalPtr<const Pair<T>>)(inp + c * plane + q.o_nw);
+              bot[c] = *(GlobalPtr<const Pair<T>>)(inp + c * plane + q.o_sw);
             }
           }
-          // texel values for the grid gradient: the two texels of a row in one 8-byte load when both exist
-          T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
-          if (gOut != T(0) && !DRTK_DBG(dbg, 2)) { // with a zero upstream gradient every term below is +-0 * finite
+          if (DRTK_DBG(dbg, 1)) {
+          } else if (cell >= 0) {
+            double* wp = s_win + C * win_cells_before(l) + cell;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (c >= C) break;
+              lds_add(wp + c * chan, static_cast<double>(q.nw * g[c]));
+              lds_add(wp + c * chan + 1, static_cast<double>(q.ne * g[c]));
+              lds_add(wp + c * chan + stride, static_cast<double>(q.sw * g[c]));
+              lds_add(wp + c * chan + stride + 1, static_cast<double>(q.se * g[c]));
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (c >= C) break;
+              const GlobalPtr<T> gp = ginp + c * plane;
+              atomic_add_g1(gp + q.o_nw, q.nw * g[c]);
+              atomic_add_g1(gp + q.o_ne, q.ne * g[c]);
+              atomic_add_g1(gp + q.o_sw, q.sw * g[c]);
+              atomic_add_g1(gp + q.o_se, q.se * g[c]);
+            }
+          }
+          const T fy1 = iy_se - q.iy, fy0 = q.iy - q.iy_nw, fx1 = ix_se - q.ix, fx0 = q.ix - q.ix_nw;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c >= C) break;
+            const T gOut = g[c];
+            // with a zero upstream gradient every term is +-0 * finite: the texels count as 0
+            const T v_nw = gOut != T(0) ? top[c].x : T(0), v_ne = gOut != T(0) ? top[c].y : T(0);
+            const T v_sw = gOut != T(0) ? bot[c].x : T(0), v_se = gOut != T(0) ? bot[c].y : T(0);
+            gix -= v_nw * fy1 * gOut;
+            giy -= v_nw * fx1 * gOut;
+            gix += v_ne * fy1 * gOut;
+            giy -= v_ne * fx0 * gOut;
+            gix -= v_sw * fy0 * gOut;
+            giy += v_sw * fx1 * gOut;
+            gix += v_se * fy0 * gOut;
+            giy += v_se * fx0 * gOut;
+          }
+        } else {
+        // General form.  One memory round trip per (tap, level): the texels of ALL channels are requested first
+        // row in one 8-byte load when both exist), the texture-gradient adds -- which wait for nothing -- are issued
+        // under them, and the grid gradient consumes the texels last.
+        T v[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c][0] = v[c][1] = v[c][2] = v[c][3] = T(0);
+        if (!DRTK_DBG(dbg, 2)) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c >= C) break;
+            const GlobalPtr<const T> p = inp + c * plane;
             if (q.o_nw >= 0 && q.o_ne >= 0) {
               const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_nw);
-              v_nw = t2.x, v_ne = t2.y;
+              v[c][0] = t2.x, v[c][1] = t2.y;
             } else {
-              if (q.o_nw >= 0) v_nw = p[q.o_nw];
-              if (q.o_ne >= 0) v_ne = p[q.o_ne];
+              if (q.o_nw >= 0) v[c][0] = p[q.o_nw];
+              if (q.o_ne >= 0) v[c][1] = p[q.o_ne];
             }
             if (q.o_sw >= 0 && q.o_se >= 0) {
               const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_sw);
-              v_sw = t2.x, v_se = t2.y;
+              v[c][2] = t2.x, v[c][3] = t2.y;
             } else {
-              if (q.o_sw >= 0) v_sw = p[q.o_sw];
-              if (q.o_se >= 0) v_se = p[q.o_se];
+              if (q.o_sw >= 0) v[c][2] = p[q.o_sw];
+              if (q.o_se >= 0) v[c][3] = p[q.o_se];
             }
           }
+        }
+        if (!DRTK_DBG(dbg, 1)) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c >= C) break;
+            if (g[c] == T(0)) continue; // a zero upstream gradient (masked channel) adds nothing
+            if (cell >= 0) {
+              double* wp = s_win + C * win_cells_before(l) + c * chan + cell;
+              if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * g[c]));
+              if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * g[c]));
+              if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * g[c]));
+              if (q.o_se >= 0) lds_add(wp + stride + 1, static_cast<double>(q.se * g[c]));
+            } else {
+              const GlobalPtr<T> gp = ginp + c * plane;
+              if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * g[c]);
+              if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * g[c]);
+              if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * g[c]);
+              if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * g[c]);
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c >= C) break;
+          const T gOut = g[c];
+          // with a zero upstream gradient every term below is +-0 * finite: the texels count as 0
+          const T v_nw = gOut != T(0) ? v[c][0] : T(0), v_ne = gOut != T(0) ? v[c][1] : T(0);
+          const T v_sw = gOut != T(0) ? v[c][2] : T(0), v_se = gOut != T(0) ? v[c][3] : T(0);
           if (q.o_nw >= 0) {
             gix -= v_nw * (iy_se - q.iy) * gOut;
             giy -= v_nw * (ix_se - q.ix) * gOut;
@@ -717,6 +947,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
             giy += v_se * (q.ix - q.ix_nw) * gOut;
           }
         }
+        } // general form
         acc_x += q.mx * gix;
         acc_y += q.my * giy;
       }
@@ -735,12 +966,13 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
     const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
     for (int c = 0; c < C; ++c) {
       // two cells per lane and step (one 16-byte LDS read); a row of 32 cells = 16 consecutive lanes
-      const double2* win2 = reinterpret_cast<const double2*>(s_win + l * win_lstride + c * (kWin * kWin));
-      for (int i2 = tid; i2 < kWin * kWin / 2; i2 += kBlock) {
+      const int stride = win_stride(l), chan = win_cells(l);
+      const double2* win2 = reinterpret_cast<const double2*>(s_win + C * win_cells_before(l) + c * chan);
+      for (int i2 = tid; i2 < (chan - kWinPad) / 2; i2 += kBlock) { // the pad cells at the end of each row are never written: 0
         const double2 q = win2[i2];
         const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
         const int i = i2 * 2;
-        const int gx = s_ox[l] + (i & (kWin - 1)), gy = s_oy[l] + i / kWin;
+        const int gx = s_ox[l] + i % stride, gy = s_oy[l] + i / stride;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
@@ -788,17 +1020,20 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
   if (!grid || !vt_dxdy_img || !out) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid_dim(static_cast<unsigned>(ceil_div(count, kBlock)));
-#define LAUNCH(T, MODE)                                                                                   \
-  DRTK_LAUNCH(                                                                                     \
-      (mipmap_forward_kernel<T, MODE>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grid), \
-      static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, force_max_aniso != 0,  \
-      clip_grad != 0, static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
+#define LAUNCH_P(T, MODE, PAD)                                                                                 \
+  DRTK_LAUNCH(                                                                                                 \
+      (mipmap_forward_kernel<T, MODE, PAD>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grid), \
+      static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, force_max_aniso != 0, clip_grad != 0, \
+      static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
+#define LAUNCH(T, MODE)                                                                    \
+  if (padding_mode == 0) LAUNCH_P(T, MODE, 0); else if (padding_mode == 1) LAUNCH_P(T, MODE, 1); else LAUNCH_P(T, MODE, 2)
   if (dtype == DRTK_F32) {
-    if (interpolation_mode == 0) LAUNCH(float, 0); else LAUNCH(float, 2);
+    if (interpolation_mode == 0) { LAUNCH(float, 0); } else { LAUNCH(float, 2); }
   } else {
-    if (interpolation_mode == 0) LAUNCH(double, 0); else LAUNCH(double, 2);
+    if (interpolation_mode == 0) { LAUNCH(double, 0); } else { LAUNCH(double, 2); }
   }
 #undef LAUNCH
+#undef LAUNCH_P
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }
@@ -828,11 +1063,18 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   if (!grid || !vt_dxdy_img || !grad_grid || (C > 0 && !grad_out)) return DRTK_ERR_INVALID_ARGUMENT;
   if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileW));
-    DRTK_LAUNCH(
-        (mipmap_backward_tiled_kernel<float>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)),
-        dim3(kBlock), sizeof(double) * kWinLevels * C * kWin * kWin, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid),
-        static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, padding_mode, align_corners != 0,
-        force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), xcd_strip(tiles_x), debug_flags());
+#define TILED(PAD, ALIGN)                                                                                                \
+  DRTK_LAUNCH(                                                                                                           \
+      (mipmap_backward_tiled_kernel<float, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      dim3(kBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const float*>(grad_out),                 \
+      static_cast<const float*>(grid), static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
+      force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), xcd_strip(tiles_x), debug_flags())
+    if (align_corners) {
+      if (padding_mode == 0) TILED(0, true); else if (padding_mode == 1) TILED(1, true); else TILED(2, true);
+    } else {
+      if (padding_mode == 0) TILED(0, false); else if (padding_mode == 1) TILED(1, false); else TILED(2, false);
+    }
+#undef TILED
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;
   }

@@ -24,6 +24,8 @@ ap.add_argument("--uvscale", type=float, default=1.0)
 ap.add_argument("--flags", default="0", help="comma list of ablation masks to time every kernel under; anything but 0 "
                 "needs the ablation build (python drtk_amd/build.py --ablation -> profiles/libdrtk_amd_ablate.so): the "
                 "product library has no such switches")
+ap.add_argument("--check", action="store_true", help="also compare interpolate_backward of the bound library with a "
+                "torch formulation of the same sums on the GPU (for --lib variants, which no test suite binds to)")
 ap.add_argument("--lib", default="", help="A/B a kernel variant: path of another build of the library (e.g. one compiled with a -D switch)")
 a = ap.parse_args()
 if a.lib:
@@ -119,3 +121,25 @@ if os.environ.get("DRTK_ABLATE"):
         th.cuda.synchronize()
         print(f"ablate {os.environ['DRTK_ABLATE']} flags={flags:2d}: {e0.elapsed_time(e1) / 5:.3f} ms")
     set_flags(0)
+
+if a.check:
+    ag, bg = capi.interpolate_backward(go, attr, vi, index, bary, True, True)
+    N, V, C = attr.shape
+    fg = index != -1
+    tri = vi.long()[index.clamp(min=0).long()] if vi.dim() == 2 else None
+    assert tri is not None
+    worst = 0.0
+    for n in range(N):
+        ref = th.zeros(V, C, device=dev, dtype=th.float64)
+        m = fg[n].reshape(-1)
+        gn = go[n].reshape(C, -1).t()[m].double()
+        refb = th.zeros(3, H * W, device=dev, dtype=th.float64)
+        for k in range(3):
+            ids = tri[n].reshape(-1, 3)[m, k]
+            ref.index_add_(0, ids, gn * bary[n, k].reshape(-1)[m].double()[:, None])
+            refb[k, m] = (gn * attr[n].double()[ids]).sum(1)
+        e_a = (ag[n].double() - ref).abs().max().item() / ref.abs().max().item()
+        e_b = (bg[n].reshape(3, -1).double() - refb).abs().max().item() / refb.abs().max().item()
+        worst = max(worst, e_a, e_b)
+    print(f"check interpolate_backward: worst error / max magnitude = {worst:.2e}")
+    assert worst < 2e-5, worst

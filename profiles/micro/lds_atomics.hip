@@ -8,6 +8,8 @@
 //      of the instruction share an address)
 //   E  ds_add_rtn_f32 (returning)
 //   F  ds_add_f64
+//   G  ds_add_f64 with the 64 lanes in groups of g on one address each (64 / g distinct addresses per instruction): what
+//      the sampler's texture-gradient windows see when neighbouring pixels hit the same texel
 // Output: nanoseconds per wave-instruction and lane-operations per clock per CU at 2.4 GHz.
 //   hipcc --offload-arch=gfx950 -O3 -o lds_atomics lds_atomics.hip && ./lds_atomics
 #include <hip/hip_runtime.h>
@@ -17,7 +19,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float* out, int iters, int active, int same) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, int active, int same, int group = 1) {
   __shared__ float tab[4][1024];
   __shared__ double tabd[4][256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -37,6 +39,10 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int active, int 
         if (MODE == 2) __hip_atomic_fetch_add((LdsU)&tab[wave][a], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (MODE == 3) { LdsF q = (LdsF)&tab[wave][a]; *q = *q + 1.0f; }
         if (MODE == 4) acc += __hip_atomic_fetch_add((LdsF)&tab[wave][a], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (MODE == 6) {
+          const int ag = ((lane / group) * 17 + (i * 8 + j) * 5) & 255;
+          __hip_atomic_fetch_add((LdsD)&tabd[wave][ag], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         if (MODE == 5) __hip_atomic_fetch_add((LdsD)&tabd[wave][a & 255], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
@@ -49,14 +55,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int active, int 
 }
 
 template <int MODE>
-void run(const char* name, float* out, int active, int same) {
+void run(const char* name, float* out, int active, int same, int group = 1) {
   const int iters = 2000, blocks = 256 * 8;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 10, active, same);
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 10, active, same, group);
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, active, same);
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, active, same, group);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -76,5 +82,9 @@ int main() {
   for (int active : {64, 8}) run<3>("D read-add-write", out, active, 0);
   for (int active : {64, 8}) run<4>("E ds_add_rtn_f32", out, active, 0);
   for (int active : {64, 8}) run<5>("F ds_add_f64", out, active, 0);
+  for (int group : {1, 2, 4, 8, 16, 64}) {
+    printf("group of %2d lanes per address: ", group);
+    run<6>("G ds_add_f64", out, 64, 0, group);
+  }
   return 0;
 }

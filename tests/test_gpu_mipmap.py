@@ -79,6 +79,41 @@ def test_capi_matches_oracle_in_every_mode(mode, padding, flags):
         close(a, b, f"grad level {i}")
 
 
+@pytest.mark.parametrize("padding", [0, 1, 2])
+@pytest.mark.parametrize("C", [3, 4])
+def test_masked_upstream_gradients_magnified_pixels_and_tap_counts_beyond_the_tap_table(padding, C):
+    """What the sampler kernels skip or look up must not change a result (oracle: nothing is skipped there).
+    * upstream gradient zero in a whole 16 x 16 tile (the tiled backward leaves early), in part of a tile and in
+      scattered pixels (dead pixels neither place the LDS windows nor run their taps), and in one channel everywhere;
+    * a magnified band (footprint < 1 texel: a == 0, the second level has weight zero and is skipped by both passes)
+      next to a minified one;
+    * max_aniso = 12 with footprints of ratio up to ~20: tap counts above the 8 rows of the LDS table of tap offsets."""
+    import oracle as O
+    from drtk_amd import capi
+
+    H, W = 40, 48
+    tex, grid, vt, gout = mipmap_inputs(300 + 7 * padding + C, 2, C, 64, 5, H, W, jscale=0.03)
+    vt = vt.clone()
+    vt[:, :, : W // 3] *= 0.02           # magnified: every pixel on level 0 with a == 0
+    vt[:, :, W // 3: 2 * W // 3, 0] *= 5  # strongly anisotropic: many taps
+    gout = gout.clone()
+    gout[:, :, :16, :16] = 0              # a dead tile
+    gout[:, :, 16:32, 20:40] = 0          # parts of four tiles
+    gout[:, 1] = 0                        # a dead channel
+    g = th.Generator().manual_seed(5)
+    gout *= (th.rand(2, 1, H, W, generator=g) > 0.2)  # scattered dead pixels
+    for align, force, clip in [(False, False, False), (True, False, True), (False, True, False)]:
+        want = O.mipmap_grid_sampler_2d(tex, grid, vt, 12, padding, 0, align, force, clip)
+        got = capi.mipmap_grid_sampler_2d(dev(tex), dev(grid), dev(vt), 12, padding, 0, align, force, clip)
+        close(got, want, "forward")
+        wl, wg = O.mipmap_grid_sampler_2d_backward(gout, tex, grid, vt, 12, padding, 0, align, force, clip)
+        gl, gg = capi.mipmap_grid_sampler_2d_backward(dev(gout), dev(tex), dev(grid), dev(vt), 12, padding, 0, align, force, clip)
+        close(gg, wg, "grad grid", atol=2e-5)
+        assert float(gg[:, :16, :16].abs().max()) == 0.0
+        for i, (a, b) in enumerate(zip(gl, wl)):
+            close(a, b, f"grad level {i}")
+
+
 def test_f64_and_odd_channel_counts_match_oracle():
     import oracle as O
     from drtk_amd import capi
