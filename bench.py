@@ -409,6 +409,41 @@ def main():
             "value": round(n_total * H * W * args.steps / elapsed_fused / 1e6, 2),
             "ms_per_step": round(elapsed_fused / args.steps * 1e3, 4), "loss": round(float(loss_fused.detach()), 6)}}
 
+    # the operators alone (reference API, wall clock): the same forward, and a backward pass seeded with RESIDENT upstream
+    # gradients instead of the user-side mask and loss -- what the step costs without the PyTorch glue around the path
+    if not textured and world == 1:
+        gsrc = th.Generator(device=dev).manual_seed(1)
+        with th.no_grad():
+            v_pix0 = transform(v_world[None], campos, camrot, focal, princpt)
+            fg = (drtk_amd.rasterize(v_pix0, vi, H, W) != -1)[:, None]
+        g_img = (th.rand(n_local, C, H, W, device=dev, generator=gsrc) * 2 - 1) * fg  # zero on the background, like a masked loss's
+        g_depth = th.full((n_local, H, W), 1.0 / (n_local * H * W), device=dev)
+        del v_pix0, fg
+
+        def ops_step():
+            for r in reducers:
+                r.enabled = False
+            for p in leaves:
+                p.grad = None
+            v_pix = transform(v_world[None], campos, camrot, focal, princpt)
+            a = attr.expand(n_local, -1, -1)
+            index_img = drtk_amd.rasterize(v_pix, vi, H, W)
+            depth_img, bary_img = drtk_amd.render(v_pix, vi, index_img)
+            img = drtk_amd.interpolate(a, vi, index_img, bary_img)
+            img = drtk_amd.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
+            th.autograd.backward([img, depth_img], [g_img, g_depth])
+            return depth_img
+
+        ops_step()
+        elapsed_ops, _ = timed_loop(ops_step, args.steps, dev, world)
+        ext["operators_only"] = {
+            "note": "transform + rasterize + render + interpolate + edge_grad_estimator forward, and their backward pass seeded with "
+                    "resident upstream gradients (random on the foreground, zero on the background): the step without the user-side "
+                    "torch.where mask and loss, wall clock; reported beside, never as `value`",
+            "value": round(n_total * H * W * args.steps / elapsed_ops / 1e6, 2),
+            "ms_per_step": round(elapsed_ops / args.steps * 1e3, 4)}
+        del g_img, g_depth
+
     # the same step (reference API) captured once as a HIP graph and replayed: what the launch / autograd overhead costs.
     # Measured in a fresh CHILD process (started here, never exec'ed over this one) while this process idles: a capture
     # that goes wrong takes down the process it runs in, and the headline must not depend on it.

@@ -74,6 +74,10 @@ def test_single_process_line_carries_roofline_and_cpu_baseline():
     g = d["graph_step"]
     assert "error" not in g, g
     assert g["ms_per_step"] > 0 and abs(g["loss"] - d["loss"]) <= 1e-5 * max(1.0, abs(d["loss"]))
+    # the operators alone (no user-side mask / loss), wall clock: beside the headline, and necessarily faster than it
+    oo = d["extensions"]["operators_only"]
+    assert 0 < oo["ms_per_step"] < d["ms_per_step"] and oo["value"] > d["value"]
+    assert oo["ms_per_step"] >= d["path_roofline"]["t_ops_ms"] * 0.9  # ... and not faster than its own kernels
 
 
 def test_gpus_flag_must_match_the_process_group():
