@@ -336,18 +336,25 @@ def interpolation_normal_matrix_values_backward(grad_values, pair_indices, index
 
 
 def _level_table(levels):
-    lv = [t.contiguous() for t in levels]
+    """Device pointers, sizes and view strides of a mip pyramid.  A level whose views are contiguous [C,h,w] blocks is
+    passed as it is, whatever its batch stride -- in particular a [1,C,h,w] texture expanded to N views (stride 0) is
+    not materialised N times; anything else is made contiguous first."""
+    lv = []
+    for t in levels:
+        ok = t.dim() == 4 and (t.shape[0] == 0 or t[0].is_contiguous()) and (t.stride(0) == 0 or t.stride(0) >= t[0].numel() or t.shape[0] <= 1)
+        lv.append(t if ok else t.contiguous())
     n = len(lv)
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lv])
     lh = (ctypes.c_int64 * n)(*[t.shape[2] for t in lv])
     lw = (ctypes.c_int64 * n)(*[t.shape[3] for t in lv])
-    return lv, ptrs, lh, lw
+    lsn = (ctypes.c_int64 * n)(*[(t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2] * t.shape[3]) for t in lv])
+    return lv, ptrs, lh, lw, lsn
 
 
 @_on_tensor_device
 def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0, interpolation_mode=0,
                            align_corners=False, force_max_aniso=False, clip_grad=False, stream=None):
-    lv, ptrs, lh, lw = _level_table(levels)
+    lv, ptrs, lh, lw, lsn = _level_table(levels)
     grid = grid.contiguous()
     vt = vt_dxdy_img.contiguous()
     N, C = lv[0].shape[:2]
@@ -355,7 +362,7 @@ def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0,
     out = th.empty(N, C, H, W, dtype=lv[0].dtype, device=lv[0].device)
     _check(
         lib().drtk_amd_mipmap_grid_sampler_2d(
-            ctypes.c_int(_dt(lv[0])), ptrs, lh, lw, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i(N), _i(C), _i(H), _i(W),
+            ctypes.c_int(_dt(lv[0])), ptrs, lh, lw, lsn, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i(N), _i(C), _i(H), _i(W),
             ctypes.c_int(max_aniso), ctypes.c_int(padding_mode), ctypes.c_int(interpolation_mode),
             ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)), ctypes.c_int(bool(clip_grad)),
             _p(out), _stream(lv[0], stream)),
@@ -367,18 +374,18 @@ def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0,
 def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_aniso, padding_mode=0,
                                     interpolation_mode=0, align_corners=False, force_max_aniso=False,
                                     clip_grad=False, stream=None):
-    lv, ptrs, lh, lw = _level_table(levels)
+    lv, ptrs, lh, lw, lsn = _level_table(levels)
     grid = grid.contiguous()
     vt = vt_dxdy_img.contiguous()
     grad_out = grad_out.contiguous()
     N, C = lv[0].shape[:2]
     H, W = grid.shape[1:3]
-    glv = [th.empty_like(t) for t in lv]
+    glv = [th.empty(t.shape, dtype=t.dtype, device=t.device) for t in lv]  # contiguous even for an expanded pyramid
     gptrs = (ctypes.c_void_p * len(lv))(*[t.data_ptr() for t in glv])
     ggrid = th.empty_like(grid)
     _check(
         lib().drtk_amd_mipmap_grid_sampler_2d_backward(
-            ctypes.c_int(_dt(lv[0])), _p(grad_out), ptrs, lh, lw, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i(N), _i(C),
+            ctypes.c_int(_dt(lv[0])), _p(grad_out), ptrs, lh, lw, lsn, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i(N), _i(C),
             _i(H), _i(W), ctypes.c_int(max_aniso), ctypes.c_int(padding_mode), ctypes.c_int(interpolation_mode),
             ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)), ctypes.c_int(bool(clip_grad)),
             gptrs, _p(ggrid), _stream(lv[0], stream)),

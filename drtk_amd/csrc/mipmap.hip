@@ -31,6 +31,7 @@ constexpr int kMaxLevels = 11; // mipmap_grid_sampler_kernel.cu:16
 struct LevelTable {
   const void* ptr[kMaxLevels];
   void* grad[kMaxLevels];
+  long long sn[kMaxLevels]; // elements between the views of a level (0: one texture shared by all views)
   int h[kMaxLevels];
   int w[kMaxLevels];
 };
@@ -284,11 +285,13 @@ __device__ __forceinline__ Cubic<T> bicubic_footprint(T x, T y, int H, int W, in
   return c;
 }
 
-__device__ __forceinline__ void stage_levels(const LevelTable& lv, int mipmaps, const void** s_ptr, void** s_grad, int* s_h, int* s_w) {
+__device__ __forceinline__ void stage_levels(
+    const LevelTable& lv, int mipmaps, const void** s_ptr, void** s_grad, int* s_h, int* s_w, long long* s_sn) {
   if (threadIdx.x < kMaxLevels) {
     const int i = threadIdx.x < mipmaps ? threadIdx.x : 0;
     s_ptr[threadIdx.x] = lv.ptr[i];
     s_grad[threadIdx.x] = lv.grad[i];
+    s_sn[threadIdx.x] = lv.sn[i];
     s_h[threadIdx.x] = lv.h[i];
     s_w[threadIdx.x] = lv.w[i];
   }
@@ -354,9 +357,10 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  __shared__ long long s_sn[kMaxLevels];
   __shared__ double s_f[kTapTab * kTapTab];
   stage_tap_table(s_f);
-  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w, s_sn);
   const int64_t index = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
   if (index >= count) return;
   const int64_t n = index / HW;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
   for (int s = 0; s < 2; ++s) {
     const int d = s < n_lv ? t.d1 + s : 0;
     lv_h[s] = s_h[d], lv_w[s] = s_w[d];
-    lv_base[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * C * (int64_t(lv_h[s]) * lv_w[s]));
+    lv_base[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * s_sn[d]);
   }
 
   for (int c0 = 0; c0 < C; c0 += kChBlock) {
@@ -481,7 +485,8 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
-  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
+  __shared__ long long s_sn[kMaxLevels];
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w, s_sn);
   const int64_t index = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
   if (index >= count) return;
   const int64_t n = index / HW;
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
       const int d = t.d1 + s;
       const int h = s_h[d], w = s_w[d];
       const int64_t plane = int64_t(h) * w;
-      const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * C * plane);
+      const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * s_sn[d]);
       const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + n * C * plane);
       const T alpha = s == 0 ? alpha_2 : alpha_1;
       T gix = T(0), giy = T(0);
@@ -666,6 +671,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  __shared__ long long s_sn[kMaxLevels];
   __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels];
   // windows [level][channel][kWin * kWin], C channels, accumulated in DOUBLE whatever T is: ds_add_f32 retires one lane
   // every three clocks on MI355X, ds_add_f64 twenty times as many (profiles/micro/lds_atomics.hip) -- the float windows
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
     return;
   }
   stage_tap_table(s_f);
-  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w);
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w, s_sn);
   if (tid == 0) s_ref = kMaxLevels;
   if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
   {
@@ -793,7 +799,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
       const int d = live[s] ? t.d1 + s : 0;
       lv_h[s] = s_h[d], lv_w[s] = s_w[d];
       lv_plane[s] = lv_h[s] * lv_w[s]; // < 2^31, checked by fill_table()
-      lv_inp[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * C * lv_plane[s]);
+      lv_inp[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]);
       lv_ginp[s] = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * lv_plane[s]);
     }
     for (int i = 0; (live[0] || live[1]) && i < t.n; ++i) {
@@ -984,7 +990,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
 
 int fill_table(
     LevelTable& lv, const void* const* levels, void* const* grad_levels, const int64_t* level_h,
-    const int64_t* level_w, int mipmaps, int64_t N, int64_t C) {
+    const int64_t* level_w, const int64_t* level_sN, int mipmaps, int64_t N, int64_t C) {
   if (mipmaps < 1 || mipmaps > kMaxLevels || !levels || !level_h || !level_w) return DRTK_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kMaxLevels; ++i) {
     const int j = i < mipmaps ? i : 0;
@@ -994,6 +1000,8 @@ int fill_table(
     lv.grad[i] = grad_levels ? grad_levels[j] : nullptr;
     lv.h[i] = static_cast<int>(level_h[j]);
     lv.w[i] = static_cast<int>(level_w[j]);
+    lv.sn[i] = level_sN ? level_sN[j] : C * level_h[j] * level_w[j];
+    if (lv.sn[i] != 0 && lv.sn[i] < C * level_h[j] * level_w[j]) return DRTK_ERR_INVALID_ARGUMENT; // overlapping views
   }
   return DRTK_OK;
 }
@@ -1004,7 +1012,7 @@ int fill_table(
 using namespace drtk_amd;
 
 extern "C" int drtk_amd_mipmap_grid_sampler_2d(
-    drtk_dtype_t dtype, const void* const* levels, const int64_t* level_h, const int64_t* level_w, int mipmaps,
+    drtk_dtype_t dtype, const void* const* levels, const int64_t* level_h, const int64_t* level_w, const int64_t* level_sN, int mipmaps,
     const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W, int max_aniso,
     int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso, int clip_grad, void* out,
     drtk_stream_t stream) {
@@ -1013,7 +1021,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
       (interpolation_mode != 0 && interpolation_mode != 2) || (dtype != DRTK_F32 && dtype != DRTK_F64))
     return DRTK_ERR_INVALID_ARGUMENT;
   LevelTable lv;
-  const int st = fill_table(lv, levels, nullptr, level_h, level_w, mipmaps, N, C);
+  const int st = fill_table(lv, levels, nullptr, level_h, level_w, level_sN, mipmaps, N, C);
   if (st != DRTK_OK) return st;
   const int64_t count = N * H * W;
   if (count == 0 || C == 0) return DRTK_OK;
@@ -1040,14 +1048,14 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
 
 extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
     drtk_dtype_t dtype, const void* grad_out, const void* const* levels, const int64_t* level_h,
-    const int64_t* level_w, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H,
+    const int64_t* level_w, const int64_t* level_sN, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H,
     int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso,
     int clip_grad, void* const* grad_levels, void* grad_grid, drtk_stream_t stream) {
   if (N < 0 || C < 0 || H < 0 || W < 0 || C >= (1 << 20) || max_aniso < 1 || padding_mode < 0 || padding_mode > 2 ||
       (interpolation_mode != 0 && interpolation_mode != 2) || (dtype != DRTK_F32 && dtype != DRTK_F64) || !grad_levels)
     return DRTK_ERR_INVALID_ARGUMENT;
   LevelTable lv;
-  const int st = fill_table(lv, levels, grad_levels, level_h, level_w, mipmaps, N, C);
+  const int st = fill_table(lv, levels, grad_levels, level_h, level_w, level_sN, mipmaps, N, C);
   if (st != DRTK_OK) return st;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t es = dtype == DRTK_F32 ? 4 : 8;

@@ -931,15 +931,23 @@ Tensor normal_matrix_values_autocast(
 struct LevelArgs {
   std::vector<Tensor> holders;
   std::vector<const void*> ptrs;
-  std::vector<int64_t> h, w;
+  std::vector<int64_t> h, w, sn;
 };
+// A level whose views are contiguous [C,h,w] blocks goes to the kernels as it is, whatever its batch stride: the common
+// case of ONE texture shared by all camera views ([1,C,h,w].expand(N, ...), stride 0) is not materialised N times per
+// call (the reference indexes through the strides, mipmap_grid_sampler_kernel.cu:40,65).  Anything else is copied.
 LevelArgs prep_levels(at::TensorList input) {
   LevelArgs a;
   for (const Tensor& t : input) {
-    a.holders.push_back(t.contiguous());
-    a.ptrs.push_back(a.holders.back().data_ptr());
+    const int64_t view = t.size(1) * t.size(2) * t.size(3);
+    const bool views_contiguous = t.stride(3) == 1 && t.stride(2) == t.size(3) && t.stride(1) == t.size(2) * t.size(3);
+    const bool as_is = t.size(0) <= 1 ? t.is_contiguous() : (views_contiguous && (t.stride(0) == 0 || t.stride(0) >= view));
+    a.holders.push_back(as_is ? t : t.contiguous());
+    const Tensor& u = a.holders.back();
+    a.ptrs.push_back(u.data_ptr());
     a.h.push_back(t.size(2));
     a.w.push_back(t.size(3));
+    a.sn.push_back(u.size(0) > 1 ? u.stride(0) : view);
   }
   return a;
 }
@@ -1018,7 +1026,7 @@ Tensor mipmap_grid_sampler_2d_hip(
   auto out = at::empty({N, C, H, W}, input[0].options());
   check_status(
       drtk_amd_mipmap_grid_sampler_2d(
-          dt, lv.ptrs.data(), lv.h.data(), lv.w.data(), static_cast<int>(mipmaps), grid_c.data_ptr(), vt_c.data_ptr(), N,
+          dt, lv.ptrs.data(), lv.h.data(), lv.w.data(), lv.sn.data(), static_cast<int>(mipmaps), grid_c.data_ptr(), vt_c.data_ptr(), N,
           C, H, W, static_cast<int>(std::min<int64_t>(max_aniso, 1 << 20)), static_cast<int>(padding_mode),
           static_cast<int>(interpolation_mode), align_corners, force_max_ansio, clip_grad, out.data_ptr(),
           current_stream(input[0])),
@@ -1046,7 +1054,7 @@ std::tuple<std::vector<Tensor>, Tensor> mipmap_grid_sampler_2d_backward_hip(
   const int64_t N = input[0].size(0), C = input[0].size(1), H = grid.size(1), W = grid.size(2);
   check_status(
       drtk_amd_mipmap_grid_sampler_2d_backward(
-          dt, go_c.data_ptr(), lv.ptrs.data(), lv.h.data(), lv.w.data(), static_cast<int>(input.size()),
+          dt, go_c.data_ptr(), lv.ptrs.data(), lv.h.data(), lv.w.data(), lv.sn.data(), static_cast<int>(input.size()),
           grid_c.data_ptr(), vt_c.data_ptr(), N, C, H, W, static_cast<int>(std::min<int64_t>(max_aniso, 1 << 20)),
           static_cast<int>(padding_mode), static_cast<int>(interpolation_mode), align_corners, force_max_ansio, clip_grad,
           gptrs.data(), grad_grid.data_ptr(), current_stream(input[0])),

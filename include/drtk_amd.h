@@ -56,7 +56,7 @@ extern "C" {
 #endif
 
 #define DRTK_AMD_VERSION_MAJOR 0
-#define DRTK_AMD_VERSION_MINOR 2
+#define DRTK_AMD_VERSION_MINOR 3
 
 typedef enum { DRTK_F32 = 0, DRTK_F64 = 1 } drtk_dtype_t;
 
@@ -202,24 +202,28 @@ int drtk_amd_interpolation_normal_matrix_values_backward(
 /* ------------------------------------------------------------------------------------------
  * mipmap_grid_sampler_2d -- grid_sample with trilinear mip selection and anisotropic taps; replaces
  * mipmap_aniso_grid_sampler_2d_cuda / _cuda_backward (mipmap_grid_sampler_kernel.cu:899-1249).
- *   levels[l]    device pointer of mip level l, contiguous [N,C,level_h[l],level_w[l]], l < mipmaps <= 11
- *                (the arrays levels / level_h / level_w / grad_levels themselves are HOST arrays)
+ *   levels[l]    device pointer of mip level l, [N,C,level_h[l],level_w[l]] with contiguous views, l < mipmaps <= 11
+ *                (the arrays levels / level_h / level_w / level_sN / grad_levels themselves are HOST arrays)
+ *   level_sN[l]  elements between consecutive views of level l: C*h*w for a contiguous tensor, 0 for ONE texture
+ *                shared by all views (a [1,C,h,w] tensor expanded to N: the reference indexes through the tensor's
+ *                strides, mipmap_grid_sampler_kernel.cu:40,65 (`input.data + n * inp_sN`), so an expanded pyramid is never copied);
+ *                NULL = every level contiguous
  *   grid         [N,H,W,2] uv in [-1,1];  vt_dxdy_img [N,H,W,2,2] = [[du/dx, dv/dx],[du/dy, dv/dy]]
  *   out          [N,C,H,W]
  *   padding_mode 0 zeros | 1 border | 2 reflection;  interpolation_mode 0 bilinear | 2 bicubic
  *   align_corners is ignored by the forward pass and honoured by the backward pass -- as in the
  *   reference (:423 vs :641-897).
- * Backward: grad_levels[l] (same shapes as levels, zero-filled here) and grad_grid [N,H,W,2]
+ * Backward: grad_levels[l] (contiguous [N,C,h,w] whatever level_sN is, zero-filled here) and grad_grid [N,H,W,2]
  * (fully written); no gradient is defined for vt_dxdy_img.
  */
 int drtk_amd_mipmap_grid_sampler_2d(
     drtk_dtype_t dtype, const void* const* levels, const int64_t* level_h, const int64_t* level_w,
-    int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W,
+    const int64_t* level_sN, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W,
     int max_aniso, int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso,
     int clip_grad, void* out, drtk_stream_t stream);
 int drtk_amd_mipmap_grid_sampler_2d_backward(
     drtk_dtype_t dtype, const void* grad_out, const void* const* levels, const int64_t* level_h,
-    const int64_t* level_w, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C,
+    const int64_t* level_w, const int64_t* level_sN, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C,
     int64_t H, int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners,
     int force_max_aniso, int clip_grad, void* const* grad_levels, void* grad_grid, drtk_stream_t stream);
 

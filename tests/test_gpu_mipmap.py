@@ -114,6 +114,42 @@ def test_masked_upstream_gradients_magnified_pixels_and_tap_counts_beyond_the_ta
             close(a, b, f"grad level {i}")
 
 
+def test_one_texture_shared_by_all_views_is_sampled_in_place():
+    """A [1,C,h,w] pyramid expanded to N views (batch stride 0) -- one texture, many cameras -- gives the results of its
+    materialised copy, through the C ABI (`level_sN` = 0) and through the torch op, forward and backward; the level
+    gradients come back as contiguous [N,C,h,w] tensors (autograd sums them over the views), and a pyramid whose views are
+    spaced wider than C*h*w (a slice of a larger batch) works too."""
+    import drtk_amd
+    from drtk_amd import capi
+
+    tex1, grid, vt, gout = mipmap_inputs(77, 3, 3, 32, 4, 20, 24)
+    tex1 = [t[:1].to(DEV) for t in tex1]
+    grid, vt, gout = dev(grid), dev(vt), dev(gout)
+    shared = [t.expand(3, -1, -1, -1) for t in tex1]
+    copies = [t.contiguous() for t in shared]
+    assert shared[0].stride(0) == 0
+    want = capi.mipmap_grid_sampler_2d(copies, grid, vt, 6, 1, 0)
+    got = capi.mipmap_grid_sampler_2d(shared, grid, vt, 6, 1, 0)
+    assert th.equal(got, want)
+    wl, wg = capi.mipmap_grid_sampler_2d_backward(gout, copies, grid, vt, 6, 1, 0)
+    gl, gg = capi.mipmap_grid_sampler_2d_backward(gout, shared, grid, vt, 6, 1, 0)
+    assert th.equal(gg, wg)
+    for a, b in zip(gl, wl):
+        assert a.is_contiguous() and a.shape == b.shape
+        close(a, b, "grad level (atomics: order differs)")
+    # views spaced wider than one view: every second entry of a batch of 6
+    wide = [th.cat([t, t * 0 - 7.0], 1).reshape(6, *t.shape[1:])[::2] for t in copies]
+    assert wide[0].stride(0) == 2 * copies[0].stride(0) and th.equal(wide[0], copies[0])
+    assert th.equal(capi.mipmap_grid_sampler_2d(wide, grid, vt, 6, 1, 0), want)
+    # the torch op, with autograd: gradient of the shared leaf = sum over the views
+    leaves = [t.clone().requires_grad_(True) for t in tex1]
+    out = drtk_amd.mipmap_grid_sample([t.expand(3, -1, -1, -1) for t in leaves], grid, vt, 6, padding_mode="border")
+    assert th.equal(out, want)
+    out.backward(gout)
+    for leaf, b in zip(leaves, wl):
+        close(leaf.grad, b.sum(0, keepdim=True), "gradient of the shared texture")
+
+
 def test_f64_and_odd_channel_counts_match_oracle():
     import oracle as O
     from drtk_amd import capi
