@@ -351,18 +351,34 @@ def _level_table(levels):
     return lv, ptrs, lh, lw, lsn
 
 
+def _grid_layout(grid):
+    """(tensor to pass, {sN, sP, sC} in elements): a uv field [N,H,W,2] whose pixels are evenly spaced in memory is read
+    in place -- contiguous, or the channel-first image of `interpolate` seen through permute(0, 2, 3, 1); anything else
+    (overlapping views, rows with padding, other permutations) is made contiguous first."""
+    N, H, W, two = grid.shape
+    sN, sH, sW, sC = grid.stride()
+    P = H * W
+    rows_ok = H <= 1 or sH == W * sW
+    pixel_major = sC == 1 and sW == 2 and rows_ok and (N <= 1 or sN >= 2 * P)             # [N,H,W,2]
+    channel_major = sW == 1 and sC >= P and rows_ok and (N <= 1 or sN >= sC + P)          # [N,2,H,W] seen as [N,H,W,2]
+    if not (two == 2 and P > 0 and (pixel_major or channel_major)):
+        grid = grid.contiguous()
+        sN, sW, sC = 2 * P, 2, 1
+    return grid, (ctypes.c_int64 * 3)(sN if N > 1 else 2 * P, sW, sC)
+
+
 @_on_tensor_device
 def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0, interpolation_mode=0,
                            align_corners=False, force_max_aniso=False, clip_grad=False, stream=None):
     lv, ptrs, lh, lw, lsn = _level_table(levels)
-    grid = grid.contiguous()
+    grid, glayout = _grid_layout(grid)
     vt = vt_dxdy_img.contiguous()
     N, C = lv[0].shape[:2]
     H, W = grid.shape[1:3]
     out = th.empty(N, C, H, W, dtype=lv[0].dtype, device=lv[0].device)
     _check(
         lib().drtk_amd_mipmap_grid_sampler_2d(
-            ctypes.c_int(_dt(lv[0])), ptrs, lh, lw, lsn, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i(N), _i(C), _i(H), _i(W),
+            ctypes.c_int(_dt(lv[0])), ptrs, lh, lw, lsn, ctypes.c_int(len(lv)), _p(grid), glayout, _p(vt), _i(N), _i(C), _i(H), _i(W),
             ctypes.c_int(max_aniso), ctypes.c_int(padding_mode), ctypes.c_int(interpolation_mode),
             ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)), ctypes.c_int(bool(clip_grad)),
             _p(out), _stream(lv[0], stream)),
@@ -375,20 +391,20 @@ def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_ani
                                     interpolation_mode=0, align_corners=False, force_max_aniso=False,
                                     clip_grad=False, stream=None):
     lv, ptrs, lh, lw, lsn = _level_table(levels)
-    grid = grid.contiguous()
+    grid, glayout = _grid_layout(grid)
     vt = vt_dxdy_img.contiguous()
     grad_out = grad_out.contiguous()
     N, C = lv[0].shape[:2]
     H, W = grid.shape[1:3]
     glv = [th.empty(t.shape, dtype=t.dtype, device=t.device) for t in lv]  # contiguous even for an expanded pyramid
     gptrs = (ctypes.c_void_p * len(lv))(*[t.data_ptr() for t in glv])
-    ggrid = th.empty_like(grid)
+    ggrid = th.empty_strided(grid.shape, grid.stride(), dtype=grid.dtype, device=grid.device)  # laid out like the grid it belongs to
     _check(
         lib().drtk_amd_mipmap_grid_sampler_2d_backward(
-            ctypes.c_int(_dt(lv[0])), _p(grad_out), ptrs, lh, lw, lsn, ctypes.c_int(len(lv)), _p(grid), _p(vt), _i(N), _i(C),
+            ctypes.c_int(_dt(lv[0])), _p(grad_out), ptrs, lh, lw, lsn, ctypes.c_int(len(lv)), _p(grid), glayout, _p(vt), _i(N), _i(C),
             _i(H), _i(W), ctypes.c_int(max_aniso), ctypes.c_int(padding_mode), ctypes.c_int(interpolation_mode),
             ctypes.c_int(bool(align_corners)), ctypes.c_int(bool(force_max_aniso)), ctypes.c_int(bool(clip_grad)),
-            gptrs, _p(ggrid), _stream(lv[0], stream)),
+            gptrs, _p(ggrid), glayout, _stream(lv[0], stream)),
         "mipmap_grid_sampler_2d_backward")
     return glv, ggrid
 

@@ -166,22 +166,44 @@ template <typename T>
 struct PixelUV {
   T u, v, dudx, dvdx, dudy, dvdy;
 };
+// Where element (n, pixel, c) of a uv field [N,H,W,2] lives: n * sN + pixel * sP + c * sC elements from the base (pixel =
+// y * W + x).  Contiguous: (2HW, 2, 1), read and written as one 8- / 16-byte pair per pixel (`pair`); the channel-first
+// image `interpolate` produces, seen through permute(0, 2, 3, 1): (2HW, 1, HW) -- two coalesced loads, no copy.
+struct GridLayout {
+  long long sN, sP, sC;
+  bool pair;
+};
 template <typename T>
-__device__ __forceinline__ PixelUV<T> load_pixel_uv(const T* __restrict__ grid, const T* __restrict__ vt, int64_t index) {
+__device__ __forceinline__ PixelUV<T> load_pixel_uv(
+    const T* __restrict__ grid, const GridLayout& gl, const T* __restrict__ vt, int64_t n, int64_t pix, int64_t index) {
   PixelUV<T> p;
+  const T* g = grid + n * gl.sN + pix * gl.sP;
+  if (gl.pair) {
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+    const V2 q = *reinterpret_cast<const V2*>(g);
+    p.u = q.x, p.v = q.y;
+  } else {
+    p.u = g[0], p.v = g[gl.sC];
+  }
   if constexpr (sizeof(T) == 4) {
-    const float2 g = *reinterpret_cast<const float2*>(grid + index * 2);
     const float4 j = *reinterpret_cast<const float4*>(vt + index * 4);
-    p.u = g.x, p.v = g.y;
     p.dudx = j.x, p.dvdx = j.y, p.dudy = j.z, p.dvdy = j.w;
   } else {
-    const double2 g = *reinterpret_cast<const double2*>(grid + index * 2);
     const double2 j0 = *reinterpret_cast<const double2*>(vt + index * 4);
     const double2 j1 = *reinterpret_cast<const double2*>(vt + index * 4 + 2);
-    p.u = g.x, p.v = g.y;
     p.dudx = j0.x, p.dvdx = j0.y, p.dudy = j1.x, p.dvdy = j1.y;
   }
   return p;
+}
+template <typename T>
+__device__ __forceinline__ void store_grid_grad(T* __restrict__ gg, const GridLayout& gl, int64_t n, int64_t pix, T gx, T gy) {
+  T* g = gg + n * gl.sN + pix * gl.sP;
+  if (gl.pair) {
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+    *reinterpret_cast<V2*>(g) = V2{gx, gy};
+  } else {
+    g[0] = gx, g[gl.sC] = gy;
+  }
 }
 template <typename T>
 __device__ __forceinline__ Taps<T> setup_taps(
@@ -223,12 +245,6 @@ __device__ __forceinline__ Taps<T> setup_taps(
     t.du = dudy, t.dv = dvdy;
   }
   return t;
-}
-template <typename T>
-__device__ __forceinline__ Taps<T> setup_taps(
-    const T* __restrict__ grid, const T* __restrict__ vt, int64_t index, int inp_H, int inp_W, int mipmaps,
-    int max_aniso, bool force_max_aniso, bool clip_grad) {
-  return setup_taps<T>(load_pixel_uv<T>(grid, vt, index), inp_H, inp_W, mipmaps, max_aniso, force_max_aniso, clip_grad);
 }
 
 // Bilinear corner geometry of one (tap, level): offsets (or -1 when out of bounds) and weights.
@@ -351,7 +367,7 @@ constexpr int kChBlock = 4; // channels accumulated in registers per sweep over 
 // PAD: the padding mode as a compile-time constant (see mipmap_backward_tiled_kernel).
 template <typename T, int MODE, int PAD>
 __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
-    LevelTable lv, int mipmaps, const T* __restrict__ grid, const T* __restrict__ vt, int64_t count, int C,
+    LevelTable lv, int mipmaps, const T* __restrict__ grid, GridLayout gl, const T* __restrict__ vt, int64_t count, int C,
     int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, T* __restrict__ out, int strip) {
   constexpr int padding = PAD;
   __shared__ const void* s_ptr[kMaxLevels];
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
   if (index >= count) return;
   const int64_t n = index / HW;
   const bool align_corners = false; // mipmap_grid_sampler_kernel.cu:423
-  const Taps<T> t = setup_taps<T>(grid, vt, index, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+  const Taps<T> t = setup_taps<T>(load_pixel_uv<T>(grid, gl, vt, n, index - n * HW, index), s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
   const int n_lv = mipmaps > 1 ? 2 : 1;
   T* out_px = out + n * C * HW + (index - n * HW);
   const T alpha_1 = t.a / t.n;
@@ -479,9 +495,9 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
-    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid,
+    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
     const T* __restrict__ vt, int64_t count, int C, int64_t HW, int max_aniso, int padding, bool align_corners,
-    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, int strip) {
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip) {
   __shared__ const void* s_ptr[kMaxLevels];
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
@@ -490,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
   const int64_t index = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
   if (index >= count) return;
   const int64_t n = index / HW;
-  const Taps<T> t = setup_taps<T>(grid, vt, index, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+  const Taps<T> t = setup_taps<T>(load_pixel_uv<T>(grid, gl, vt, n, index - n * HW, index), s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
   const int n_lv = mipmaps > 1 ? 2 : 1;
   const T* gout_px = grad_out + n * C * HW + (index - n * HW);
   const T alpha_1 = t.a / t.n;
@@ -587,8 +603,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
       }
     }
   }
-  grad_grid[index * 2 + 0] = acc_x;
-  grad_grid[index * 2 + 1] = acc_y;
+  store_grid_grad<T>(grad_grid, ggl, n, index - n * HW, acc_x, acc_y);
 }
 
 // Backward, bilinear, C <= 4: LDS-windowed accumulation of the texture gradient.
@@ -662,9 +677,9 @@ constexpr int kWinCells = win_cells_before(kWinLevels);
 // them: SQ counters of the runtime-parameter version showed 490 scalar and 950 vector instructions per wave).
 template <typename T, int PAD, bool ALIGN>
 __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
-    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid,
+    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
     const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
-    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, int strip, int dbg) {
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
   constexpr int padding = PAD;
   constexpr bool align_corners = ALIGN;
   __shared__ double s_f[kTapTab * kTapTab];
@@ -697,13 +712,14 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   }
   // (uv and Jacobian are requested in the same batch: one memory round trip for everything the pixel reads but texels)
   PixelUV<T> uv = {};
-  if (valid) uv = load_pixel_uv<T>(grid, vt, index);
+  const int64_t pix = int64_t(py) * W + px;
+  if (valid) uv = load_pixel_uv<T>(grid, gl, vt, n, pix, index);
   // A pixel whose upstream gradient is zero in every channel (the masked background of a render) adds nothing to the
   // texture and has a zero grid gradient: it skips its tap set-up, and a tile of such pixels -- 44 % of the tiles of the
   // textured benchmark -- leaves here, before any window is touched.
   const bool has_go = go[0] != T(0) || go[1] != T(0) || go[2] != T(0) || go[3] != T(0);
   if (!__syncthreads_or(has_go)) {
-    if (valid) grad_grid[index * 2 + 0] = T(0), grad_grid[index * 2 + 1] = T(0);
+    if (valid) store_grid_grad<T>(grad_grid, ggl, n, pix, T(0), T(0));
     return;
   }
   stage_tap_table(s_f);
@@ -958,8 +974,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
         acc_y += q.my * giy;
       }
     }
-    grad_grid[index * 2 + 0] = acc_x;
-    grad_grid[index * 2 + 1] = acc_y;
+    store_grid_grad<T>(grad_grid, ggl, n, pix, acc_x, acc_y);
   }
   __syncthreads();
   // flush the windows: consecutive threads = consecutive texels of a row; cells that stayed 0 cost nothing,
@@ -1006,6 +1021,17 @@ int fill_table(
   return DRTK_OK;
 }
 
+// grid_layout = {sN, sP, sC} in elements (NULL: contiguous [N,H,W,2]); the pair access needs sC = 1, even strides and a
+// base aligned to two elements
+int make_grid_layout(GridLayout& gl, const int64_t* layout, const void* base, int64_t H, int64_t W, size_t elem) {
+  gl.sN = layout ? layout[0] : 2 * H * W;
+  gl.sP = layout ? layout[1] : 2;
+  gl.sC = layout ? layout[2] : 1;
+  if (gl.sN < 0 || gl.sP <= 0 || gl.sC <= 0) return DRTK_ERR_INVALID_ARGUMENT;
+  gl.pair = gl.sC == 1 && gl.sP % 2 == 0 && gl.sN % 2 == 0 && reinterpret_cast<uintptr_t>(base) % (2 * elem) == 0;
+  return DRTK_OK;
+}
+
 } // namespace
 } // namespace drtk_amd
 
@@ -1013,7 +1039,7 @@ using namespace drtk_amd;
 
 extern "C" int drtk_amd_mipmap_grid_sampler_2d(
     drtk_dtype_t dtype, const void* const* levels, const int64_t* level_h, const int64_t* level_w, const int64_t* level_sN, int mipmaps,
-    const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W, int max_aniso,
+    const void* grid, const int64_t* grid_layout, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W, int max_aniso,
     int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso, int clip_grad, void* out,
     drtk_stream_t stream) {
   (void)align_corners; // ignored by the reference's forward kernel (:423)
@@ -1026,11 +1052,13 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
   const int64_t count = N * H * W;
   if (count == 0 || C == 0) return DRTK_OK;
   if (!grid || !vt_dxdy_img || !out) return DRTK_ERR_INVALID_ARGUMENT;
+  GridLayout gl;
+  if (make_grid_layout(gl, grid_layout, grid, H, W, dtype == DRTK_F32 ? 4 : 8) != DRTK_OK) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid_dim(static_cast<unsigned>(ceil_div(count, kBlock)));
 #define LAUNCH_P(T, MODE, PAD)                                                                                 \
   DRTK_LAUNCH(                                                                                                 \
-      (mipmap_forward_kernel<T, MODE, PAD>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grid), \
+      (mipmap_forward_kernel<T, MODE, PAD>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grid), gl, \
       static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, force_max_aniso != 0, clip_grad != 0, \
       static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
 #define LAUNCH(T, MODE)                                                                    \
@@ -1048,9 +1076,10 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
 
 extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
     drtk_dtype_t dtype, const void* grad_out, const void* const* levels, const int64_t* level_h,
-    const int64_t* level_w, const int64_t* level_sN, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H,
-    int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso,
-    int clip_grad, void* const* grad_levels, void* grad_grid, drtk_stream_t stream) {
+    const int64_t* level_w, const int64_t* level_sN, int mipmaps, const void* grid, const int64_t* grid_layout, const void* vt_dxdy_img,
+    int64_t N, int64_t C, int64_t H, int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners,
+    int force_max_aniso, int clip_grad, void* const* grad_levels, void* grad_grid, const int64_t* grad_grid_layout,
+    drtk_stream_t stream) {
   if (N < 0 || C < 0 || H < 0 || W < 0 || C >= (1 << 20) || max_aniso < 1 || padding_mode < 0 || padding_mode > 2 ||
       (interpolation_mode != 0 && interpolation_mode != 2) || (dtype != DRTK_F32 && dtype != DRTK_F64) || !grad_levels)
     return DRTK_ERR_INVALID_ARGUMENT;
@@ -1069,14 +1098,17 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   const int64_t count = N * H * W;
   if (count == 0) return DRTK_OK;
   if (!grid || !vt_dxdy_img || !grad_grid || (C > 0 && !grad_out)) return DRTK_ERR_INVALID_ARGUMENT;
+  GridLayout gl, ggl;
+  if (make_grid_layout(gl, grid_layout, grid, H, W, es) != DRTK_OK || make_grid_layout(ggl, grad_grid_layout, grad_grid, H, W, es) != DRTK_OK)
+    return DRTK_ERR_INVALID_ARGUMENT;
   if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileW));
 #define TILED(PAD, ALIGN)                                                                                                \
   DRTK_LAUNCH(                                                                                                           \
       (mipmap_backward_tiled_kernel<float, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
       dim3(kBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const float*>(grad_out),                 \
-      static_cast<const float*>(grid), static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
-      force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), xcd_strip(tiles_x), debug_flags())
+      static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
+      force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
     if (align_corners) {
       if (padding_mode == 0) TILED(0, true); else if (padding_mode == 1) TILED(1, true); else TILED(2, true);
     } else {
@@ -1090,8 +1122,8 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
 #define LAUNCH(T, MODE)                                                                                       \
   DRTK_LAUNCH(                                                                                         \
       (mipmap_backward_kernel<T, MODE>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grad_out), \
-      static_cast<const T*>(grid), static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, \
-      align_corners != 0, force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid),                       \
+      static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso, padding_mode, \
+      align_corners != 0, force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl,                  \
       xcd_strip(ceil_div(16 * W, kBlock)))
   if (dtype == DRTK_F32) {
     if (interpolation_mode == 0) LAUNCH(float, 0); else LAUNCH(float, 2);

@@ -952,6 +952,30 @@ LevelArgs prep_levels(at::TensorList input) {
   return a;
 }
 
+// A uv field [N,H,W,2] whose pixels are evenly spaced in memory is read in place: contiguous, or the channel-first image
+// `interpolate` produces seen through permute(0, 2, 3, 1) (the reference reads grid through its strides,
+// mipmap_grid_sampler_kernel.cu:430-445).  Anything else is made contiguous.  layout = {sN, sP, sC} for the C ABI.
+struct GridArg {
+  Tensor t;
+  int64_t layout[3];
+};
+GridArg prep_grid(const Tensor& grid) {
+  const int64_t N = grid.size(0), H = grid.size(1), W = grid.size(2), P = H * W;
+  const int64_t sN = grid.stride(0), sH = grid.stride(1), sW = grid.stride(2), sC = grid.stride(3);
+  const bool rows_ok = H <= 1 || sH == W * sW;
+  const bool pixel_major = sC == 1 && sW == 2 && rows_ok && (N <= 1 || sN >= 2 * P);
+  const bool channel_major = sW == 1 && sC >= P && rows_ok && (N <= 1 || sN >= sC + P);
+  GridArg a;
+  if (grid.size(3) == 2 && P > 0 && (pixel_major || channel_major)) {
+    a.t = grid;
+    a.layout[0] = N > 1 ? sN : 2 * P, a.layout[1] = sW, a.layout[2] = sC;
+  } else {
+    a.t = grid.contiguous();
+    a.layout[0] = 2 * P, a.layout[1] = 2, a.layout[2] = 1;
+  }
+  return a;
+}
+
 Tensor mipmap_grid_sampler_2d_hip(
     at::TensorList input, const Tensor& grid, const Tensor& vt_dxdy_img, int64_t max_aniso, int64_t padding_mode,
     int64_t interpolation_mode, bool align_corners, bool force_max_ansio, bool clip_grad) {
@@ -1020,13 +1044,13 @@ Tensor mipmap_grid_sampler_2d_hip(
   const drtk_dtype_t dt = dtype_of(input[0], "mipmap_aniso_grid_sampler_2d_kernel");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input[0].device());
   const LevelArgs lv = prep_levels(input);
-  const auto grid_c = grid.contiguous();
+  const GridArg ga = prep_grid(grid);
   const auto vt_c = vt_dxdy_img.contiguous();
   const int64_t N = input[0].size(0), C = input[0].size(1), H = grid.size(1), W = grid.size(2);
   auto out = at::empty({N, C, H, W}, input[0].options());
   check_status(
       drtk_amd_mipmap_grid_sampler_2d(
-          dt, lv.ptrs.data(), lv.h.data(), lv.w.data(), lv.sn.data(), static_cast<int>(mipmaps), grid_c.data_ptr(), vt_c.data_ptr(), N,
+          dt, lv.ptrs.data(), lv.h.data(), lv.w.data(), lv.sn.data(), static_cast<int>(mipmaps), ga.t.data_ptr(), ga.layout, vt_c.data_ptr(), N,
           C, H, W, static_cast<int>(std::min<int64_t>(max_aniso, 1 << 20)), static_cast<int>(padding_mode),
           static_cast<int>(interpolation_mode), align_corners, force_max_ansio, clip_grad, out.data_ptr(),
           current_stream(input[0])),
@@ -1041,7 +1065,7 @@ std::tuple<std::vector<Tensor>, Tensor> mipmap_grid_sampler_2d_backward_hip(
   const drtk_dtype_t dt = dtype_of(input[0], "mipmap_aniso_grid_sampler_2d_backward_kernel");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input[0].device());
   const LevelArgs lv = prep_levels(input);
-  const auto grid_c = grid.contiguous();
+  const GridArg ga = prep_grid(grid);
   const auto vt_c = vt_dxdy_img.contiguous();
   const auto go_c = grad_output.to(input[0].scalar_type()).contiguous();
   std::vector<Tensor> grad_input;
@@ -1050,14 +1074,16 @@ std::tuple<std::vector<Tensor>, Tensor> mipmap_grid_sampler_2d_backward_hip(
     grad_input.push_back(at::empty(t.sizes(), t.options()));
     gptrs.push_back(grad_input.back().data_ptr());
   }
-  auto grad_grid = at::empty(grid.sizes(), grid.options());
+  // laid out like the grid it belongs to: the gradient of a permuted channel-first uv image arrives channel-first at
+  // interpolate's backward, which would otherwise copy it (the reference allocates it contiguous, :1126)
+  auto grad_grid = at::empty_strided(ga.t.sizes(), ga.t.strides(), grid.options());
   const int64_t N = input[0].size(0), C = input[0].size(1), H = grid.size(1), W = grid.size(2);
   check_status(
       drtk_amd_mipmap_grid_sampler_2d_backward(
           dt, go_c.data_ptr(), lv.ptrs.data(), lv.h.data(), lv.w.data(), lv.sn.data(), static_cast<int>(input.size()),
-          grid_c.data_ptr(), vt_c.data_ptr(), N, C, H, W, static_cast<int>(std::min<int64_t>(max_aniso, 1 << 20)),
+          ga.t.data_ptr(), ga.layout, vt_c.data_ptr(), N, C, H, W, static_cast<int>(std::min<int64_t>(max_aniso, 1 << 20)),
           static_cast<int>(padding_mode), static_cast<int>(interpolation_mode), align_corners, force_max_ansio, clip_grad,
-          gptrs.data(), grad_grid.data_ptr(), current_stream(input[0])),
+          gptrs.data(), grad_grid.data_ptr(), ga.layout, current_stream(input[0])),
       "mipmap_aniso_grid_sampler_2d_backward");
   return {grad_input, grad_grid};
 }

@@ -208,7 +208,11 @@ int drtk_amd_interpolation_normal_matrix_values_backward(
  *                shared by all views (a [1,C,h,w] tensor expanded to N: the reference indexes through the tensor's
  *                strides, mipmap_grid_sampler_kernel.cu:40,65 (`input.data + n * inp_sN`), so an expanded pyramid is never copied);
  *                NULL = every level contiguous
- *   grid         [N,H,W,2] uv in [-1,1];  vt_dxdy_img [N,H,W,2,2] = [[du/dx, dv/dx],[du/dy, dv/dy]]
+ *   grid         [N,H,W,2] uv in [-1,1];  vt_dxdy_img [N,H,W,2,2] = [[du/dx, dv/dx],[du/dy, dv/dy]], contiguous
+ *   grid_layout  HOST array {sN, sP, sC}: element (n, pixel y*W+x, c) of grid lies n*sN + pixel*sP + c*sC elements from
+ *                `grid` (the reference reads grid through its strides, :430-445).  NULL = contiguous {2HW, 2, 1}; the
+ *                channel-first uv image of `interpolate` seen through permute(0,2,3,1) is {2HW, 1, HW} -- no copy.
+ *                grad_grid_layout: the same for grad_grid (every element is written)
  *   out          [N,C,H,W]
  *   padding_mode 0 zeros | 1 border | 2 reflection;  interpolation_mode 0 bilinear | 2 bicubic
  *   align_corners is ignored by the forward pass and honoured by the backward pass -- as in the
@@ -218,14 +222,15 @@ int drtk_amd_interpolation_normal_matrix_values_backward(
  */
 int drtk_amd_mipmap_grid_sampler_2d(
     drtk_dtype_t dtype, const void* const* levels, const int64_t* level_h, const int64_t* level_w,
-    const int64_t* level_sN, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W,
-    int max_aniso, int padding_mode, int interpolation_mode, int align_corners, int force_max_aniso,
-    int clip_grad, void* out, drtk_stream_t stream);
+    const int64_t* level_sN, int mipmaps, const void* grid, const int64_t* grid_layout, const void* vt_dxdy_img, int64_t N,
+    int64_t C, int64_t H, int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners,
+    int force_max_aniso, int clip_grad, void* out, drtk_stream_t stream);
 int drtk_amd_mipmap_grid_sampler_2d_backward(
     drtk_dtype_t dtype, const void* grad_out, const void* const* levels, const int64_t* level_h,
-    const int64_t* level_w, const int64_t* level_sN, int mipmaps, const void* grid, const void* vt_dxdy_img, int64_t N, int64_t C,
-    int64_t H, int64_t W, int max_aniso, int padding_mode, int interpolation_mode, int align_corners,
-    int force_max_aniso, int clip_grad, void* const* grad_levels, void* grad_grid, drtk_stream_t stream);
+    const int64_t* level_w, const int64_t* level_sN, int mipmaps, const void* grid, const int64_t* grid_layout,
+    const void* vt_dxdy_img, int64_t N, int64_t C, int64_t H, int64_t W, int max_aniso, int padding_mode,
+    int interpolation_mode, int align_corners, int force_max_aniso, int clip_grad, void* const* grad_levels,
+    void* grad_grid, const int64_t* grad_grid_layout, drtk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * screen_space_uv_derivative -- vt_dxdy_img [N,H,W,2,2] = [[du/dx, dv/dx],[du/dy, dv/dy]] per pixel, the

@@ -150,6 +150,42 @@ def test_one_texture_shared_by_all_views_is_sampled_in_place():
         close(leaf.grad, b.sum(0, keepdim=True), "gradient of the shared texture")
 
 
+@pytest.mark.parametrize("dtype", [th.float32, th.float64])
+def test_channel_first_uv_image_is_read_in_place(dtype):
+    """grid = uv_img.permute(0, 2, 3, 1) -- how every caller builds it from `interpolate`'s [N,2,H,W] output -- is read
+    through its strides (C ABI: grid_layout {2HW, 1, HW}) with the results of its contiguous copy, the grid gradient
+    comes back in the same layout (so that it is channel-first contiguous after the permute's backward), a uv image that
+    is a channel slice of a wider tensor works too, and layouts the kernels do not take (rows with padding) are copied."""
+    import drtk_amd
+    from drtk_amd import capi
+
+    tol = dict(atol=1e-5, rtol=1e-5) if dtype == th.float32 else dict(atol=1e-11, rtol=1e-11)
+    for C, mode in ((3, 0), (5, 0), (2, 2)):  # tiled backward, direct backward, bicubic
+        tex, grid, vt, gout = mipmap_inputs(90 + C, 2, C, 32, 4, 18, 28, dtype)
+        tex, grid, vt, gout = dev(tex), dev(grid), dev(vt), dev(gout)
+        uv_img = grid.permute(0, 3, 1, 2).contiguous()          # [N,2,H,W]
+        cf = uv_img.permute(0, 2, 3, 1)
+        assert not cf.is_contiguous() and th.equal(cf, grid)
+        want = capi.mipmap_grid_sampler_2d(tex, grid, vt, 6, 1, mode)
+        assert th.equal(capi.mipmap_grid_sampler_2d(tex, cf, vt, 6, 1, mode), want)
+        wl, wg = capi.mipmap_grid_sampler_2d_backward(gout, tex, grid, vt, 6, 1, mode)
+        gl, gg = capi.mipmap_grid_sampler_2d_backward(gout, tex, cf, vt, 6, 1, mode)
+        assert gg.stride() == cf.stride() and th.equal(gg, wg)
+        for a, b in zip(gl, wl):
+            close(a, b, "grad level", **tol)
+        wide = th.cat([uv_img * 0 + 9, uv_img, uv_img * 0 - 9], 1)[:, 2:4].permute(0, 2, 3, 1)  # channels 2..3 of 6
+        assert th.equal(capi.mipmap_grid_sampler_2d(tex, wide, vt, 6, 1, mode), want)
+        padded = th.cat([grid, grid * 0], 2)[:, :, : grid.shape[2]]                              # rows with padding
+        assert not padded.is_contiguous() and th.equal(capi.mipmap_grid_sampler_2d(tex, padded, vt, 6, 1, mode), want)
+        # the torch op with autograd: the gradient reaches the channel-first leaf contiguous and equal
+        leaf = uv_img.clone().requires_grad_(True)
+        out = drtk_amd.mipmap_grid_sample(tex, leaf.permute(0, 2, 3, 1), vt, 6, mode="bilinear" if mode == 0 else "bicubic",
+                                          padding_mode="border")
+        assert th.equal(out, want)
+        out.backward(gout)
+        assert leaf.grad.is_contiguous() and th.equal(leaf.grad, wg.permute(0, 3, 1, 2))
+
+
 def test_f64_and_odd_channel_counts_match_oracle():
     import oracle as O
     from drtk_amd import capi
