@@ -9,7 +9,7 @@
 // CDNA4 mapping, two passes, no atomics, no zero-fill:
 //   A. edge_dots_kernel  -- dense stream over img and grad_output with 16-byte loads: for every
 //      pixel the two pair terms  gdx = sum_c (img_R - img_C) * 0.5 (g_R + g_C)  and the same
-//      downwards (gdy).  A wave walks a 256-pixel-wide strip down R rows keeping the previous row in
+//      downwards (gdy).  A wave walks a 252-pixel-wide strip down R rows keeping the previous row in
 //      registers, so each row is read (R+1)/R times instead of twice.  8 B/px of scratch out.
 //   B. edge_gather_kernel -- every pixel OWNS its output: it classifies the four pairs it takes
 //      part in (as centre of its own stencil, as the right pixel of its left neighbour's, as the
@@ -58,12 +58,11 @@ __device__ __forceinline__ Row<T, VEC> load_row(
 #pragma unroll
     for (int j = 0; j < VEC; ++j) r.v[j] = T(0);
   }
-  r.next = __shfl_down(r.v[0], 1);
-  if (lane == kWave - 1 && x_ok && x + VEC < W) r.next = plane[row_off + x + VEC];
+  r.next = __shfl_down(r.v[0], 1); // lane 63's is never used: it is the halo lane (see edge_dots_kernel)
   return r;
 }
 
-// One wave = strip of 64*VEC pixels x R rows; the WAVES waves of a workgroup are stacked vertically
+// One wave = strip of 63*VEC pixels (+ VEC halo pixels in lane 63) x R rows; the WAVES waves of a workgroup are stacked vertically
 // on the same pixel columns (WAVES*R rows per workgroup), so the extra "row below" every wave needs
 // is the first row of its sibling wave and is served by this CU's L1 -- HBM sees each row
 // (WAVES*R+1)/(WAVES*R) times.
@@ -80,7 +79,10 @@ __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
   const int lane = threadIdx.x & (kWave - 1);
   const int y0 = (by * WAVES + threadIdx.x / kWave) * R;
   if (y0 >= H) return;
-  const int x = (sx * kWave + lane) * VEC;
+  // strips are 63 lanes wide: lane 63 holds the first pixels of the next strip and only feeds lane 62's pair term.  (A
+  // one-lane load of that pixel per row, plane and channel was half of this kernel's memory instructions: 0.783-0.801 ->
+  // 0.772-0.773 ms for the fused route on the bench shape.)
+  const int x = (sx * (kWave - 1) + lane) * VEC;
   const T* img_n = img + int64_t(n) * C * HW;
   const T* go_n = grad_output + int64_t(n) * C * HW;
 
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
       }
     }
   }
-  if (!x_ok) return;
+  if (!x_ok || lane == kWave - 1) return;
   T* ox = gdx + int64_t(n) * HW;
   T* oy = gdy + int64_t(n) * HW;
 #pragma unroll
@@ -724,7 +726,7 @@ int edge_grad_backward_impl(
       (reinterpret_cast<uintptr_t>(grad_output) % (4 * sizeof(T)) == 0) &&
       (reinterpret_cast<uintptr_t>(workspace) % (4 * sizeof(T)) == 0) &&
       (reinterpret_cast<uintptr_t>(index_img) % 16 == 0);
-  const int px_per_wave = kWave * (vec ? 4 : 1);
+  const int px_per_wave = (kWave - 1) * (vec ? 4 : 1); // lane 63 = halo
   const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
@@ -750,7 +752,7 @@ int edge_grad_backward_impl(
 // pass A shared by both routes
 template <typename T>
 int launch_edge_dots(const T* img, const T* grad_output, const int32_t* index_img, int64_t N, int64_t C, int64_t H, int64_t W, T* gdx, T* gdy, bool vec, hipStream_t stream) {
-  const int px_per_wave = kWave * (vec ? 4 : 1);
+  const int px_per_wave = (kWave - 1) * (vec ? 4 : 1); // lane 63 = halo
   const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));

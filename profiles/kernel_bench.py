@@ -26,6 +26,8 @@ ap.add_argument("--flags", default="0", help="comma list of ablation masks to ti
                 "product library has no such switches")
 ap.add_argument("--check", action="store_true", help="also compare interpolate_backward of the bound library with a "
                 "torch formulation of the same sums on the GPU (for --lib variants, which no test suite binds to)")
+ap.add_argument("--dump", default="", help="save the outputs of the edge routes, render backward and rasterize (view 0) of the bound "
+                "library: two libraries are compared with `mipmap_bench.py --compare A B`")
 ap.add_argument("--lib", default="", help="A/B a kernel variant: path of another build of the library (e.g. one compiled with a -D switch)")
 a = ap.parse_args()
 if a.lib:
@@ -143,3 +145,9 @@ if a.check:
         worst = max(worst, e_a, e_b)
     print(f"check interpolate_backward: worst error / max magnitude = {worst:.2e}")
     assert worst < 2e-5, worst
+
+if a.dump:
+    outs = [capi.edge_grad_backward(v, img, index, vi, go)[:1], capi.edge_grad_backward_fused(v, img, index, vi, bary, go)[:1],
+            capi.render_backward(v, vi, index, gd, gb)[:1], capi.rasterize(v, vi, H, W)[0][:1],
+            capi.rasterize(v, vi, H, W)[1][:1].float() + 2]
+    th.save([t.cpu() for t in outs], a.dump)
