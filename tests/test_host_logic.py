@@ -542,3 +542,44 @@ print(drtk.__file__); print("ok")
                   ld_path=os.path.join(ROOT, "drtk_amd"))
     lines = out.strip().splitlines()
     assert lines[-1] == "ok" and lines[-2].startswith(str(tmp_path))
+
+
+def test_sampler_inputs_that_are_read_in_place_and_those_that_are_copied():
+    """Host logic of the sampler's strided inputs (capi._grid_layout / _level_table; torch_ops.cpp's prep_grid /
+    prep_levels decide the same way): which layouts go to the kernels as they are, with which strides, and which are
+    made contiguous first."""
+    from drtk_amd import capi
+
+    N, H, W = 3, 5, 7
+    P = H * W
+    grid = th.rand(N, H, W, 2)
+    g, lay = capi._grid_layout(grid)
+    assert g is grid and list(lay) == [2 * P, 2, 1]
+    uv_img = th.rand(N, 2, H, W)
+    cf = uv_img.permute(0, 2, 3, 1)
+    g, lay = capi._grid_layout(cf)
+    assert g is cf and list(lay) == [2 * P, 1, P]                       # channel-first image read through its strides
+    wide = th.rand(N, 6, H, W)[:, 2:4].permute(0, 2, 3, 1)
+    g, lay = capi._grid_layout(wide)
+    assert g is wide and list(lay) == [6 * P, 1, P]                     # two channels of a wider image
+    one = th.rand(1, H, W, 2).expand(1, H, W, 2)
+    assert list(capi._grid_layout(one)[1]) == [2 * P, 2, 1]
+    for bad in (th.rand(N, H, 2 * W, 2)[:, :, :W],                      # rows with padding
+                th.rand(1, H, W, 2).expand(N, H, W, 2),                 # one uv field for all views: overlapping
+                th.rand(N, W, H, 2).permute(0, 2, 1, 3),                # transposed image
+                th.rand(N, H, W, 4)[..., ::2]):                         # strided channels, pixels not evenly spaced the same way
+        g, lay = capi._grid_layout(bad)
+        assert g is not bad and g.is_contiguous() and list(lay) == [2 * P, 2, 1] and th.equal(g, bad)
+
+    C, h, w = 3, 4, 6
+    lv = th.rand(1, C, h, w)
+    shared = lv.expand(N, C, h, w)
+    kept, _, lh, lw, lsn = capi._level_table([shared, lv])
+    assert kept[0] is shared and list(lsn) == [0, C * h * w] and list(lh) == [h, h] and list(lw) == [w, w]
+    spaced = th.rand(2 * N, C, h, w)[::2]
+    kept, _, _, _, lsn = capi._level_table([spaced])
+    assert kept[0] is spaced and list(lsn) == [2 * C * h * w]
+    for bad in (th.rand(N, 2 * C, h, w)[:, ::2],                        # views that are not contiguous blocks
+                th.rand(N, C, w, h).transpose(2, 3)):
+        kept, _, _, _, lsn = capi._level_table([bad])
+        assert kept[0] is not bad and kept[0].is_contiguous() and list(lsn) == [C * h * w]
