@@ -396,7 +396,12 @@ def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_ani
     grad_out = grad_out.contiguous()
     N, C = lv[0].shape[:2]
     H, W = grid.shape[1:3]
-    glv = [th.empty(t.shape, dtype=t.dtype, device=t.device) for t in lv]  # contiguous even for an expanded pyramid
+    # contiguous even for an expanded pyramid, and back to back in one buffer: the call then zeroes them with one launch
+    flat = th.empty(sum(t.numel() for t in lv), dtype=lv[0].dtype, device=lv[0].device)
+    glv, off = [], 0
+    for t in lv:
+        glv.append(flat[off:off + t.numel()].view(t.shape))
+        off += t.numel()
     gptrs = (ctypes.c_void_p * len(lv))(*[t.data_ptr() for t in glv])
     ggrid = th.empty_strided(grid.shape, grid.stride(), dtype=grid.dtype, device=grid.device)  # laid out like the grid it belongs to
     _check(

@@ -1088,12 +1088,20 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   if (st != DRTK_OK) return st;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t es = dtype == DRTK_F32 ? 4 : 8;
-  for (int i = 0; i < mipmaps; ++i) { // :1120-1123 zeros_like
-    const size_t bytes = es * N * C * level_h[i] * level_w[i];
-    if (bytes > 0) {
-      if (!grad_levels[i]) return DRTK_ERR_INVALID_ARGUMENT;
-      if (fill_bytes_async(grad_levels[i], 0, bytes, s) != DRTK_OK) return DRTK_ERR_LAUNCH;
+  // :1120-1123 zeros_like.  Levels that lie back to back in memory (a caller that carves the gradient pyramid out of one
+  // buffer, like the torch shim) are zeroed by one launch: the coarse levels are a few KB each and a launch costs more
+  // than their fill.
+  for (int i = 0; i < mipmaps;) {
+    size_t bytes = es * N * C * level_h[i] * level_w[i];
+    if (bytes > 0 && !grad_levels[i]) return DRTK_ERR_INVALID_ARGUMENT;
+    int j = i + 1;
+    while (j < mipmaps && bytes > 0 && grad_levels[j] == static_cast<unsigned char*>(grad_levels[i]) + bytes &&
+           es * N * C * level_h[j] * level_w[j] > 0) {
+      bytes += es * N * C * level_h[j] * level_w[j];
+      ++j;
     }
+    if (bytes > 0 && fill_bytes_async(grad_levels[i], 0, bytes, s) != DRTK_OK) return DRTK_ERR_LAUNCH;
+    i = j;
   }
   const int64_t count = N * H * W;
   if (count == 0) return DRTK_OK;

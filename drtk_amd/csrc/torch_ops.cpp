@@ -1070,9 +1070,20 @@ std::tuple<std::vector<Tensor>, Tensor> mipmap_grid_sampler_2d_backward_hip(
   const auto go_c = grad_output.to(input[0].scalar_type()).contiguous();
   std::vector<Tensor> grad_input;
   std::vector<void*> gptrs;
-  for (const Tensor& t : input) { // zero-filled by the call (:1120-1123)
-    grad_input.push_back(at::empty(t.sizes(), t.options()));
-    gptrs.push_back(grad_input.back().data_ptr());
+  // zero-filled by the call (:1120-1123); the levels are carved out of ONE buffer, back to back (16-byte multiples), so
+  // that the call zeroes them with one launch instead of one per level
+  {
+    int64_t total = 0;
+    std::vector<int64_t> offs;
+    for (const Tensor& t : input) {
+      offs.push_back(total);
+      total += t.numel();
+    }
+    const Tensor flat = at::empty({total}, input[0].options());
+    for (size_t l = 0; l < input.size(); ++l) {
+      grad_input.push_back(flat.narrow(0, offs[l], input[l].numel()).view(input[l].sizes()));
+      gptrs.push_back(grad_input.back().data_ptr());
+    }
   }
   // laid out like the grid it belongs to: the gradient of a permuted channel-first uv image arrives channel-first at
   // interpolate's backward, which would otherwise copy it (the reference allocates it contiguous, :1126)
