@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 // differing pixel pair twice -- once from each end -- inside four divergent branches; that arithmetic was
 // 60 % of such a kernel, which is instruction-issue bound (1.27 ms fused; this kernel: 0.96 ms).
 // Here the unit of work is the PAIR: a wave compacts the horizontal pairs (x,y)-(x+1,y) and the vertical
-// pairs (x,y)-(x,y+1) of its 256 x 4 tile whose indices differ (same stencil domain, edge_grad_kernel.cu:270),
+// pairs (x,y)-(x,y+1) of its 256 x kPairRows tile whose indices differ (same stencil domain, edge_grad_kernel.cu:270),
 // one pair per lane, evaluates it ONCE with the axis as a compile-time constant, and scatters both ends'
 // contributions (pixel A: -gA on the axis, -zA on z; pixel B: -gB, -zB; each times its own pixel's
 // barycentrics) through the run reduction of segscatter.hpp with six corner slots (A0..A2, B0..B2) and
@@ -531,13 +531,22 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 // IDX_VEC: index_img is 16-byte aligned (its rows are fetched as int4); otherwise four scalar loads per row --
 // the only global vector access of this kernel, so that a contiguous but merely element-aligned index_img (a view
 // into a flat buffer) stays on the fused route.  W % 4 == 0 in both cases.
+#ifndef DRTK_PAIR_ROWS
+#define DRTK_PAIR_ROWS 2
+#endif
+// Image rows per wave of edge_scatter_pairs_kernel (its tile: 256 x kPairRows pixels).  The kernel is bound by the
+// dependent loads of each 64-pair round (list -> index -> corners -> vertices) at 2-3 waves per SIMD, and its waves'
+// work varies with the number of pairs in their tile: more, shorter waves keep more rounds in flight and even out the
+// tail.  Fused route on one box (kernel_bench): 4 rows 0.799-0.804 ms, 2 rows 0.759-0.762, 1 row 0.800 (the halo row
+// doubles the index traffic and the lists get short), 8 rows 0.830; 1M triangles at 2 x 4096^2: 0.468 -> 0.409 ms.
+constexpr int kPairRows = DRTK_PAIR_ROWS;
 template <typename T, bool IDX_VEC>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_pairs_kernel(
     const T* __restrict__ v_pix, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ bary_img, const T* __restrict__ gdx, const T* __restrict__ gdy, int64_t V, int64_t vi_sN,
     int H, int W, int strips_x, T M, T* __restrict__ grad_v_pix, int strip) {
   constexpr int kWaves = kBlock / kWave;
-  constexpr int kRows = 4;
+  constexpr int kRows = kPairRows;
   constexpr int kCap = kWave * 4 * 2 * 2; // pairs of two rows, both axes: the most one list build can hold
   __shared__ uint16_t s_list[kWaves][kCap];
 #ifndef DRTK_EDGE_SLOTS
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
     prefix4(__popc(vf[r]), t);
     grand += t;
   }
-  const int rows_per_group = grand <= kCap ? kRows : 2;
+  const int rows_per_group = grand <= kCap ? kRows : (kRows < 2 ? kRows : 2);
   for (int r0 = 0; r0 < kRows; r0 += rows_per_group) {
     // list layout: [horizontal pairs of the group, row-major][vertical pairs, row-major]
     int n_h = 0, n_all = 0;
@@ -790,9 +799,9 @@ int edge_grad_backward_fused_impl(
     const int st = launch_edge_dots<T>(img, grad_output, index_img, N, C, H, W, gdx, gdy, vec_a, stream);
     if (st != DRTK_OK) return st;
     const int strips_x = static_cast<int>(ceil_div(W, kWave * 4));
-    const int64_t waves = int64_t(strips_x) * ceil_div(H, 4);
+    const int64_t waves = int64_t(strips_x) * ceil_div(H, kPairRows);
     const dim3 grid(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
-    const int strip = xcd_strip(ceil_div(int64_t(strips_x) * 4, kBlock / kWave));
+    const int strip = xcd_strip(ceil_div(int64_t(strips_x) * (16 / kPairRows), kBlock / kWave));
     if (aligned_to(index_img, 16)) {
       DRTK_LAUNCH((edge_scatter_pairs_kernel<T, true>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
     } else {
