@@ -820,6 +820,9 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
   const int n_items = queue[1];
   DRTK_PHASE_INIT();
   for (;;) {
+    // (popping the NEXT item when this one starts, to take the atomic's round trip off the critical path, was measured
+    // slower: 0.444 vs 0.424 ms -- a workgroup that reserves an item while it is still busy delays that item, and the
+    // heavy-first order of the list only balances the tail if items are taken when they can be started)
     if (tid == 0) s_item = atomicAdd(&queue[0], 1);
     __syncthreads();
     if (tid == 0) DRTK_PHASE(0); // queue pop
