@@ -296,8 +296,18 @@ struct BinLayout {
 };
 
 // Work items of the raster pass: a tile, or one of 4 / 16 sub-rectangles of a heavy tile.
-constexpr int kSplit4Threshold = 384;   // triangles in a tile's list above which it is split 2x2
-constexpr int kSplit16Threshold = 1536; // ... 4x4
+// Triangles in a tile's list above which the tile is split 2x2 (four times that: 4x4).  A split buys parallelism and a
+// shorter tail at the price of every sub-rectangle re-scanning the tile's list, so the threshold follows the size of the
+// job: kSplit4Min where there are few tiles to go round (4 views of 10k triangles at 512^2: 0.085 ms with 384, 0.096
+// with 512), a multiple of the mean list length per workgroup slot where there are many (split_threshold(): 8 x 100k at
+// 2048^2 0.428 -> 0.410 ms with 512; 8 x 250k 0.686 -> 0.577 with 1280; 2 x 1M at 4096^2 0.716 -> 0.628; 8 x 1M 2.5 ->
+// 1.9 with 2048; lower thresholds only lose: 256 0.451, 192 0.487, 128 0.577 ms on the bench shape).
+constexpr int kSplit4Min = 384, kSplit4Max = 2048;
+inline int split_threshold(int64_t N, int64_t F) {
+  const int64_t slots = int64_t(num_compute_units()) * 4; // resident raster workgroups
+  const int64_t t = (N * F * 13) / (20 * (slots > 0 ? slots : 1)); // 0.65 x triangles per slot
+  return static_cast<int>(t < kSplit4Min ? kSplit4Min : (t > kSplit4Max ? kSplit4Max : t));
+}
 __host__ __device__ inline uint32_t make_item(uint32_t tile, uint32_t sub, uint32_t split_log) {
   return tile | (sub << 24) | (split_log << 28);
 }
@@ -337,8 +347,8 @@ inline BinLayout make_layout(int64_t N, int64_t F, int64_t H, int64_t W) {
   o += align_up(sizeof(int32_t) * N * F, 256);
   L.off_pairs = o;
   o += align_up(sizeof(int32_t) * kMaxSmallTiles * N * F, 256);
-  // every split tile holds > kSplit4Threshold of the <= 4*N*F list entries and yields <= 16 items
-  L.max_items = L.num_tiles + 16 * ((kMaxSmallTiles * N * F) / kSplit4Threshold);
+  // every split tile holds > kSplit4Min of the <= 4*N*F list entries and yields <= 16 items
+  L.max_items = L.num_tiles + 16 * ((kMaxSmallTiles * N * F) / kSplit4Min);
   L.off_items = o;
   o += align_up(sizeof(uint32_t) * L.max_items, 256);
   L.total_bytes = o > 0 ? o : 256;
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void bin_count_kernel(
 // a serial tail.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(
     const unsigned long long* __restrict__ tile_count64, int32_t* __restrict__ tile_offset, int num_tiles,
-    int tile_shift, uint32_t* __restrict__ items, int32_t* __restrict__ queue) {
+    int tile_shift, int split4, uint32_t* __restrict__ items, int32_t* __restrict__ queue) {
   // One block-wide scan of FIVE running sums per thread -- list entries, and work items of each of the four
   // classes -- gives every thread the list offset of its first tile and its first slot in every class of the
   // work list: no atomics (1024 threads bumping four LDS counters are served one lane at a time), two
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
   const int end = min(begin + chunk, num_tiles);
   const int max_split_log = max(0, min(2, tile_shift - 4)); // sub-rectangles are at least 16 px
   auto split_log_of = [&](int c) {
-    int sl = c > kSplit16Threshold ? 2 : (c > kSplit4Threshold ? 1 : 0);
+    int sl = c > 4 * split4 ? 2 : (c > split4 ? 1 : 0);
     return min(sl, max_split_log);
   };
   auto class_of = [&](int c, int sl) { return c == 0 ? 3 : 2 - sl; }; // 0: 4x4 split, 1: 2x2, 2: whole tile, 3: empty list
@@ -1064,7 +1074,7 @@ int rasterize_impl(
   }
   DRTK_LAUNCH(
       bin_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_count, tile_offset, (int)L.num_tiles,
-      L.tile_shift, items, queue);
+      L.tile_shift, split_threshold(N, F), items, queue);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   if (total > 0) {
     DRTK_LAUNCH(
