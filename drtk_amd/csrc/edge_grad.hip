@@ -719,8 +719,16 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
   table_flush<T, TableAcc, kSlots>(t_keys[wave], t_vals[wave], 4, 3, grad_n, 3, 0);
 }
 
-constexpr int kStripRows = 2; // rows per wave
-constexpr int kDotsWaves = 4; // vertically stacked waves per workgroup (8 measured no faster: 1.51 vs 1.50 ms)
+#ifndef DRTK_DOTS_ROWS
+#define DRTK_DOTS_ROWS 2
+#endif
+#ifndef DRTK_DOTS_WAVES
+#define DRTK_DOTS_WAVES 4
+#endif
+// rows per wave x vertically stacked waves per workgroup.  Fused route on one box, round 2 (build.py --variant):
+// 2 x 4 0.711-0.717 ms, 2 x 8 0.769, 1 x 4 0.778, 1 x 8 0.777, 3 x 4 0.838, 4 x 2 0.910, 4 x 4 0.941.
+constexpr int kStripRows = DRTK_DOTS_ROWS;
+constexpr int kDotsWaves = DRTK_DOTS_WAVES;
 
 template <typename T>
 int edge_grad_backward_impl(
