@@ -147,7 +147,7 @@ if a.check:
     assert worst < 2e-5, worst
 
 if a.dump:
-    outs = [capi.edge_grad_backward(v, img, index, vi, go)[:1], capi.edge_grad_backward_fused(v, img, index, vi, bary, go)[:1],
+    outs = [capi.interpolate(attr, vi, index, bary)[:1], capi.edge_grad_backward(v, img, index, vi, go)[:1], capi.edge_grad_backward_fused(v, img, index, vi, bary, go)[:1],
             capi.render_backward(v, vi, index, gd, gb)[:1], capi.rasterize(v, vi, H, W)[0][:1],
             capi.rasterize(v, vi, H, W)[1][:1].float() + 2]
     th.save([t.cpu() for t in outs], a.dump)
