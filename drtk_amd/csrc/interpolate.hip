@@ -28,7 +28,13 @@ struct Vec4<double> {
 // (Two pixels per lane instead of four -- half the registers, twice the waves in flight for a kernel whose waves spend
 // four gather round trips each -- was measured slower, 0.652 vs 0.543-0.577 ms: the 8-byte stores cost more than the
 // occupancy buys.)
-template <typename T, int VEC, int CV>
+// PREFETCH (VEC = CV = 4, more than one channel chunk): the attribute rows of the NEXT chunk are requested before this
+// chunk's products and stores.  A wave's life was four dependent gather round trips (SQ counters: 39 k cycles alive for
+// 1.7 k cycles of vector issue); with the next chunk in flight the kernel takes 158 instead of 88 VGPRs -- 3 waves per
+// SIMD instead of 5 -- and is still faster: 0.573 -> 0.548-0.560 ms on the bench shape, 2.46 -> 2.18 at 8 x 4096^2,
+// 1.46 -> 1.30 at C = 32.  With a single chunk (C = 4) there is nothing to prefetch and only the registers are paid
+// (0.216 -> 0.232 ms): that case keeps the plain loop.
+template <typename T, int VEC, int CV, bool PREFETCH = false>
 __global__ __launch_bounds__(kBlock) void interpolate_kernel(
     const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
@@ -81,6 +87,57 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
     bgx[j] = (static_cast<T>(x0 + j) * T(2.0) + T(1.0)) / static_cast<T>(W) - T(1.0);
   }
 
+  if constexpr (PREFETCH) {
+    static_assert(CV == 4 && VEC == 4, "the prefetching loop is written for 4 pixels x 4 channels");
+    V4 Q[VEC][3], Qn[VEC][3];
+    // rows as 32-bit element offsets from attrs_n (V * C < 2^31 on this path, checked by the launcher): 12 registers
+    // instead of 24 for the addresses
+    uint32_t off[VEC][3];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      off[j][0] = static_cast<uint32_t>(a0[j] - attrs_n);
+      off[j][1] = static_cast<uint32_t>(a1[j] - attrs_n);
+      off[j][2] = static_cast<uint32_t>(a2[j] - attrs_n);
+    }
+    auto fetch = [&](int c0, V4 (&q)[VEC][3]) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (tr[j] != -1) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) q[j][k] = *reinterpret_cast<const V4*>(attrs_n + off[j][k] + c0);
+        }
+      }
+    };
+    fetch(0, Q);
+    for (int c0 = 0; c0 < C; c0 += CV) {
+      if (c0 + CV < C) fetch(c0 + CV, Qn);
+      T r[CV][VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (tr[j] != -1) {
+          const T u0[4] = {Q[j][0].x, Q[j][0].y, Q[j][0].z, Q[j][0].w};
+          const T u1[4] = {Q[j][1].x, Q[j][1].y, Q[j][1].z, Q[j][1].w};
+          const T u2[4] = {Q[j][2].x, Q[j][2].y, Q[j][2].z, Q[j][2].w};
+#pragma unroll
+          for (int cc = 0; cc < CV; ++cc) r[cc][j] = u0[cc] * B0[j] + u1[cc] * B1[j] + u2[cc] * B2[j];
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < CV; ++cc) r[cc][j] = zero_background ? T(0) : (((c0 + cc) & 1) ? bgy : bgx[j]);
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < CV; ++cc) {
+        T* o = out_p + int64_t(c0 + cc) * HW;
+        *reinterpret_cast<V4*>(o) = V4{r[cc][0], r[cc][1], r[cc][2], r[cc][3]};
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Q[j][k] = Qn[j][k];
+      }
+    }
+    return;
+  }
   for (int c0 = 0; c0 < C; c0 += CV) {
     T r[CV][VEC];
 #pragma unroll
@@ -582,13 +639,15 @@ int interpolate_impl(
       (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0);
   const bool cvec = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(attrs) % (4 * sizeof(T)) == 0);
   const dim3 block(kBlock);
-#define LAUNCH(VEC, CV)                                                                         \
+#define LAUNCH(VEC, CV, ...)                                                                    \
   DRTK_LAUNCH(                                                                           \
-      (interpolate_kernel<T, VEC, CV>),                                                         \
+      (interpolate_kernel<T, VEC, CV, ##__VA_ARGS__>),                                          \
       dim3(static_cast<unsigned>(ceil_div(HW / VEC, kBlock)), static_cast<unsigned>(N)), block, \
       0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out, zero_background, \
       xcd_strip(ceil_div(16 * W, int64_t(kBlock) * VEC)))
-  if (pvec && cvec)
+  if (pvec && cvec && C > 4 && V * C < (int64_t(1) << 31)) // (32-bit row offsets in the prefetching loop)
+    LAUNCH(4, 4, true);
+  else if (pvec && cvec)
     LAUNCH(4, 4);
   else if (pvec)
     LAUNCH(4, 1);
