@@ -727,6 +727,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
 #endif
 // rows per wave x vertically stacked waves per workgroup.  Fused route on one box, round 2 (build.py --variant):
 // 2 x 4 0.711-0.717 ms, 2 x 8 0.769, 1 x 4 0.778, 1 x 8 0.777, 3 x 4 0.838, 4 x 2 0.910, 4 x 4 0.941.
+// Requesting the NEXT channel's rows before this channel's products (what pays in interpolate forward): 98 instead of 76
+// VGPRs, 4 instead of 6 waves per SIMD, 0.748-0.749 vs 0.736-0.754 ms -- nothing.
 constexpr int kStripRows = DRTK_DOTS_ROWS;
 constexpr int kDotsWaves = DRTK_DOTS_WAVES;
 
