@@ -728,7 +728,10 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
 // rows per wave x vertically stacked waves per workgroup.  Fused route on one box, round 2 (build.py --variant):
 // 2 x 4 0.711-0.717 ms, 2 x 8 0.769, 1 x 4 0.778, 1 x 8 0.777, 3 x 4 0.838, 4 x 2 0.910, 4 x 4 0.941.
 // Requesting the NEXT channel's rows before this channel's products (what pays in interpolate forward): 98 instead of 76
-// VGPRs, 4 instead of 6 waves per SIMD, 0.748-0.749 vs 0.736-0.754 ms -- nothing.
+// VGPRs, 4 instead of 6 waves per SIMD, 0.748-0.749 vs 0.736-0.754 ms -- nothing.  Nor does it matter that every load of
+// load_row sits in a divergent branch with an s_waitcnt vmcnt(0) behind it (six round trips per channel, one after the
+// other): with unconditional loads from clamped addresses the compiler batches them four and two, and the kernel takes
+// the same 0.701 ms -- at 21 waves per CU the memory system is busy either way; this is what a 32-plane stream reaches.
 constexpr int kStripRows = DRTK_DOTS_ROWS;
 constexpr int kDotsWaves = DRTK_DOTS_WAVES;
 

@@ -539,6 +539,14 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
       const int y = y0 + ps;
       const int64_t pix = int64_t(y) * W + x;
       const bool covered = tr != -1;
+      // 0. the two CONDITIONAL fetches of the rows ahead come first: `cond ? load : default` compiles to a branch around the
+      //    load with an s_waitcnt vmcnt(0) inside it; issued after the next row's 19 loads (as they used to be) that wait
+      //    held the wave until all of them had landed, before the phase 2 they were meant to fly under (0.659 -> 0.650 ms;
+      //    making the two fetches unconditional instead cost registers and was slower, 0.675)
+      if (ps + 1 < kPasses) {
+        load_face(tr_n, vn0, vn1, vn2);
+        tr_nn = load_tr(ps + 2);
+      }
       // 1. stage this row
 #pragma unroll
       for (int c = 0; c < CH; ++c) s_g[wave][c * kRunPad + lane] = G[c];
@@ -564,11 +572,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
         }
       }
       // 3. the next row's operands (and the ids of the row after it) fly under phase 2
-      if (ps + 1 < kPasses) {
-        load_row(ps + 1, tr_n != -1);
-        load_face(tr_n, vn0, vn1, vn2);
-        tr_nn = load_tr(ps + 2);
-      }
+      if (ps + 1 < kPasses) load_row(ps + 1, tr_n != -1);
       wave_lds_sync();
       // 4. phase 2: run sums per (corner, channel) lane -> one 64-byte atomic request per corner and run
       //    (a per-vertex LDS table in front of the atomics was measured slower here, twice: 1.01 vs 0.83 ms in round 1;
