@@ -539,6 +539,8 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 // work varies with the number of pairs in their tile: more, shorter waves keep more rounds in flight and even out the
 // tail.  Fused route on one box (kernel_bench): 4 rows 0.799-0.804 ms, 2 rows 0.759-0.762, 1 row 0.800 (the halo row
 // doubles the index traffic and the lists get short), 8 rows 0.830; 1M triangles at 2 x 4096^2: 0.468 -> 0.409 ms.
+// Narrower tiles instead (2 pixels per lane, 128 x 2 or 128 x 4): 0.80-0.84 ms against 0.72-0.76 -- the 8-byte index
+// loads and half-empty pair rounds cost more than the extra waves bring.
 constexpr int kPairRows = DRTK_PAIR_ROWS;
 template <typename T, bool IDX_VEC>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_pairs_kernel(
