@@ -344,8 +344,9 @@ def main():
         vt, vti = S.uv_sphere_atlas(nl, no, device=dev)
         vt = vt[None].half().requires_grad_(True)  # uv attributes stored in fp16, shared across views and ranks
         tex = [t.half().requires_grad_(True) for t in S.texture_pyramid(1, 3, args.tex, device=dev)]  # shared fp16 texture pyramid
-        shared = [v_world]  # (vt and the pyramid are fp16 leaves: reduced by a second reducer of their dtype)
-        reducers = [ddist.SharedGradReducer([v_world]), ddist.SharedGradReducer([vt] + tex)]
+        # two collectives per step: the fp16 leaves (uv attributes + every mip level) as ONE group staged in float32 --
+        # their gradients are accumulated, summed over the ranks and only then rounded to fp16 -- and the vertices
+        reducers = [ddist.SharedGradReducer([v_world, [vt] + tex], dtype=th.float32)]
     else:
         attr = S.random_attributes(1, v_world.shape[0], C, seed=0, device=dev)[:1].contiguous()
         attr = attr.clone().requires_grad_(True)        # shared across views and ranks
@@ -365,8 +366,9 @@ def main():
         v_pix = transform(v_world[None], campos, camrot, focal, princpt)  # shared [1,V,3] -> [n_local,V,3]
         if textured:
             with th.autocast("cuda", dtype=th.float16):
-                out = S.textured_shading(drtk_amd, v_world[None].expand(n_local, -1, -1), v_pix, vi, vt.expand(n_local, -1, -1), vti,
-                                         [t.expand(n_local, -1, -1, -1) for t in tex], campos, camrot, focal, H, W)
+                up = reducers[0].upcast  # the fp16 leaves enter the pipeline as float32 (what autocast would do inside the ops)
+                out = S.textured_shading(drtk_amd, v_world[None].expand(n_local, -1, -1), v_pix, vi, up(vt).expand(n_local, -1, -1), vti,
+                                         [up(t).expand(n_local, -1, -1, -1) for t in tex], campos, camrot, focal, H, W)
             img, depth_img = out["img"], out["depth_img"]
         else:
             a = attr.expand(n_local, -1, -1)
@@ -398,7 +400,11 @@ def main():
     elapsed, loss = timed_loop(step, args.steps, dev, world)
     ms_per_step = elapsed / args.steps * 1e3
     mpix = n_total * H * W * args.steps / elapsed / 1e6
-    comm = reducers[0].timings_ms() if world > 1 else None
+    comm = None
+    if world > 1:
+        per = [r.timings_ms() for r in reducers]
+        if all(t is not None for t in per):
+            comm = (sum(t[0] for t in per), sum(t[1] for t in per))
     loss_value = float(loss.detach())
 
     # the same step with the drtk_amd.interpolate_masked extension (reported beside, never as `value`)
@@ -575,7 +581,8 @@ def main():
             },
             "loss": round(loss_value, 6),
             "all_reduce": None if comm is None else {
-                "bytes": nbytes, "collectives_per_step": len(reducers[0].params),
+                "bytes": nbytes, "collectives_per_step": sum(r.collectives_per_step() for r in reducers),
+                "staging_dtype": str(reducers[0].flat.dtype).replace("torch.", ""),
                 "ms_launch_to_done": round(comm[0], 4), "ms_exposed_on_main_stream": round(comm[1], 4),
                 "note": "last timed step, rank 0: side-stream time from each collective's launch to its completion (sum), and how "
                         "long the main stream then waited for them"},

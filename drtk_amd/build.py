@@ -95,9 +95,10 @@ def build_variant(out, defines, verbose=True):
     """A/B helper for kernel work: the library compiled with extra -D switches into `out` (profiles/kernel_bench.py --lib)."""
     objs, cmds = [], []
     for s in KERNEL_SRCS:
-        o = os.path.join(CSRC, s + ".variant.o")
+        o = os.path.join(CSRC, s + "." + os.path.basename(out) + ".o")
         objs.append(o)
-        cmds.append([HIPCC, *HIP_FLAGS, *[f"-D{d}" for d in defines], "-c", os.path.join(CSRC, s), "-o", o])
+        # DEFINE[=value] becomes -DDEFINE[=value]; anything that starts with '-' is passed to hipcc as it is
+        cmds.append([HIPCC, *HIP_FLAGS, *[d if d.startswith("-") else f"-D{d}" for d in defines], "-c", os.path.join(CSRC, s), "-o", o])
     with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
         list(ex.map(_run, cmds))
     _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs])

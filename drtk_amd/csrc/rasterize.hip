@@ -26,6 +26,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "segscatter.hpp" // wave_lds_sync
 
 #ifdef DRTK_AMD_ABLATION
 // Phase clocks of the profiling build (this translation unit only: device globals do not link across units without
@@ -286,6 +287,14 @@ __device__ __forceinline__ bool fragment(const TriSetup<T>& s, int x, int y, uin
   return true;
 }
 
+// The work queue is sharded: a single head word serves ~88 pops per microsecond (MI355X_MICROARCH.md, "dequeue"), and
+// the ~9000 items of the bench shape, popped by 1024 workgroups, sat on it for most of the ~0.15 ms the pass takes
+// with no triangle work at all.  Item i belongs to shard i % 8; a workgroup starts on shard blockIdx % 8 (its XCD, for
+// what that is worth) and moves on to the next one when its shard runs dry.
+constexpr int kQueueShards = 8;
+constexpr int kQueueStride = 32; // int32 words between the heads (128 B: one head per memory-side line)
+constexpr uint32_t kItemEmpty = 0x80000000u; // work item flag: nothing was binned to this tile
+
 struct BinLayout {
   int tile_shift; // log2(tile size in pixels)
   int tiles_x, tiles_y;
@@ -334,8 +343,8 @@ inline BinLayout make_layout(int64_t N, int64_t F, int64_t H, int64_t W) {
   o += align_up(sizeof(int32_t) * (N > 0 ? N : 1), 256);
   L.off_view_stats = o; // per view: {sum z, count} of positively / negatively oriented triangles
   o += align_up(sizeof(float) * 4 * (N > 0 ? N : 1), 256);
-  L.off_queue = o; // [0] next work item, [1] number of work items
-  o += 256;
+  L.off_queue = o; // [1] number of work items; [kQueueStride * (1 + s)] next position of shard s
+  o += align_up(sizeof(int32_t) * kQueueStride * (1 + kQueueShards), 256);
   L.zero_bytes = o;
   L.off_offset = o;
   o += align_up(sizeof(int32_t) * (L.num_tiles + 1), 256);
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(
     const int sl = split_log_of(c);
     const int cls = class_of(c, sl);
     const int n_sub = 1 << (2 * sl);
-    for (int j = 0; j < n_sub; ++j) items[slot[cls] + j] = make_item(static_cast<uint32_t>(i), j, sl);
+    for (int j = 0; j < n_sub; ++j) items[slot[cls] + j] = make_item(static_cast<uint32_t>(i), j, sl) | (c == 0 ? kItemEmpty : 0u);
     slot[cls] += n_sub;
   };
   if (in_regs) {
@@ -677,6 +686,7 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(
 }
 
 
+#ifdef DRTK_RASTER_LEGACY
 // ---- pass 4: per-tile rasterization with the z-buffer in LDS -----------------------------------
 // Wave-uniform plane equations of one triangle (broadcast out of the lane that set it up).
 template <typename T>
@@ -993,6 +1003,420 @@ __global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
   }
 }
 
+#else
+// ---- pass 4: per-tile rasterization with the z-buffer in LDS -----------------------------------
+// Four triangles per pass, one per 16-lane DPP row.  A wave sets 64 triangles up one per lane (gathers + exact set-up)
+// and then walks them in 16 steps: in step k row r (lanes 16r .. 16r+15) shades the triangle held by ITS lane k -- the
+// plane equations reach the row's lanes with row-local DPP broadcasts (`row_newbcast:k`, which the compiler folds into
+// the consuming instruction where a value is used once), stay in VGPRs, and the row covers the triangle's clipped bbox
+// 16 pixels at a time in row-major order of the bbox (pixel p of the bbox = p % bw, p / bw), resolved with ds_min_u64
+// into the tile.  Against the first design (one triangle per pass, its equations broadcast into SGPRs with 28
+// v_readlane, 64-pixel stamps) the serial per-TRIANGLE chain is paid once per four triangles and runs on the vector
+// unit, and a 16-pixel stamp wastes fewer lanes on a ~100-pixel bbox than a 64-pixel one.
+__device__ __forceinline__ int mbcnt(unsigned long long m) { // set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+template <int K>
+__device__ __forceinline__ int row_bcast(int x) { // lane l <- lane K of l's 16-lane row (all lanes active at the call)
+  return __builtin_amdgcn_mov_dpp(x, 0x150 + K, 0xF, 0xF, true);
+}
+template <int K>
+__device__ __forceinline__ float row_bcast(float x) {
+  return __builtin_bit_cast(float, row_bcast<K>(__builtin_bit_cast(int, x)));
+}
+template <int K>
+__device__ __forceinline__ double row_bcast(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = row_bcast<K>(static_cast<int>(u & 0xFFFFFFFFull));
+  const unsigned hi = row_bcast<K>(static_cast<int>(u >> 32));
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// What a row needs to shade one triangle.  Edge k: b_k = (py - ay) * dx - (px - ax) * dy with the orientation sign
+// (rasterize_kernel.cu:133-141: canonical direction x sign of the denominator) folded into dx, dy -- negating both
+// factors' partner negates the rounded products and their rounded difference exactly, so b_k is the reference's value
+// up to the sign of a zero, which no later operation can see (b_k == 0, b_k >= 0, +-0 / d added to a non-zero sum).
+template <typename T>
+struct TriRow {
+  T ax[3], ay[3], dx[3], dy[3];
+  T abs_denom, rdenom, dinv0, dinv1, dinv2;
+  int id_tl; // triangle id | top-left bits of the three edges << 29 (ids are < 2^29: N F < 2^31 / 4)
+  int box;   // clipped bbox relative to the item's rectangle, 6 bits each: x, y of the first pixel, width - 1, height - 1;
+             // bit 24: there is something to draw
+};
+constexpr int kTlShift = 29;
+constexpr int kBoxDraw = 1 << 24;
+
+template <int K, typename T>
+__device__ __forceinline__ TriRow<T> row_bcast_tri(const TriRow<T>& o) {
+  TriRow<T> u;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    u.ax[k] = row_bcast<K>(o.ax[k]);
+    u.ay[k] = row_bcast<K>(o.ay[k]);
+    u.dx[k] = row_bcast<K>(o.dx[k]);
+    u.dy[k] = row_bcast<K>(o.dy[k]);
+  }
+  u.abs_denom = row_bcast<K>(o.abs_denom);
+  u.rdenom = row_bcast<K>(o.rdenom);
+  u.dinv0 = row_bcast<K>(o.dinv0);
+  u.dinv1 = row_bcast<K>(o.dinv1);
+  u.dinv2 = row_bcast<K>(o.dinv2);
+  u.id_tl = row_bcast<K>(o.id_tl);
+  u.box = row_bcast<K>(o.box);
+  return u;
+}
+
+// Own-lane state from the exact set-up: oriented edges, bbox clipped to the item's rectangle [x0, x1] x [y0, y1].
+template <typename T>
+__device__ __forceinline__ TriRow<T> make_row_state(bool valid, const TriSetup<T>& s, int f, int x0, int y0, int x1, int y1) {
+  TriRow<T> o;
+  const T px[3] = {s.p1x, s.p2x, s.p0x}, py[3] = {s.p1y, s.p2y, s.p0y}; // edge k starts at p_{k+1}
+  const T qx[3] = {s.p2x, s.p0x, s.p1x}, qy[3] = {s.p2y, s.p0y, s.p1y}; // ... and ends at p_{k+2}
+  const bool c[3] = {s.c0, s.c1, s.c2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    o.ax[k] = c[k] ? px[k] : qx[k];
+    o.ay[k] = c[k] ? py[k] : qy[k];
+    const T bx = c[k] ? qx[k] : px[k], by = c[k] ? qy[k] : py[k];
+    const bool neg = c[k] ? (s.sign_denom < T(0)) : !(s.sign_denom < T(0));
+    const T ex = bx - o.ax[k], ey = by - o.ay[k];
+    o.dx[k] = neg ? -ex : ex;
+    o.dy[k] = neg ? -ey : ey;
+  }
+  o.abs_denom = s.abs_denom;
+  o.rdenom = s.rdenom;
+  o.dinv0 = s.dinv0;
+  o.dinv1 = s.dinv1;
+  o.dinv2 = s.dinv2;
+  const int bx0 = max(s.bb_min_x, x0), bx1 = min(s.bb_max_x, x1);
+  const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
+  const bool draw = valid && bx0 <= bx1 && by0 <= by1;
+  o.box = draw ? ((bx0 - x0) | ((by0 - y0) << 6) | ((bx1 - bx0) << 12) | ((by1 - by0) << 18) | kBoxDraw) : 0;
+  o.id_tl = f | ((s.tl0 ? 1 : 0) | (s.tl1 ? 2 : 0) | (s.tl2 ? 4 : 0)) << kTlShift;
+  return o;
+}
+
+// One step: every row shades the triangle `u` it was handed.  Coverage, depth and the packed atomicMin are the
+// reference's (rasterize_kernel.cu:117-161), evaluated per lane = per pixel.
+template <typename T, int TILE_SHIFT>
+__device__ __forceinline__ void shade_rows(
+    const TriRow<T>& u, float lane16_half, float x0f, float y0f, unsigned long long* __restrict__ zbuf, int dbg) {
+  constexpr float kTileF = static_cast<float>(1 << TILE_SHIFT);
+  const float rx0f = static_cast<float>(u.box & 63), ry0f = static_cast<float>((u.box >> 6) & 63);
+  const float bwf = static_cast<float>(((u.box >> 12) & 63) + 1), bhf = static_cast<float>(((u.box >> 18) & 63) + 1);
+  const float npxf = (u.box & kBoxDraw) ? bwf * bhf : 0.0f;
+  const float bx0f = x0f + rx0f, by0f = y0f + ry0f; // absolute pixel coordinates: integers < 2^22, exact
+  const float c0f = __builtin_fmaf(ry0f, kTileF, rx0f); // index of the bbox's first pixel in the LDS tile
+  // pixel p of the bbox -> (p % bw, p / bw) in float: (p + 1/2) / bw is never within 1 / (2 bw) >= 1/128 of an integer,
+  // the product with the 1-ulp reciprocal is off by < 2e-5; p - ly * bw is exact (integers below 2^13)
+  const float rbw = __builtin_amdgcn_rcpf(bwf);
+  const bool div_ok = exact_div_ok(u.abs_denom);
+  const bool ntl0 = !(u.id_tl & (1 << kTlShift)), ntl1 = !(u.id_tl & (2 << kTlShift)), ntl2 = !(u.id_tl & (4 << kTlShift));
+  const unsigned long long id = static_cast<uint32_t>(u.id_tl) & ((1u << kTlShift) - 1u);
+  for (float ph = lane16_half; ph < npxf; ph += 16.0f) {
+    const float fly = __builtin_truncf(ph * rbw);
+    const float flx = __builtin_fmaf(-fly, bwf, ph - 0.5f);
+    const T px = static_cast<T>(bx0f + flx), py = static_cast<T>(by0f + fly);
+    const T b0 = (py - u.ay[0]) * u.dx[0] - (px - u.ax[0]) * u.dy[0];
+    const T b1 = (py - u.ay[1]) * u.dx[1] - (px - u.ax[1]) * u.dy[1];
+    const T b2 = (py - u.ay[2]) * u.dx[2] - (px - u.ax[2]) * u.dy[2];
+    // coverage + top-left rule (:133-145) as ONE predicate: inside or on an edge, and not on an edge that is not top/left
+    const bool inside = (b0 >= T(0)) & (b1 >= T(0)) & (b2 >= T(0));
+    const bool on_excluded_edge = (ntl0 & (b0 == T(0))) | (ntl1 & (b1 == T(0))) | (ntl2 & (b2 == T(0)));
+    if (!inside | on_excluded_edge) continue;
+    const int zi = static_cast<int>(__builtin_fmaf(fly, kTileF, c0f) + flx);
+    if (DRTK_DBG(dbg, 4)) {
+      atomicMin(&zbuf[zi], id);
+      continue;
+    }
+    // b_k / abs_denom (:148), 1 / epsclamp(depth_inverse) (:153): the correctly rounded fast forms are evaluated
+    // unconditionally; whether any lane needs the IEEE fallback (operands outside the guarded range: denormal
+    // quotients, an all-ones significand) is ONE wave-uniform test per pass instead of a divergent branch per
+    // division -- the fallback itself is exact_div / exact_rcp
+    const T q0 = b0 * u.rdenom, q1 = b1 * u.rdenom, q2 = b2 * u.rdenom;
+    const bool fast_ok = div_ok & ((q0 >= DivRange<T>::tiny()) | (b0 == T(0))) & ((q1 >= DivRange<T>::tiny()) | (b1 == T(0))) &
+        ((q2 >= DivRange<T>::tiny()) | (b2 == T(0)));
+    T d0 = markstein2(b0, u.abs_denom, u.rdenom, q0);
+    T d1 = markstein2(b1, u.abs_denom, u.rdenom, q1);
+    T d2 = markstein2(b2, u.abs_denom, u.rdenom, q2);
+    if (__ballot(!fast_ok) != 0) {
+      d0 = exact_div(b0, u.abs_denom, u.rdenom, div_ok);
+      d1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
+      d2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
+    }
+    const T depth_inverse = u.dinv0 * d0 + u.dinv1 * d1 + u.dinv2 * d2;
+    const T di = epsclamp(depth_inverse);
+    T rd = fast_rcp(di);
+    if (__ballot(!fast_rcp_ok(di)) != 0) rd = exact_rcp(di);
+    const float depth = static_cast<float>(rd);
+    const unsigned long long packed = (static_cast<unsigned long long>(__float_as_uint(depth)) << 32) | id;
+    atomicMin(&zbuf[zi], packed);
+  }
+}
+
+// Rasterize the triangles held one per lane (own-lane state `o`): `nsteps` steps, step k = lane k of every row.
+template <typename T, int TILE_SHIFT>
+__device__ __forceinline__ void raster_rows(
+    const TriRow<T>& o, int nsteps, int x0, int y0, unsigned long long* __restrict__ zbuf, int dbg) {
+  const float x0f = static_cast<float>(x0), y0f = static_cast<float>(y0);
+  const float lane16_half = static_cast<float>(lane_id() & 15) + 0.5f;
+  for (int k = 0; k < nsteps; ++k) {
+    TriRow<T> u;
+    switch (k) {
+#define DRTK_ROW_STEP(K) case K: u = row_bcast_tri<K>(o); break;
+      DRTK_ROW_STEP(0) DRTK_ROW_STEP(1) DRTK_ROW_STEP(2) DRTK_ROW_STEP(3) DRTK_ROW_STEP(4) DRTK_ROW_STEP(5)
+      DRTK_ROW_STEP(6) DRTK_ROW_STEP(7) DRTK_ROW_STEP(8) DRTK_ROW_STEP(9) DRTK_ROW_STEP(10) DRTK_ROW_STEP(11)
+      DRTK_ROW_STEP(12) DRTK_ROW_STEP(13) DRTK_ROW_STEP(14)
+      default: u = row_bcast_tri<15>(o); break;
+#undef DRTK_ROW_STEP
+    }
+    shade_rows<T, TILE_SHIFT>(u, lane16_half, x0f, y0f, zbuf, dbg);
+  }
+}
+
+// 8 waves per workgroup share one 32 KiB tile.  Registers: the lane's own triangle (19) + the row's triangle (19) + the
+// pixel loop; bounded to 80 VGPRs = 3 workgroups = 24 waves per CU (what spills at that bound is per-ITEM state: a few
+// scratch accesses per tile, none inside the step or pixel loops).
+#ifndef DRTK_RASTER_WAVES_PER_SIMD
+#define DRTK_RASTER_WAVES_PER_SIMD 6
+#endif
+constexpr int kRasterBlock = 512;
+constexpr int kRasterWaves = kRasterBlock / kWave;
+constexpr int kIdRing = 128; // accepted triangle ids waiting for set-up, per wave (power of two, >= 2 * kWave - 1)
+
+template <typename T, int TILE_SHIFT>
+__global__ __launch_bounds__(kRasterBlock, DRTK_RASTER_WAVES_PER_SIMD) void tile_raster_kernel(
+    const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN,
+    int H, int W, int tiles_x, int tiles_per_view, const int32_t* __restrict__ tile_offset,
+    const unsigned long long* __restrict__ tile_count, const float* __restrict__ view_stats,
+    const int32_t* __restrict__ pairs, const int32_t* __restrict__ big_count,
+    const int32_t* __restrict__ big_list, const uint2* __restrict__ tri_range, const uint4* __restrict__ tri_pre,
+    const uint32_t* __restrict__ items, int32_t* __restrict__ queue, float* __restrict__ depth_img,
+    int32_t* __restrict__ index_img, int dbg) {
+  constexpr int TILE = 1 << TILE_SHIFT;
+  constexpr int NPIX = TILE * TILE;
+  __shared__ unsigned long long zbuf[NPIX];
+  __shared__ uint32_t s_zmax[(TILE / 8) * (TILE / 8)];
+  __shared__ int32_t s_idq[kRasterWaves][kIdRing];
+  __shared__ int s_item;
+
+  const int tid = threadIdx.x;
+  const int wave = tid / kWave, lane = tid & (kWave - 1);
+  const int n_items = queue[1];
+  int shard = blockIdx.x % kQueueShards, dry = 0; // thread 0's view of the queue
+  DRTK_PHASE_INIT();
+  for (;;) {
+    if (tid == 0) {
+      int idx = -1;
+      while (dry < kQueueShards) {
+        idx = atomicAdd(&queue[kQueueStride * (1 + shard)], 1) * kQueueShards + shard;
+        if (idx < n_items) break;
+        idx = -1;
+        ++dry;
+        shard = (shard + 1) % kQueueShards;
+      }
+      s_item = idx;
+    }
+    __syncthreads();
+    if (tid == 0) DRTK_PHASE(0); // queue pop
+    const int item_index = s_item;
+    if (item_index < 0) break;
+    const uint32_t item = items[item_index];
+    const int tile = item & 0xFFFFFF;
+    const int sub = (item >> 24) & 0xF, split_log = (item >> 28) & 3;
+    const int n = tile / tiles_per_view;
+    const int t_in_view = tile - n * tiles_per_view;
+    const int ty = t_in_view / tiles_x, tx = t_in_view - ty * tiles_x;
+    const int ss = TILE >> split_log; // side of this item's rectangle
+    const int x0 = (tx << TILE_SHIFT) + (sub & ((1 << split_log) - 1)) * ss;
+    const int y0 = (ty << TILE_SHIFT) + (sub >> split_log) * ss;
+    const int x1 = min(x0 + ss - 1, W - 1), y1 = min(y0 + ss - 1, H - 1);
+    if (x0 < W && y0 < H) {
+      const int rows = y1 - y0 + 1;
+      const int nbig = big_count[n];
+      const int64_t img_base = int64_t(n) * H * W;
+      const bool vec_ok = (W & 3) == 0;
+      const int quads_per_row = ss >> 2;
+      if ((item & kItemEmpty) && nbig == 0) {
+        // nothing can touch this tile: background straight to the images, no LDS tile, no barrier
+        for (int q = tid; q < rows * quads_per_row; q += kRasterBlock) {
+          const int row = q / quads_per_row;
+          const int col = (q - row * quads_per_row) << 2;
+          const int y = y0 + row, x = x0 + col;
+          if (x > x1) continue;
+          const int64_t o = img_base + int64_t(y) * W + x;
+          if (vec_ok) {
+            *reinterpret_cast<int4*>(index_img + o) = make_int4(-1, -1, -1, -1);
+            *reinterpret_cast<float4*>(depth_img + o) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          } else {
+            for (int j = 0; j < 4 && x + j <= x1; ++j) {
+              index_img[o + j] = -1;
+              depth_img[o + j] = 0.0f;
+            }
+          }
+        }
+        __syncthreads(); // s_item is reused by the next pop
+        continue;
+      }
+      for (int i = tid; i < (ss << TILE_SHIFT); i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
+      __syncthreads();
+      if (tid == 0) DRTK_PHASE(1); // clear
+
+      const T* v_n = v + int64_t(n) * V * 3;
+      const int32_t* vi_n = vi + int64_t(n) * vi_sN;
+      const int nb = ss >> 3; // 8x8-pixel blocks per side of this item's rectangle
+      int32_t* idq = s_idq[wave];
+
+      // The tile's list is partitioned by orientation (bin_fill): [positive ... | ... negative].  The
+      // group that is nearer on average in this view (on a closed mesh: the visible one) is drawn first;
+      // then the farthest depth of every 8x8 block is known (empty pixels count as infinitely far), and
+      // a triangle of the second group whose depth lower bound lies beyond the farthest depth of all
+      // blocks its clipped bbox touches cannot win a single pixel -- (depth, id) only ever decreases --
+      // so it is dropped before any fragment work.  On a closed mesh that removes the hidden half of
+      // the triangles; on any input the image is unchanged (strict comparison: ties still go by id).
+      const int begin = tile_offset[tile], end_all = tile_offset[tile + 1];
+      const int n_pos = static_cast<int>(tile_count[tile] >> 32);
+      const float* st = view_stats + 4 * n;
+      const bool pos_first = st[0] * st[3] <= st[2] * st[1]; // mean z of positive <= mean z of negative
+      const uint4* pre_n = tri_pre + int64_t(n) * F;
+      const int32_t* big_n = big_list + int64_t(n) * F;
+      const uint2* range_n = tri_range + int64_t(n) * F;
+      for (int phase = 0; phase < 2; ++phase) {
+        if (phase == 1 && DRTK_DBG(dbg, 64)) break; // timing only: the second (mostly hidden) group is not drawn at all
+        const bool take_pos = (phase == 0) == pos_first;
+        const int g_begin = take_pos ? begin : begin + n_pos, g_end = take_pos ? begin + n_pos : end_all;
+        // the test on a triangle's pre-reject record (bin_count: clamped pixel bbox + depth lower bound): does its bbox
+        // touch this item's rectangle, and (second group) can it still win a pixel of the 8x8 blocks it touches
+        auto accept = [&](int bx_min, int by_min, int bx_max, int by_max, uint32_t z_lo_bits) -> bool {
+          if (!(bx_min <= x1 && bx_max >= x0 && by_min <= y1 && by_max >= y0)) return false;
+          if (phase == 0 || z_lo_bits == 0 || DRTK_DBG(dbg, 16)) return true;
+          const int cx0 = (max(bx_min, x0) - x0) >> 3, cx1 = (min(bx_max, x1) - x0) >> 3;
+          const int cy0 = (max(by_min, y0) - y0) >> 3, cy1 = (min(by_max, y1) - y0) >> 3;
+          if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 16) return true;
+          uint32_t far = 0;
+          for (int by = cy0; by <= cy1; ++by)
+            for (int bx = cx0; bx <= cx1; ++bx) far = max(far, s_zmax[by * nb + bx]);
+          return !(z_lo_bits > far);
+        };
+        // triangle f of this view on its record alone (one 16-byte load); canvases beyond 65535 pixels a side have no
+        // record (.w == 0): those are tested after the set-up
+        auto pre_accept = [&](int f) -> bool {
+          const uint4 pre = pre_n[f];
+          return pre.w == 0u ||
+              accept(static_cast<int>(pre.x & 0xFFFFu), static_cast<int>(pre.y & 0xFFFFu), static_cast<int>(pre.x >> 16),
+                     static_cast<int>(pre.y >> 16), pre.z);
+        };
+        // The wave's share of the group (equal parts, so that the waves reach the barrier together), then -- with the
+        // first group, whatever their orientation -- its share of the view's big triangles (more than kMaxSmallTiles
+        // tiles; filtered by tile range).  Candidates are screened 64 at a time on their records; the ids that pass
+        // queue up in a wave-private ring until 64 are there (or the input is exhausted), so that set-up and the raster
+        // steps always run on full rows: a split tile's sub-rectangle or the hidden second group pass a few per cent.
+        const int per_wave = (g_end - g_begin + kRasterWaves - 1) / kRasterWaves;
+        int cursor = g_begin + wave * per_wave;
+        const int end = min(cursor + per_wave, g_end);
+        const int big_per_wave = phase == 0 ? (nbig + kRasterWaves - 1) / kRasterWaves : 0;
+        int big_cursor = wave * big_per_wave;
+        const int big_end = min(big_cursor + big_per_wave, phase == 0 ? nbig : 0);
+        int head = 0, tail = 0; // ring positions (wave-uniform)
+        if (DRTK_DBG(dbg, 8)) cursor = end, big_cursor = big_end;
+        for (;;) {
+          while (tail - head < kWave && (cursor < end || big_cursor < big_end)) {
+            bool ok = false;
+            int f = 0;
+            if (cursor < end) {
+              const int i = cursor + lane;
+              if (i < end) {
+                f = pairs[i];
+                ok = pre_accept(f);
+              }
+              cursor += kWave;
+            } else {
+              const int i = big_cursor + lane;
+              if (i < big_end) {
+                f = big_n[i];
+                const uint2 r = range_n[f];
+                const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = (r.y & ~kFacingBit) >> 16;
+                ok = tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1 && pre_accept(f);
+              }
+              big_cursor += kWave;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) idq[(tail + mbcnt(m)) & (kIdRing - 1)] = f;
+            tail += __popcll(m);
+          }
+          const int cnt = min(kWave, tail - head);
+          if (cnt == 0) break;
+          wave_lds_sync();
+          // entry e of the round goes to row e % 4, lane e / 4 of the row: every step has (up to) four triangles
+          const int e = ((lane & 15) << 2) | (lane >> 4);
+          bool valid = e < cnt;
+          const int f = valid ? idq[(head + e) & (kIdRing - 1)] : 0;
+          head += cnt;
+          wave_lds_sync(); // the ring slots just read may be overwritten by the next screening round
+          TriSetup<T> s = {};
+          if (valid) {
+            valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
+            if (valid && pre_n[f].w == 0u) valid = accept(s.bb_min_x, s.bb_min_y, s.bb_max_x, s.bb_max_y, 0u);
+          }
+          const TriRow<T> own = make_row_state<T>(valid, s, f, x0, y0, x1, y1);
+          if (!DRTK_DBG(dbg, 1)) raster_rows<T, TILE_SHIFT>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
+        }
+        if (tid == 0) DRTK_PHASE(2 + 4 * phase); // wave 0's share of the group: 2 = first group, 6 = second
+        if (phase == 1) break;
+        __syncthreads();
+        if (tid == 0) DRTK_PHASE(4); // wave 0 waiting for the other waves' first group
+        for (int bi = wave; bi < nb * nb; bi += kRasterWaves) {
+          const int bx = bi % nb, by = bi / nb;
+          uint32_t m = static_cast<uint32_t>(zbuf[(((by << 3) + (lane >> 3)) << TILE_SHIFT) + (bx << 3) + (lane & 7)] >> 32);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) m = max(m, static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), o)));
+          if (lane == 0) s_zmax[bi] = m;
+        }
+        __syncthreads();
+        if (tid == 0) DRTK_PHASE(5); // block-farthest reduction
+      }
+      __syncthreads();
+      if (tid == 0) DRTK_PHASE(7); // wave 0 waiting for the other waves' second group
+
+      // unpack + store (rasterize_kernel.cu:402-415)
+      for (int q = tid; q < rows * quads_per_row; q += kRasterBlock) {
+        const int row = q / quads_per_row;
+        const int col = (q - row * quads_per_row) << 2;
+        const int y = y0 + row, x = x0 + col;
+        if (x > x1) continue;
+        int32_t idx4[4];
+        float dep4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned long long pv = zbuf[(row << TILE_SHIFT) + col + j];
+          const uint32_t hi = static_cast<uint32_t>(pv >> 32);
+          dep4[j] = (hi == 0xFFFFFFFFu) ? 0.0f : __uint_as_float(hi);
+          idx4[j] = static_cast<int32_t>(static_cast<uint32_t>(pv & 0xFFFFFFFFu));
+        }
+        const int64_t o = img_base + int64_t(y) * W + x;
+        if (vec_ok) { // x % 4 == 0 and W % 4 == 0 -> x+3 < W and 16-byte aligned
+          *reinterpret_cast<int4*>(index_img + o) = make_int4(idx4[0], idx4[1], idx4[2], idx4[3]);
+          *reinterpret_cast<float4*>(depth_img + o) = make_float4(dep4[0], dep4[1], dep4[2], dep4[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (x + j <= x1) {
+              index_img[o + j] = idx4[j];
+              depth_img[o + j] = dep4[j];
+            }
+          }
+        }
+      }
+    }
+    if (tid == 0) DRTK_PHASE(8); // unpack + store (issue)
+    __syncthreads(); // zbuf and s_item are reused by the next item
+    if (tid == 0) DRTK_PHASE(9); // waiting for the other waves' stores
+  }
+}
+
+#endif // DRTK_RASTER_LEGACY
+
 // Diagnostics: exact_div against the IEEE division on pseudo-random operands.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void exact_div_selftest_kernel(
@@ -1083,7 +1507,11 @@ int rasterize_impl(
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   // persistent workgroups pulling work items: as many as can be resident, never more than items
+#ifdef DRTK_RASTER_LEGACY
   const int64_t resident = int64_t(num_compute_units()) * 4;
+#else
+  const int64_t resident = int64_t(num_compute_units()) * (DRTK_RASTER_WAVES_PER_SIMD / 2);
+#endif
   const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(L.max_items, resident));
   if (L.tile_shift == 6) {
     DRTK_LAUNCH(

@@ -47,116 +47,231 @@ def shard_views(n_views: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < rem else 0))
 
 
+class _StagedCast(th.autograd.Function):
+    """`p.to(staging dtype)` whose backward hands the gradient to the reducer IN THE STAGING DTYPE (see
+    SharedGradReducer.upcast)."""
+
+    @staticmethod
+    def forward(ctx, p, reducer, index):
+        ctx.reducer, ctx.index, ctx.dtype = reducer, index, p.dtype
+        return p.to(reducer.flat.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        r = ctx.reducer
+        if r._active():
+            # the whole gradient of this pass (autograd has summed every use of the cast tensor): accumulate it unrounded
+            r._begin_round()
+            r.segments[ctx.index].add_(g.reshape(-1))
+            r._staged_seen.add(ctx.index)
+            r._on_grad_ready(ctx.index)
+            return None, None, None  # the leaf's .grad is written once, by finish(), from the reduced sum
+        return g.to(ctx.dtype), None, None
+
+
 class SharedGradReducer:
     """All-reduces the gradients of view-shared leaf tensors, overlapped with the rest of the backward pass.
 
-    The gradients live in ONE flat buffer (`.grad` of every parameter is a view of its segment, so nothing is packed
-    or unpacked).  A post-accumulate-grad hook on each parameter launches the all-reduce of its segment on a side
-    stream the moment autograd has finished that gradient: on the hot path `attr.grad` (4*V*C bytes, most of the
-    buffer) is final right after interpolate backward, and its collective then runs under render backward, the edge
-    route and transform backward; the vertices' gradient is final last and is reduced at the end.  xGMI is
-    point-to-point and these messages are latency-bound (megabytes), so each segment is one call.
+    `params` lists tensors and/or LISTS of tensors; a list is a group that is reduced by ONE collective (many small
+    leaves -- the levels of a mip pyramid -- must not cost one latency-bound call each).  All gradients live in ONE flat
+    buffer of `dtype` (default: the parameters' common dtype, float32 if they differ):
+
+    * a parameter of that dtype has its `.grad` set to a VIEW of its segment, so nothing is packed or unpacked;
+    * a parameter of another dtype (fp16 attributes / textures) is STAGED: its segment holds the gradient in the buffer's
+      dtype, the sum over the ranks is formed there, and `.grad` receives it rounded once, after the reduction.  Feed
+      such a leaf to the pipeline through `reducer.upcast(p)` and its gradient is also ACCUMULATED unrounded (the
+      gradient of the cast tensor goes straight into the segment); without `upcast` the leaf's own, already rounded
+      `.grad` is copied into the segment when it is final.
+
+    Order of the collectives.  Every rank must issue the same collectives in the same order, whatever its autograd
+    graph looked like this step (a rank with an empty shard runs no backward pass at all; a parameter may be unused on
+    one rank).  So the order is FIXED: groups are reduced last-listed first -- list the tensors in the order the
+    forward pass uses them, their gradients then become final in the order the collectives are issued.  A gradient
+    hook only marks its parameter ready; the next group in the fixed order is launched (on a side stream) as soon as
+    all its members are ready, and `finish()` launches the rest in the same order, ready or not (a parameter that got
+    no gradient takes part with zeros).  On the hot path `attr.grad` (4*V*C bytes, most of the buffer) is final right
+    after interpolate backward: listed after the vertices, its collective runs under render backward, the edge route
+    and transform backward; the vertices' gradient is final last and is reduced at the end.
+
+    One backward pass per `finish()`: a group that was already reduced this round would silently receive
+    un-reduced local gradients from a second pass, so that raises.  For gradient accumulation run the earlier passes
+    under `with reducer.no_sync():` -- they only accumulate locally, the last pass (outside the context) reduces the sum.
 
     Usage per step:   reducer.zero_grad();  loss.backward();  reducer.finish();  optimizer.step()
-    `finish()` reduces whatever no hook has reduced yet (a parameter without gradient this step still takes part, with
-    zeros: every rank issues the same collectives in the same order), waits for the side stream and leaves the summed
-    (or averaged) gradients in `.grad`.  `all_reduce()` is the old name of `finish()`; with `overlap=False` no hooks
-    are installed and `finish()` does everything after the backward pass, in one call on the whole buffer.
+    `all_reduce()` is the old name of `finish()`; with `overlap=False` nothing is launched from inside the backward
+    pass and `finish()` reduces the whole buffer in one call.
     """
 
-    def __init__(self, params: Iterable[th.Tensor], average: bool = False, overlap: bool = True):
-        self.params: List[th.Tensor] = list(params)
+    def __init__(self, params: Iterable, average: bool = False, overlap: bool = True, dtype: Optional[th.dtype] = None):
+        groups = [list(g) if isinstance(g, (list, tuple)) else [g] for g in params]
+        self.params: List[th.Tensor] = [p for g in groups for p in g]
         assert self.params, "no shared tensors given"
-        dev, dt = self.params[0].device, self.params[0].dtype
-        assert all(p.device == dev and p.dtype == dt and p.is_leaf for p in self.params)
+        dev = self.params[0].device
+        assert all(p.device == dev and p.is_leaf and p.is_floating_point() for p in self.params)
+        dtypes = {p.dtype for p in self.params}
+        if dtype is None:
+            dtype = dtypes.pop() if len(dtypes) == 1 else th.float32
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = th.zeros(self.numel, dtype=dt, device=dev)
+        self.flat = th.zeros(self.numel, dtype=dtype, device=dev)
         self.average = average
         self.overlap = overlap
         self.cuda = dev.type == "cuda"
         self.stream = th.cuda.Stream(device=dev) if self.cuda else None
-        self.segments = []
+        self.segments, self.direct, self.group_of = [], [], []
+        self.group_members: List[List[int]] = []
+        self.group_slices = []
         off = 0
-        for p in self.params:
-            self.segments.append(self.flat[off:off + p.numel()])
-            off += p.numel()
-        self._pending = {}   # param index -> work handle of its in-flight all-reduce
-        self._reduced = set()
-        self._events = []    # (start, end) HIP events on the side stream, one pair per collective of the step
+        for gi, g in enumerate(groups):
+            g_off, members = off, []
+            for p in g:
+                members.append(len(self.segments))
+                self.segments.append(self.flat[off:off + p.numel()])
+                self.direct.append(p.dtype == dtype)
+                self.group_of.append(gi)
+                off += p.numel()
+            self.group_members.append(members)
+            self.group_slices.append(self.flat[g_off:off])
+        self.order = list(range(len(groups) - 1, -1, -1))  # launch order of the groups: fixed, the same on every rank
+        self._next = 0          # position in `order` of the next group to launch
+        self._ready = set()     # parameters whose gradient of this round is final
+        self._staged_seen = set()  # staged parameters whose segment was filled through upcast() this round
+        self._pending = {}      # group index -> work handle of its in-flight all-reduce
+        self._events = []       # (start, end) HIP events on the side stream, one pair per collective of the step
         self._handles = []
         self._finished = False
+        self._defer = False
+        self._staged_dirty = False  # staged segments still hold the last round's reduced sums (readable until the next round)
         self._wait_events = None
         self.enabled = True  # False: hooks and finish() do nothing (a rank stepping on its own, e.g. for profiling)
-        if overlap:
-            for i, p in enumerate(self.params):
-                self._handles.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._launch(i)))
+        for i, p in enumerate(self.params):
+            self._handles.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_leaf_grad(i)))
         self.zero_grad()
 
     def nbytes(self) -> int:
         return self.flat.numel() * self.flat.element_size()
 
+    def collectives_per_step(self) -> int:
+        return len(self.group_members) if self.overlap else 1
+
     def _active(self) -> bool:
         return self.enabled and dist.is_initialized() and dist.get_world_size() > 1
 
+    def upcast(self, p: th.Tensor) -> th.Tensor:
+        """`p` in the buffer's dtype for use in the forward pass.  For a staged parameter (stored in another dtype) the
+        gradient of the returned tensor is accumulated into the flat buffer unrounded and reduced there; `p.grad` is
+        written once by `finish()`.  With the reducer inactive (one rank) this is `p.to(dtype)` with the usual gradient."""
+        i = next((k for k, q in enumerate(self.params) if q is p), None)
+        assert i is not None, "upcast(): not one of this reducer's tensors"
+        return p if self.direct[i] else _StagedCast.apply(p, self, i)
+
+    def no_sync(self):
+        """Context manager: backward passes inside it only accumulate locally (no collective is launched); the first
+        pass outside reduces the accumulated sum."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self):
+                reducer._defer = True
+
+            def __exit__(self, *exc):
+                reducer._defer = False
+                return False
+
+        return _NoSync()
+
     def zero_grad(self) -> None:
-        """Zero the flat buffer and (re-)attach every `.grad` as a view of its segment."""
+        """Zero the flat buffer, (re-)attach every direct `.grad` as a view of its segment, drop the staged ones."""
         self.flat.zero_()
-        for p, seg in zip(self.params, self.segments):
-            p.grad = seg.view_as(p)
-        self._pending.clear()
-        self._reduced.clear()
+        for p, seg, direct in zip(self.params, self.segments, self.direct):
+            p.grad = seg.view_as(p) if direct else None
+        self._reset_round()
+        self._staged_dirty = False
         self._events.clear()
+
+    def _begin_round(self) -> None:
+        """Staged segments ACCUMULATE, so a new round must find them zero: the sums finish() left there (in the buffer's
+        dtype, for whoever wants them unrounded) are cleared when the next round's first gradient arrives."""
+        if self._staged_dirty:
+            for seg, direct in zip(self.segments, self.direct):
+                if not direct:
+                    seg.zero_()
+            self._staged_dirty = False
+
+    def _reset_round(self) -> None:
+        self._pending.clear()
+        self._ready.clear()
+        self._staged_seen.clear()
+        self._next = 0
 
     def _new_step(self) -> None:
         if self._finished:  # first collective after a finish(): a new step's bookkeeping
             self._events.clear()
             self._finished = False
 
-    def _launch(self, i: int) -> None:
-        if not self._active() or i in self._reduced:
+    def _on_leaf_grad(self, i: int) -> None:
+        # a leaf fed through upcast() still sees its (undefined) gradient arrive: that pass was already accounted for
+        if i not in self._staged_seen:
+            self._on_grad_ready(i)
+
+    def _on_grad_ready(self, i: int) -> None:
+        if not self._active() or self._defer:
             return
-        self._new_step()
+        if self.group_of[i] in self._pending:
+            raise RuntimeError(
+                "SharedGradReducer: a second backward pass reached a gradient whose all-reduce was already launched this "
+                "round -- it would add un-reduced local gradients to the reduced sum.  Call finish() after every backward "
+                "pass, or run the passes to be accumulated under `with reducer.no_sync():`")
+        self._begin_round()
+        self._ready.add(i)
+        if self.overlap:
+            while self._next < len(self.order) and all(m in self._ready for m in self.group_members[self.order[self._next]]):
+                self._launch(self.order[self._next])
+                self._next += 1
+
+    def _fill_segment(self, i: int) -> None:
+        """Bring parameter i's segment up to date with its gradient, whichever way that gradient was delivered."""
         p, seg = self.params[i], self.segments[i]
+        if i in self._staged_seen:
+            return  # accumulated unrounded by upcast()'s backward
         if p.grad is None:
-            seg.zero_()
-        elif p.grad.data_ptr() != seg.data_ptr():  # someone replaced .grad (e.g. zero_grad(set_to_none=True)): pack it
-            seg.copy_(p.grad.reshape(-1))
-        self._reduced.add(i)
+            if self.direct[i]:
+                seg.zero_()  # (a staged segment without gradient is still zero from zero_grad() / the last finish())
+        elif not (self.direct[i] and p.grad.data_ptr() == seg.data_ptr()):
+            seg.copy_(p.grad.reshape(-1))  # replaced `.grad` (zero_grad(set_to_none=True)) or a staged leaf's own gradient
+
+    def _all_reduce(self, key: int, buf: th.Tensor) -> None:
         if self.cuda:
             cur = th.cuda.current_stream(self.flat.device)
             self.stream.wait_stream(cur)  # the gradient is written on the stream autograd runs on
             with th.cuda.stream(self.stream):
                 ev0 = th.cuda.Event(enable_timing=True)
                 ev0.record()
-                self._pending[i] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+                self._pending[key] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
                 self._events.append([ev0, None])
         else:
-            self._pending[i] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+            self._pending[key] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _launch(self, g: int) -> None:
+        self._new_step()
+        self._begin_round()
+        for i in self.group_members[g]:
+            self._fill_segment(i)
+        self._all_reduce(g, self.group_slices[g])
 
     def finish(self) -> None:
         if not self._active():
             return
-        if not self.overlap and not self._reduced:
-            # one call on the whole buffer (gradients that are not views of it are packed first)
+        if not self.overlap:
+            # one call on the whole buffer
             self._new_step()
-            for i, (p, seg) in enumerate(zip(self.params, self.segments)):
-                if p.grad is None:
-                    seg.zero_()
-                elif p.grad.data_ptr() != seg.data_ptr():
-                    seg.copy_(p.grad.reshape(-1))
-                self._reduced.add(i)
-            if self.cuda:
-                self.stream.wait_stream(th.cuda.current_stream(self.flat.device))
-                with th.cuda.stream(self.stream):
-                    ev0 = th.cuda.Event(enable_timing=True)
-                    ev0.record()
-                    self._pending[-1] = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
-                    self._events.append([ev0, None])
-            else:
-                self._pending[-1] = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+            self._begin_round()
+            for i in range(len(self.params)):
+                self._fill_segment(i)
+            self._all_reduce(-1, self.flat)
         else:
-            for i in range(len(self.params)):  # parameters whose hook did not fire, in a fixed order
-                self._launch(i)
+            while self._next < len(self.order):  # groups no hook completed, in the same fixed order
+                self._launch(self.order[self._next])
+                self._next += 1
         if self.cuda:
             cur = th.cuda.current_stream(self.flat.device)
             with th.cuda.stream(self.stream):
@@ -174,14 +289,17 @@ class SharedGradReducer:
         else:
             for work in self._pending.values():
                 work.wait()
-        self._pending.clear()
-        self._reduced.clear()  # the next backward pass starts a new round, whoever zeroes the gradients
+        self._reset_round()  # the next backward pass starts a new round, whoever zeroes the gradients
         self._finished = True
         if self.average:
             self.flat.div_(dist.get_world_size())
-        for p, seg in zip(self.params, self.segments):
-            if p.grad is None or p.grad.data_ptr() != seg.data_ptr():
-                p.grad = seg.view_as(p)
+        for p, seg, direct in zip(self.params, self.segments, self.direct):
+            if direct:
+                if p.grad is None or p.grad.data_ptr() != seg.data_ptr():
+                    p.grad = seg.view_as(p)
+            else:
+                p.grad = seg.view_as(p).to(p.dtype)  # the ONE rounding of a staged gradient
+                self._staged_dirty = True
 
     all_reduce = finish
 

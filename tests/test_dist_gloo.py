@@ -76,10 +76,10 @@ def _worker(rank, world, port, out_dir):
         order = []
         if overlap:
             launch = red._launch
-            red._launch = lambda i, launch=launch, order=order: (order.append(i), launch(i))[1]
+            red._launch = lambda g, launch=launch, order=order: (order.append(g), launch(g))[1]
         loss = _local_step(ops, v_world, attr, vi, cams, views, H, W)
         if overlap:
-            assert order[:2] == [1, 0], order  # attributes first (final after interpolate backward), vertices last
+            assert order == [1, 0], order  # attributes first (final after interpolate backward), vertices last
             assert set(red._pending) == {0, 1}  # both collectives were launched from inside the backward pass
         else:
             assert not red._pending
@@ -96,6 +96,67 @@ def _worker(rank, world, port, out_dir):
         _local_step(ops, v_world, attr, vi, cams, views, H, W)
         red.all_reduce()
         out.update({f"v_step{step}": v_world.grad.clone(), f"a_step{step}": attr.grad.clone()})
+    for h in red._handles:
+        h.remove()
+
+    # (d) a second backward pass before finish() must not add local gradients to a sum that was already reduced:
+    # it raises; gradient accumulation goes through no_sync() -- two passes, one reduction of their sum
+    red = ddist.SharedGradReducer([v_world, attr])
+    _local_step(ops, v_world, attr, vi, cams, views, H, W)
+    try:
+        _local_step(ops, v_world, attr, vi, cams, views, H, W)
+        out["second_backward_raised"] = False
+    except RuntimeError as e:
+        out["second_backward_raised"] = "no_sync" in str(e)
+    red.finish()
+    red.zero_grad()
+    with red.no_sync():
+        _local_step(ops, v_world, attr, vi, cams, views, H, W)
+        assert not red._pending
+    _local_step(ops, v_world, attr, vi, cams, views, H, W)
+    red.finish()
+    out.update({"v_accum": v_world.grad.clone(), "a_accum": attr.grad.clone()})
+    for h in red._handles:
+        h.remove()
+
+    # (e) a rank whose shard is EMPTY (one view, two ranks) runs no backward pass at all: no hook fires there, finish()
+    # issues the same collectives in the same fixed order as the rank that launched them from its hooks
+    red = ddist.SharedGradReducer([v_world, attr])
+    one = ddist.shard_views(1, rank, world)
+    launched = []
+    launch = red._launch
+    red._launch = lambda g, launch=launch: (launched.append((g, bool(red._ready))), launch(g))[1]
+    if len(one):
+        _local_step(ops, v_world, attr, vi, cams, one, H, W)
+    red.finish()
+    out.update({"v_one": v_world.grad.clone(), "a_one": attr.grad.clone(), "one_views": list(one), "one_launched": launched})
+    for h in red._handles:
+        h.remove()
+
+    # (f) leaves stored in fp16 (attributes), reduced as ONE group with the vertices' own collective beside it: staged in
+    # float32 -- accumulated unrounded through upcast(), summed over the ranks in float32, rounded to fp16 once
+    attr16 = attr.detach().half().requires_grad_(True)
+    extra16 = th.ones(3, dtype=th.float16, requires_grad=True)  # a second member of the group; no gradient on rank 1
+    red = ddist.SharedGradReducer([v_world, [attr16, extra16]], dtype=th.float32)
+    assert red.collectives_per_step() == 2 and red.flat.dtype == th.float32 and attr16.grad is None
+    v_world.grad = None
+    n = len(views)
+    from drtk_amd.transform import transform
+
+    campos, camrot, focal, princpt = (t[views.start:views.stop] for t in cams)
+    v_pix = transform(v_world[None].expand(n, -1, -1), campos, camrot, focal, princpt)
+    a32 = red.upcast(attr16)
+    assert a32.dtype == th.float32 and th.equal(a32, attr16.float())
+    index_img = ops.rasterize(v_pix, vi, H, W)
+    depth_img, bary_img = ops.render(v_pix, vi, index_img)
+    img = ops.interpolate(a32.expand(n, -1, -1), vi, index_img, bary_img)
+    img = th.where((index_img != -1)[:, None], img, 0.0)
+    extra = red.upcast(extra16).sum() * (3.0 if rank == 0 else 0.0) if rank == 0 else 0.0
+    ((img * img).sum() + depth_img.sum() + extra).backward()
+    red.finish()
+    i16 = next(k for k, q in enumerate(red.params) if q is attr16)
+    out.update({"a16_f32_sum": red.segments[i16].clone().view_as(attr16), "a16_grad": attr16.grad.clone(),
+                "extra16_grad": extra16.grad.clone(), "a16_input": attr16.detach().float()})
     ddist.barrier_and_sync()
     th.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     th.distributed.destroy_process_group()
@@ -131,8 +192,35 @@ def test_two_ranks_match_single_process(tmp_path):
     N, H, W, C, v_world, vi, cams, attr = _scene()
     v_world = v_world.clone().requires_grad_(True)
     attr = attr.clone().requires_grad_(True)
-    loss = _local_step(make_ops(OracleBackend(1)), v_world, attr, vi, cams, range(0, N), H, W)
+    ops = make_ops(OracleBackend(1))
+    loss = _local_step(ops, v_world, attr, vi, cams, range(0, N), H, W)
     assert abs(loss - (res[0]["loss"] + res[1]["loss"])) <= 1e-3 * abs(loss)
     for got, want in ((res[0]["v"], v_world.grad), (res[0]["a"], attr.grad)):
         tol = 1e-5 + 1e-5 * float(want.abs().max())
         assert float((got - want).abs().max()) <= tol * 10
+    # (d) second backward before finish() raises and names no_sync(); two accumulated passes = twice the gradients
+    for r in res:
+        assert r["second_backward_raised"] is True
+        for k, want in (("v_accum", v_world.grad), ("a_accum", attr.grad)):
+            assert float((r[k] - 2 * want).abs().max()) <= 2e-4 * float(want.abs().max()), k
+    # (e) one view over two ranks: rank 1 has none, ran no backward pass, launched both collectives from finish() in the
+    # order rank 0 launched them from its hooks; both end with the one-view gradients
+    assert res[0]["one_views"] == [0] and res[1]["one_views"] == []
+    assert [g for g, _ in res[0]["one_launched"]] == [g for g, _ in res[1]["one_launched"]] == [1, 0]
+    assert all(ready for _, ready in res[0]["one_launched"]) and not any(ready for _, ready in res[1]["one_launched"])
+    v1, a1 = v_world.detach().clone().requires_grad_(True), attr.detach().clone().requires_grad_(True)
+    _local_step(ops, v1, a1, vi, cams, range(0, 1), H, W)
+    for r in res:
+        for got, want in ((r["v_one"], v1.grad), (r["a_one"], a1.grad)):
+            assert float((got - want).abs().max()) <= 1e-5 + 1e-5 * float(want.abs().max())
+    # (f) fp16 leaves staged in float32: the float32 sum over the ranks equals the single-process float32 gradient (at
+    # the fp16-stored attribute values) to 1e-5, the leaf's .grad is that sum rounded ONCE, and the group member that
+    # only rank 0 used carries rank 0's gradient on both ranks
+    a_in = res[0]["a16_input"].clone().requires_grad_(True)
+    v2 = v_world.detach().clone().requires_grad_(True)
+    _local_step(ops, v2, a_in, vi, cams, range(0, N), H, W)
+    for r in res:
+        tol = 1e-5 + 1e-5 * float(a_in.grad.abs().max())
+        assert float((r["a16_f32_sum"] - a_in.grad).abs().max()) <= tol
+        assert r["a16_grad"].dtype == th.float16 and th.equal(r["a16_grad"], r["a16_f32_sum"].half())
+        assert th.equal(r["extra16_grad"], th.full((3,), 3.0, dtype=th.float16))
