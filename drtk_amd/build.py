@@ -46,6 +46,26 @@ def _newer(target, deps):
     return os.path.isfile(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
 
 
+def check_no_vgpr_spills(compiler_output, what):
+    """No kernel of the library may spill vector registers.  A spill is not only slow: ROCm 7.2's register allocator was
+    seen to place a spill STORE in a block that runs with an empty EXEC mask (straight after a divergent loop's exit,
+    before the mask is restored), so the value never reached its slot and the reload returned a stale one -- in
+    tile_raster that silently dropped almost half of the work items (round 3).  Kernels are kept below their register
+    bound by construction; this check (over -Rpass-analysis=kernel-resource-usage) keeps it that way."""
+    import re
+
+    name, bad = "?", []
+    for line in compiler_output.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and int(m.group(1)) != 0:
+            bad.append(f"{name}: {m.group(1)} VGPRs spilled")
+    if bad:
+        raise RuntimeError(f"{what}: vector register spills are not allowed (see build.py check_no_vgpr_spills):\n  " + "\n  ".join(bad))
+
+
 def build_kernels(force=False, verbose=True):
     deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
     if not force and _newer(LIB, deps):
@@ -54,9 +74,12 @@ def build_kernels(force=False, verbose=True):
     for s in KERNEL_SRCS:
         o = os.path.join(CSRC, s + ".o")
         objs.append(o)
-        cmds.append([HIPCC, *HIP_FLAGS, "-c", os.path.join(CSRC, s), "-o", o])
+        cmds.append([HIPCC, *HIP_FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, s), "-o", o])
     with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
         outs = list(ex.map(_run, cmds))
+    for s, out in zip(KERNEL_SRCS, outs):
+        check_no_vgpr_spills(out, s)
+    outs = ["\n".join(l for l in out.splitlines() if "remark:" not in l and "[-Rpass-analysis" not in l and l.strip() not in ("^",) and not l.lstrip().startswith(("|", "^")) and not l.strip().split(" | ")[0].strip().isdigit()) for out in outs]
     _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
     for o in objs:
         os.remove(o)

@@ -164,12 +164,19 @@ def rasterize_lines_workspace_bytes(N, H, W) -> int:
 
 
 @_on_tensor_device
-def rasterize(v, vi, height, width, stream=None, workspace=None, wireframe=False) -> Tuple[th.Tensor, th.Tensor]:
+def rasterize(v, vi, height, width, stream=None, workspace=None, wireframe=False, out=None) -> Tuple[th.Tensor, th.Tensor]:
+    """`out` = (depth_img, index_img) to write into (contiguous [N,H,W] float32 / int32): tests pre-fill them with a
+    sentinel to see that every pixel is written."""
     v = v.contiguous()
     N, V, _ = v.shape
     vi_c, vi_sN, F = _vi(vi, N)
-    depth = th.empty(N, height, width, dtype=th.float32, device=v.device)
-    index = th.empty(N, height, width, dtype=th.int32, device=v.device)
+    if out is not None:
+        depth, index = out
+        assert depth.shape == (N, height, width) and index.shape == (N, height, width) and depth.is_contiguous() and index.is_contiguous()
+        assert depth.dtype == th.float32 and index.dtype == th.int32
+    else:
+        depth = th.empty(N, height, width, dtype=th.float32, device=v.device)
+        index = th.empty(N, height, width, dtype=th.int32, device=v.device)
     nbytes = rasterize_lines_workspace_bytes(N, height, width) if wireframe else rasterize_workspace_bytes(N, F, height, width)
     ws = workspace if workspace is not None else th.empty(nbytes, dtype=th.uint8, device=v.device)
     _check(

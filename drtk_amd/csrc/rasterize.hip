@@ -156,6 +156,26 @@ __device__ __forceinline__ float fast_rcp(float x) {
 __device__ __forceinline__ bool fast_rcp_ok(double) {
   return true;
 }
+// fast_rcp_ok for an argument that went through epsclamp (|x| >= 1e-8 > 2^-100, NaN replaced by eps): only the upper
+// end of the range and the all-ones significand remain to be tested
+__device__ __forceinline__ bool fast_rcp_ok_clamped(float x) {
+  const uint32_t bits = __float_as_uint(x);
+  return ((bits & 0x7FFFFFu) != 0x7FFFFFu) & (__uint_as_float(bits & 0x7FFFFFFFu) <= 0x1p100f);
+}
+__device__ __forceinline__ bool fast_rcp_ok_clamped(double) {
+  return true;
+}
+// +0, or the smallest positive (subnormal) number of T
+template <typename T>
+__device__ __forceinline__ T smallest_positive_if(bool on);
+template <>
+__device__ __forceinline__ float smallest_positive_if<float>(bool on) {
+  return __uint_as_float(on ? 1u : 0u);
+}
+template <>
+__device__ __forceinline__ double smallest_positive_if<double>(bool on) {
+  return __longlong_as_double(on ? 1ll : 0ll);
+}
 __device__ __forceinline__ double fast_rcp(double x) {
   return 1.0 / x;
 }
@@ -291,7 +311,10 @@ __device__ __forceinline__ bool fragment(const TriSetup<T>& s, int x, int y, uin
 // the ~9000 items of the bench shape, popped by 1024 workgroups, sat on it for most of the ~0.15 ms the pass takes
 // with no triangle work at all.  Item i belongs to shard i % 8; a workgroup starts on shard blockIdx % 8 (its XCD, for
 // what that is worth) and moves on to the next one when its shard runs dry.
-constexpr int kQueueShards = 8;
+#ifndef DRTK_RASTER_QUEUE_SHARDS
+#define DRTK_RASTER_QUEUE_SHARDS 8
+#endif
+constexpr int kQueueShards = DRTK_RASTER_QUEUE_SHARDS;
 constexpr int kQueueStride = 32; // int32 words between the heads (128 B: one head per memory-side line)
 constexpr uint32_t kItemEmpty = 0x80000000u; // work item flag: nothing was binned to this tile
 
@@ -313,7 +336,10 @@ struct BinLayout {
 // 1.9 with 2048; lower thresholds only lose: 256 0.451, 192 0.487, 128 0.577 ms on the bench shape).
 constexpr int kSplit4Min = 384, kSplit4Max = 2048;
 inline int split_threshold(int64_t N, int64_t F) {
-  const int64_t slots = int64_t(num_compute_units()) * 4; // resident raster workgroups
+#ifndef DRTK_RASTER_SPLIT_SLOTS
+#define DRTK_RASTER_SPLIT_SLOTS 4
+#endif
+  const int64_t slots = int64_t(num_compute_units()) * DRTK_RASTER_SPLIT_SLOTS; // resident raster workgroups
   const int64_t t = (N * F * 13) / (20 * (slots > 0 ? slots : 1)); // 0.65 x triangles per slot
   return static_cast<int>(t < kSplit4Min ? kSplit4Min : (t > kSplit4Max ? kSplit4Max : t));
 }
@@ -1097,6 +1123,66 @@ __device__ __forceinline__ TriRow<T> make_row_state(bool valid, const TriSetup<T
   return o;
 }
 
+#ifdef DRTK_RASTER_RAW_STATE
+// Variant: the lane keeps the RAW set-up (six coordinates + orientation flags in `box`) and the row derives the
+// oriented edges after the broadcast: 13 instead of 19 registers of own-lane state, ~30 more VALU per step.
+constexpr int kBoxC0 = 1 << 25, kBoxC1 = 1 << 26, kBoxC2 = 1 << 27, kBoxNeg = 1 << 28;
+template <typename T>
+struct TriRaw {
+  T p0x, p0y, p1x, p1y, p2x, p2y;
+  T abs_denom, rdenom, dinv0, dinv1, dinv2;
+  int id_tl, box;
+};
+template <typename T>
+__device__ __forceinline__ TriRaw<T> make_raw_state(bool valid, const TriSetup<T>& s, int f, int x0, int y0, int x1, int y1) {
+  TriRaw<T> o;
+  o.p0x = s.p0x, o.p0y = s.p0y, o.p1x = s.p1x, o.p1y = s.p1y, o.p2x = s.p2x, o.p2y = s.p2y;
+  o.abs_denom = s.abs_denom, o.rdenom = s.rdenom, o.dinv0 = s.dinv0, o.dinv1 = s.dinv1, o.dinv2 = s.dinv2;
+  const int bx0 = max(s.bb_min_x, x0), bx1 = min(s.bb_max_x, x1);
+  const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
+  const bool draw = valid && bx0 <= bx1 && by0 <= by1;
+  o.box = draw ? ((bx0 - x0) | ((by0 - y0) << 6) | ((bx1 - bx0) << 12) | ((by1 - by0) << 18) | kBoxDraw |
+                  (s.c0 ? kBoxC0 : 0) | (s.c1 ? kBoxC1 : 0) | (s.c2 ? kBoxC2 : 0) | (s.sign_denom < T(0) ? kBoxNeg : 0)) : 0;
+  o.id_tl = f | ((s.tl0 ? 1 : 0) | (s.tl1 ? 2 : 0) | (s.tl2 ? 4 : 0)) << kTlShift;
+  return o;
+}
+template <int K, typename T>
+__device__ __forceinline__ TriRow<T> row_bcast_tri(const TriRaw<T>& o) {
+  const T p0x = row_bcast<K>(o.p0x), p0y = row_bcast<K>(o.p0y), p1x = row_bcast<K>(o.p1x), p1y = row_bcast<K>(o.p1y);
+  const T p2x = row_bcast<K>(o.p2x), p2y = row_bcast<K>(o.p2y);
+  TriRow<T> u;
+  u.abs_denom = row_bcast<K>(o.abs_denom);
+  u.rdenom = row_bcast<K>(o.rdenom);
+  u.dinv0 = row_bcast<K>(o.dinv0);
+  u.dinv1 = row_bcast<K>(o.dinv1);
+  u.dinv2 = row_bcast<K>(o.dinv2);
+  u.id_tl = row_bcast<K>(o.id_tl);
+  u.box = row_bcast<K>(o.box);
+  const T px[3] = {p1x, p2x, p0x}, py[3] = {p1y, p2y, p0y};
+  const T qx[3] = {p2x, p0x, p1x}, qy[3] = {p2y, p0y, p1y};
+  const bool c[3] = {(u.box & kBoxC0) != 0, (u.box & kBoxC1) != 0, (u.box & kBoxC2) != 0};
+  const bool sneg = (u.box & kBoxNeg) != 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    u.ax[k] = c[k] ? px[k] : qx[k];
+    u.ay[k] = c[k] ? py[k] : qy[k];
+    const T bx = c[k] ? qx[k] : px[k], by = c[k] ? qy[k] : py[k];
+    const bool neg = c[k] ? sneg : !sneg;
+    const T ex = bx - u.ax[k], ey = by - u.ay[k];
+    u.dx[k] = neg ? -ex : ex;
+    u.dy[k] = neg ? -ey : ey;
+  }
+  return u;
+}
+template <typename T>
+using TriOwn = TriRaw<T>;
+#define DRTK_MAKE_OWN make_raw_state
+#else
+template <typename T>
+using TriOwn = TriRow<T>;
+#define DRTK_MAKE_OWN make_row_state
+#endif
+
 // One step: every row shades the triangle `u` it was handed.  Coverage, depth and the packed atomicMin are the
 // reference's (rasterize_kernel.cu:117-161), evaluated per lane = per pixel.
 template <typename T, int TILE_SHIFT>
@@ -1110,9 +1196,19 @@ __device__ __forceinline__ void shade_rows(
   const float c0f = __builtin_fmaf(ry0f, kTileF, rx0f); // index of the bbox's first pixel in the LDS tile
   // pixel p of the bbox -> (p % bw, p / bw) in float: (p + 1/2) / bw is never within 1 / (2 bw) >= 1/128 of an integer,
   // the product with the 1-ulp reciprocal is off by < 2e-5; p - ly * bw is exact (integers below 2^13)
-  const float rbw = __builtin_amdgcn_rcpf(bwf);
+  float rbw = __builtin_amdgcn_rcpf(bwf);
+  asm volatile("" : "+v"(rbw)); // keeps the quarter-rate reciprocal OUT of the pixel loop (the compiler rematerialises it there)
   const bool div_ok = exact_div_ok(u.abs_denom);
-  const bool ntl0 = !(u.id_tl & (1 << kTlShift)), ntl1 = !(u.id_tl & (2 << kTlShift)), ntl2 = !(u.id_tl & (4 << kTlShift));
+  // Coverage + top-left rule (:133-145) as three comparisons: a pixel is kept iff b_k >= 0 on top-left edges and b_k > 0
+  // on the others, i.e. b_k >= thr_k with thr_k = +0 or the smallest positive (subnormal) number -- `b >= denorm_min`
+  // IS `b > 0`; comparisons never flush subnormals.  (-0 >= +0 holds, -0 >= denorm_min does not: same as the two-sided form.)
+  const T thr0 = smallest_positive_if<T>(!(u.id_tl & (1 << kTlShift)));
+  const T thr1 = smallest_positive_if<T>(!(u.id_tl & (2 << kTlShift)));
+  const T thr2 = smallest_positive_if<T>(!(u.id_tl & (4 << kTlShift)));
+  // The fast quotients are valid when b_k * rdenom >= DivRange::tiny() or b_k == 0 (exact_div's guard).  ONE cheaper,
+  // stricter test decides for the wave: every b_k >= 2^-40 abs_denom (then the quotient is >= ~2^-41); a pixel exactly on
+  // an edge (b_k == 0) therefore also sends its wave through exact_div, which is correct for it -- only slower.
+  const T b_min = u.abs_denom * T(0x1p-40);
   const unsigned long long id = static_cast<uint32_t>(u.id_tl) & ((1u << kTlShift) - 1u);
   for (float ph = lane16_half; ph < npxf; ph += 16.0f) {
     const float fly = __builtin_truncf(ph * rbw);
@@ -1121,10 +1217,7 @@ __device__ __forceinline__ void shade_rows(
     const T b0 = (py - u.ay[0]) * u.dx[0] - (px - u.ax[0]) * u.dy[0];
     const T b1 = (py - u.ay[1]) * u.dx[1] - (px - u.ax[1]) * u.dy[1];
     const T b2 = (py - u.ay[2]) * u.dx[2] - (px - u.ax[2]) * u.dy[2];
-    // coverage + top-left rule (:133-145) as ONE predicate: inside or on an edge, and not on an edge that is not top/left
-    const bool inside = (b0 >= T(0)) & (b1 >= T(0)) & (b2 >= T(0));
-    const bool on_excluded_edge = (ntl0 & (b0 == T(0))) | (ntl1 & (b1 == T(0))) | (ntl2 & (b2 == T(0)));
-    if (!inside | on_excluded_edge) continue;
+    if (!((b0 >= thr0) & (b1 >= thr1) & (b2 >= thr2))) continue;
     const int zi = static_cast<int>(__builtin_fmaf(fly, kTileF, c0f) + flx);
     if (DRTK_DBG(dbg, 4)) {
       atomicMin(&zbuf[zi], id);
@@ -1135,8 +1228,7 @@ __device__ __forceinline__ void shade_rows(
     // quotients, an all-ones significand) is ONE wave-uniform test per pass instead of a divergent branch per
     // division -- the fallback itself is exact_div / exact_rcp
     const T q0 = b0 * u.rdenom, q1 = b1 * u.rdenom, q2 = b2 * u.rdenom;
-    const bool fast_ok = div_ok & ((q0 >= DivRange<T>::tiny()) | (b0 == T(0))) & ((q1 >= DivRange<T>::tiny()) | (b1 == T(0))) &
-        ((q2 >= DivRange<T>::tiny()) | (b2 == T(0)));
+    const bool fast_ok = div_ok & (min3(b0, b1, b2) >= b_min);
     T d0 = markstein2(b0, u.abs_denom, u.rdenom, q0);
     T d1 = markstein2(b1, u.abs_denom, u.rdenom, q1);
     T d2 = markstein2(b2, u.abs_denom, u.rdenom, q2);
@@ -1148,7 +1240,7 @@ __device__ __forceinline__ void shade_rows(
     const T depth_inverse = u.dinv0 * d0 + u.dinv1 * d1 + u.dinv2 * d2;
     const T di = epsclamp(depth_inverse);
     T rd = fast_rcp(di);
-    if (__ballot(!fast_rcp_ok(di)) != 0) rd = exact_rcp(di);
+    if (__ballot(!fast_rcp_ok_clamped(di)) != 0) rd = exact_rcp(di);
     const float depth = static_cast<float>(rd);
     const unsigned long long packed = (static_cast<unsigned long long>(__float_as_uint(depth)) << 32) | id;
     atomicMin(&zbuf[zi], packed);
@@ -1158,7 +1250,7 @@ __device__ __forceinline__ void shade_rows(
 // Rasterize the triangles held one per lane (own-lane state `o`): `nsteps` steps, step k = lane k of every row.
 template <typename T, int TILE_SHIFT>
 __device__ __forceinline__ void raster_rows(
-    const TriRow<T>& o, int nsteps, int x0, int y0, unsigned long long* __restrict__ zbuf, int dbg) {
+    const TriOwn<T>& o, int nsteps, int x0, int y0, unsigned long long* __restrict__ zbuf, int dbg) {
   const float x0f = static_cast<float>(x0), y0f = static_cast<float>(y0);
   const float lane16_half = static_cast<float>(lane_id() & 15) + 0.5f;
   for (int k = 0; k < nsteps; ++k) {
@@ -1183,10 +1275,14 @@ __device__ __forceinline__ void raster_rows(
 #endif
 constexpr int kRasterBlock = 512;
 constexpr int kRasterWaves = kRasterBlock / kWave;
+template <typename T>
+constexpr int raster_waves_per_simd() { // double: twice the registers per value -> 2 workgroups per CU, no spilling
+  return sizeof(T) == 4 ? DRTK_RASTER_WAVES_PER_SIMD : 2;
+}
 constexpr int kIdRing = 128; // accepted triangle ids waiting for set-up, per wave (power of two, >= 2 * kWave - 1)
 
 template <typename T, int TILE_SHIFT>
-__global__ __launch_bounds__(kRasterBlock, DRTK_RASTER_WAVES_PER_SIMD) void tile_raster_kernel(
+__global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile_raster_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN,
     int H, int W, int tiles_x, int tiles_per_view, const int32_t* __restrict__ tile_offset,
     const unsigned long long* __restrict__ tile_count, const float* __restrict__ view_stats,
@@ -1200,24 +1296,34 @@ __global__ __launch_bounds__(kRasterBlock, DRTK_RASTER_WAVES_PER_SIMD) void tile
   __shared__ uint32_t s_zmax[(TILE / 8) * (TILE / 8)];
   __shared__ int32_t s_idq[kRasterWaves][kIdRing];
   __shared__ int s_item;
+  __shared__ int s_queue[3];
 
   const int tid = threadIdx.x;
-  const int wave = tid / kWave, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid & (kWave - 1);
   const int n_items = queue[1];
-  int shard = blockIdx.x % kQueueShards, dry = 0; // thread 0's view of the queue
+  // The queue state of the workgroup -- the shard it draws from, how many shards it has seen run dry, the item it has
+  // reserved -- lives in LDS, read and written by thread 0 alone: as loop-carried registers of one lane they were kept
+  // in spill slots across the item loop, and one such spill was placed where EXEC is empty (straight after a divergent
+  // loop's exit, before the mask is restored), so the update was lost and almost half of the tiles were never drawn.
+  auto pop = [&]() { // thread 0 only; leaves the reserved item (or -1) in s_queue[2]
+    int shard = s_queue[0], dry = s_queue[1], idx = -1;
+    while (dry < kQueueShards) {
+      idx = atomicAdd(&queue[kQueueStride * (1 + shard)], 1) * kQueueShards + shard;
+      if (idx < n_items) break;
+      idx = -1;
+      ++dry;
+      shard = (shard + 1) % kQueueShards;
+    }
+    s_queue[0] = shard, s_queue[1] = dry, s_queue[2] = idx;
+  };
+  if (tid == 0) {
+    s_queue[0] = blockIdx.x % kQueueShards, s_queue[1] = 0;
+    pop();
+  }
+  for (int i = tid; i < NPIX; i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488; every item leaves the tile cleared
   DRTK_PHASE_INIT();
   for (;;) {
-    if (tid == 0) {
-      int idx = -1;
-      while (dry < kQueueShards) {
-        idx = atomicAdd(&queue[kQueueStride * (1 + shard)], 1) * kQueueShards + shard;
-        if (idx < n_items) break;
-        idx = -1;
-        ++dry;
-        shard = (shard + 1) % kQueueShards;
-      }
-      s_item = idx;
-    }
+    if (tid == 0) s_item = s_queue[2];
     __syncthreads();
     if (tid == 0) DRTK_PHASE(0); // queue pop
     const int item_index = s_item;
@@ -1232,13 +1338,22 @@ __global__ __launch_bounds__(kRasterBlock, DRTK_RASTER_WAVES_PER_SIMD) void tile
     const int x0 = (tx << TILE_SHIFT) + (sub & ((1 << split_log) - 1)) * ss;
     const int y0 = (ty << TILE_SHIFT) + (sub >> split_log) * ss;
     const int x1 = min(x0 + ss - 1, W - 1), y1 = min(y0 + ss - 1, H - 1);
-    if (x0 < W && y0 < H) {
+    if (!(x0 < W && y0 < H)) { // a sub-rectangle of a border tile that lies off the canvas
+      if (tid == 0) pop();
+      __syncthreads();
+      continue;
+    }
+    {
       const int rows = y1 - y0 + 1;
       const int nbig = big_count[n];
       const int64_t img_base = int64_t(n) * H * W;
       const bool vec_ok = (W & 3) == 0;
       const int quads_per_row = ss >> 2;
+#ifdef DRTK_RASTER_NO_EMPTY_FASTPATH
+      if (false) {
+#else
       if ((item & kItemEmpty) && nbig == 0) {
+#endif
         // nothing can touch this tile: background straight to the images, no LDS tile, no barrier
         for (int q = tid; q < rows * quads_per_row; q += kRasterBlock) {
           const int row = q / quads_per_row;
@@ -1246,22 +1361,23 @@ __global__ __launch_bounds__(kRasterBlock, DRTK_RASTER_WAVES_PER_SIMD) void tile
           const int y = y0 + row, x = x0 + col;
           if (x > x1) continue;
           const int64_t o = img_base + int64_t(y) * W + x;
+          int none = -1;
+          float zero = 0.0f;
+          asm volatile("" : "+v"(none), "+v"(zero)); // constants made here (see `cleared` below)
           if (vec_ok) {
-            *reinterpret_cast<int4*>(index_img + o) = make_int4(-1, -1, -1, -1);
-            *reinterpret_cast<float4*>(depth_img + o) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            *reinterpret_cast<int4*>(index_img + o) = make_int4(none, none, none, none);
+            *reinterpret_cast<float4*>(depth_img + o) = make_float4(zero, zero, zero, zero);
           } else {
             for (int j = 0; j < 4 && x + j <= x1; ++j) {
-              index_img[o + j] = -1;
-              depth_img[o + j] = 0.0f;
+              index_img[o + j] = none;
+              depth_img[o + j] = zero;
             }
           }
         }
+        if (tid == 0) pop();
         __syncthreads(); // s_item is reused by the next pop
         continue;
       }
-      for (int i = tid; i < (ss << TILE_SHIFT); i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
-      __syncthreads();
-      if (tid == 0) DRTK_PHASE(1); // clear
 
       const T* v_n = v + int64_t(n) * V * 3;
       const int32_t* vi_n = vi + int64_t(n) * vi_sN;
@@ -1359,19 +1475,25 @@ __global__ __launch_bounds__(kRasterBlock, DRTK_RASTER_WAVES_PER_SIMD) void tile
             valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
             if (valid && pre_n[f].w == 0u) valid = accept(s.bb_min_x, s.bb_min_y, s.bb_max_x, s.bb_max_y, 0u);
           }
-          const TriRow<T> own = make_row_state<T>(valid, s, f, x0, y0, x1, y1);
+          const TriOwn<T> own = DRTK_MAKE_OWN<T>(valid, s, f, x0, y0, x1, y1);
           if (!DRTK_DBG(dbg, 1)) raster_rows<T, TILE_SHIFT>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
         }
         if (tid == 0) DRTK_PHASE(2 + 4 * phase); // wave 0's share of the group: 2 = first group, 6 = second
         if (phase == 1) break;
         __syncthreads();
         if (tid == 0) DRTK_PHASE(4); // wave 0 waiting for the other waves' first group
-        for (int bi = wave; bi < nb * nb; bi += kRasterWaves) {
-          const int bx = bi % nb, by = bi / nb;
-          uint32_t m = static_cast<uint32_t>(zbuf[(((by << 3) + (lane >> 3)) << TILE_SHIFT) + (bx << 3) + (lane & 7)] >> 32);
+        // farthest depth of every 8x8 block: a wave takes a row of blocks, lane = pixel column, eight rows per lane, then
+        // the maximum over each group of 8 lanes (xor 1, xor 2 within quads, mirror of the 8-lane half row: DPP, no LDS)
+        for (int by = wave; by < nb; by += kRasterWaves) {
+          uint32_t m = 0;
+          if (lane < ss) {
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) m = max(m, static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), o)));
-          if (lane == 0) s_zmax[bi] = m;
+            for (int r = 0; r < 8; ++r) m = max(m, static_cast<uint32_t>(zbuf[(((by << 3) + r) << TILE_SHIFT) + lane] >> 32));
+          }
+          m = max(m, static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0xB1, 0xF, 0xF, true)));  // quad_perm [1,0,3,2]
+          m = max(m, static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0x4E, 0xF, 0xF, true)));  // quad_perm [2,3,0,1]
+          m = max(m, static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0x141, 0xF, 0xF, true))); // row_half_mirror
+          if ((lane & 7) == 0 && lane < ss) s_zmax[by * nb + (lane >> 3)] = m;
         }
         __syncthreads();
         if (tid == 0) DRTK_PHASE(5); // block-farthest reduction
@@ -1379,7 +1501,9 @@ __global__ __launch_bounds__(kRasterBlock, DRTK_RASTER_WAVES_PER_SIMD) void tile
       __syncthreads();
       if (tid == 0) DRTK_PHASE(7); // wave 0 waiting for the other waves' second group
 
-      // unpack + store (rasterize_kernel.cu:402-415)
+      // unpack + store (rasterize_kernel.cu:402-415); the tile is cleared for the next item as it is read, and the next
+      // item is requested now, so that the queue's round trip runs under the stores
+      if (tid == 0) pop();
       for (int q = tid; q < rows * quads_per_row; q += kRasterBlock) {
         const int row = q / quads_per_row;
         const int col = (q - row * quads_per_row) << 2;
@@ -1387,9 +1511,12 @@ __global__ __launch_bounds__(kRasterBlock, DRTK_RASTER_WAVES_PER_SIMD) void tile
         if (x > x1) continue;
         int32_t idx4[4];
         float dep4[4];
+        unsigned long long cleared = ~0ull;
+        asm volatile("" : "+v"(cleared)); // a constant made here, per quad: hoisted out of the item loop it is spilled across it
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const unsigned long long pv = zbuf[(row << TILE_SHIFT) + col + j];
+          zbuf[(row << TILE_SHIFT) + col + j] = cleared;
           const uint32_t hi = static_cast<uint32_t>(pv >> 32);
           dep4[j] = (hi == 0xFFFFFFFFu) ? 0.0f : __uint_as_float(hi);
           idx4[j] = static_cast<int32_t>(static_cast<uint32_t>(pv & 0xFFFFFFFFu));
@@ -1510,7 +1637,7 @@ int rasterize_impl(
 #ifdef DRTK_RASTER_LEGACY
   const int64_t resident = int64_t(num_compute_units()) * 4;
 #else
-  const int64_t resident = int64_t(num_compute_units()) * (DRTK_RASTER_WAVES_PER_SIMD / 2);
+  const int64_t resident = int64_t(num_compute_units()) * (raster_waves_per_simd<T>() / 2);
 #endif
   const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(L.max_items, resident));
   if (L.tile_shift == 6) {

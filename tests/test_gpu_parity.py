@@ -266,6 +266,45 @@ def test_full_size_properties(cfg):
     assert th.isfinite(gv).all()
 
 
+@pytest.mark.parametrize("cfg", [("100k", 8, 2048), ("250k", 8, 2048), ("10k", 4, 512), ("1M", 2, 4096)])
+def test_batch_at_bench_shape_every_pixel_written_and_last_views_match_oracle(cfg):
+    """The BATCHED bench shapes (BASELINE.json configs[1..4], their per-GPU share): the raster pass is a persistent
+    kernel whose workgroups each pull ~10 work items from a queue, and only a batch this large makes every workgroup
+    come back to the queue many times.  (Round 3: a build that lost the queue state between items left 48 % of the
+    8192 tiles unwritten -- and passed every single-view test, because one view is ~1 item per workgroup and fresh
+    allocator memory reads as a plausible image.)  The outputs are pre-filled with a sentinel, so an unwritten pixel
+    cannot pass for a value; then the LAST and a middle view -- the ones behind the 64-bit per-view offsets and the late
+    queue items -- are compared with the oracle bit for bit, rasterize depth included."""
+    import oracle as O
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    mesh, n, res = cfg
+    nl, no = S.MESH_SIZES[mesh]
+    v, vi = S.sphere_views(n, nl, no, res, res, lobes=0.05, device=DEV)
+    for rep, sentinel in enumerate((-7, -9)):
+        depth = th.full((n, res, res), float(sentinel), dtype=th.float32, device=DEV)
+        index = th.full((n, res, res), sentinel, dtype=th.int32, device=DEV)
+        capi.rasterize(v, vi, res, res, out=(depth, index))
+        missed = index == sentinel
+        assert not bool(missed.any()), f"{int(missed.sum())} pixels of index_img were never written (views {missed.flatten(1).any(1).nonzero().flatten().tolist()})"
+        assert not bool((depth == float(sentinel)).any()), "pixels of depth_img were never written"
+        if rep == 0:
+            first = (depth.clone(), index.clone())
+    assert th.equal(first[0], depth) and th.equal(first[1], index)
+    assert int(index.max()) < vi.shape[0] and int(index.min()) == -1
+    assert th.equal(depth == 0, index == -1)
+    for k in sorted({n - 1, n // 2}):
+        d_o, i_o = O.rasterize(v[k:k + 1].cpu(), vi.cpu(), res, res, nthreads=0)
+        assert th.equal(index[k:k + 1].cpu(), i_o), f"view {k}: {int((index[k:k + 1].cpu() != i_o).sum())} index pixels differ"
+        assert th.equal(depth[k:k + 1].cpu(), d_o), f"view {k}: depth differs"
+    # the ops downstream of it, on the same batch: every element of every output written (NaN-filled outputs)
+    rd, rb = capi.render(v, vi, index)
+    assert bool(th.isfinite(rd).all()) and bool(th.isfinite(rb).all())
+    cov = index >= 0
+    assert bool((rb.sum(1)[~cov] == 0).all()) and float((rb.sum(1)[cov] - 1).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("cfg", [("100k", 2048, 16), ("250k", 2048, 16), ("1M", 4096, 4)])
 def test_full_size_view_matches_oracle(cfg):
     """One view of BASELINE.json configs[2], [3] and [4] at FULL resolution against the CPU oracle (all host
