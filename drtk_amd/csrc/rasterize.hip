@@ -1069,6 +1069,7 @@ struct TriRow {
   int id_tl; // triangle id | top-left bits of the three edges << 29 (ids are < 2^29: N F < 2^31 / 4)
   int box;   // clipped bbox relative to the item's rectangle, 6 bits each: x, y of the first pixel, width - 1, height - 1;
              // bit 24: there is something to draw
+  uint32_t z_lo; // f32 bits of the rigorous lower bound of the triangle's depths (bin_count's record; 0: none)
 };
 constexpr int kTlShift = 29;
 constexpr int kBoxDraw = 1 << 24;
@@ -1090,13 +1091,15 @@ __device__ __forceinline__ TriRow<T> row_bcast_tri(const TriRow<T>& o) {
   u.dinv2 = row_bcast<K>(o.dinv2);
   u.id_tl = row_bcast<K>(o.id_tl);
   u.box = row_bcast<K>(o.box);
+  u.z_lo = static_cast<uint32_t>(row_bcast<K>(static_cast<int>(o.z_lo)));
   return u;
 }
 
 // Own-lane state from the exact set-up: oriented edges, bbox clipped to the item's rectangle [x0, x1] x [y0, y1].
 template <typename T>
-__device__ __forceinline__ TriRow<T> make_row_state(bool valid, const TriSetup<T>& s, int f, int x0, int y0, int x1, int y1) {
+__device__ __forceinline__ TriRow<T> make_row_state(bool valid, const TriSetup<T>& s, int f, uint32_t z_lo, int x0, int y0, int x1, int y1) {
   TriRow<T> o;
+  o.z_lo = z_lo;
   const T px[3] = {s.p1x, s.p2x, s.p0x}, py[3] = {s.p1y, s.p2y, s.p0y}; // edge k starts at p_{k+1}
   const T qx[3] = {s.p2x, s.p0x, s.p1x}, qy[3] = {s.p2y, s.p0y, s.p1y}; // ... and ends at p_{k+2}
   const bool c[3] = {s.c0, s.c1, s.c2};
@@ -1123,69 +1126,12 @@ __device__ __forceinline__ TriRow<T> make_row_state(bool valid, const TriSetup<T
   return o;
 }
 
-#ifdef DRTK_RASTER_RAW_STATE
-// Variant: the lane keeps the RAW set-up (six coordinates + orientation flags in `box`) and the row derives the
-// oriented edges after the broadcast: 13 instead of 19 registers of own-lane state, ~30 more VALU per step.
-constexpr int kBoxC0 = 1 << 25, kBoxC1 = 1 << 26, kBoxC2 = 1 << 27, kBoxNeg = 1 << 28;
-template <typename T>
-struct TriRaw {
-  T p0x, p0y, p1x, p1y, p2x, p2y;
-  T abs_denom, rdenom, dinv0, dinv1, dinv2;
-  int id_tl, box;
-};
-template <typename T>
-__device__ __forceinline__ TriRaw<T> make_raw_state(bool valid, const TriSetup<T>& s, int f, int x0, int y0, int x1, int y1) {
-  TriRaw<T> o;
-  o.p0x = s.p0x, o.p0y = s.p0y, o.p1x = s.p1x, o.p1y = s.p1y, o.p2x = s.p2x, o.p2y = s.p2y;
-  o.abs_denom = s.abs_denom, o.rdenom = s.rdenom, o.dinv0 = s.dinv0, o.dinv1 = s.dinv1, o.dinv2 = s.dinv2;
-  const int bx0 = max(s.bb_min_x, x0), bx1 = min(s.bb_max_x, x1);
-  const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
-  const bool draw = valid && bx0 <= bx1 && by0 <= by1;
-  o.box = draw ? ((bx0 - x0) | ((by0 - y0) << 6) | ((bx1 - bx0) << 12) | ((by1 - by0) << 18) | kBoxDraw |
-                  (s.c0 ? kBoxC0 : 0) | (s.c1 ? kBoxC1 : 0) | (s.c2 ? kBoxC2 : 0) | (s.sign_denom < T(0) ? kBoxNeg : 0)) : 0;
-  o.id_tl = f | ((s.tl0 ? 1 : 0) | (s.tl1 ? 2 : 0) | (s.tl2 ? 4 : 0)) << kTlShift;
-  return o;
-}
-template <int K, typename T>
-__device__ __forceinline__ TriRow<T> row_bcast_tri(const TriRaw<T>& o) {
-  const T p0x = row_bcast<K>(o.p0x), p0y = row_bcast<K>(o.p0y), p1x = row_bcast<K>(o.p1x), p1y = row_bcast<K>(o.p1y);
-  const T p2x = row_bcast<K>(o.p2x), p2y = row_bcast<K>(o.p2y);
-  TriRow<T> u;
-  u.abs_denom = row_bcast<K>(o.abs_denom);
-  u.rdenom = row_bcast<K>(o.rdenom);
-  u.dinv0 = row_bcast<K>(o.dinv0);
-  u.dinv1 = row_bcast<K>(o.dinv1);
-  u.dinv2 = row_bcast<K>(o.dinv2);
-  u.id_tl = row_bcast<K>(o.id_tl);
-  u.box = row_bcast<K>(o.box);
-  const T px[3] = {p1x, p2x, p0x}, py[3] = {p1y, p2y, p0y};
-  const T qx[3] = {p2x, p0x, p1x}, qy[3] = {p2y, p0y, p1y};
-  const bool c[3] = {(u.box & kBoxC0) != 0, (u.box & kBoxC1) != 0, (u.box & kBoxC2) != 0};
-  const bool sneg = (u.box & kBoxNeg) != 0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    u.ax[k] = c[k] ? px[k] : qx[k];
-    u.ay[k] = c[k] ? py[k] : qy[k];
-    const T bx = c[k] ? qx[k] : px[k], by = c[k] ? qy[k] : py[k];
-    const bool neg = c[k] ? sneg : !sneg;
-    const T ex = bx - u.ax[k], ey = by - u.ay[k];
-    u.dx[k] = neg ? -ex : ex;
-    u.dy[k] = neg ? -ey : ey;
-  }
-  return u;
-}
-template <typename T>
-using TriOwn = TriRaw<T>;
-#define DRTK_MAKE_OWN make_raw_state
-#else
 template <typename T>
 using TriOwn = TriRow<T>;
-#define DRTK_MAKE_OWN make_row_state
-#endif
 
 // One step: every row shades the triangle `u` it was handed.  Coverage, depth and the packed atomicMin are the
 // reference's (rasterize_kernel.cu:117-161), evaluated per lane = per pixel.
-template <typename T, int TILE_SHIFT>
+template <typename T, int TILE_SHIFT, bool EARLY_Z>
 __device__ __forceinline__ void shade_rows(
     const TriRow<T>& u, float lane16_half, float x0f, float y0f, unsigned long long* __restrict__ zbuf, int dbg) {
   constexpr float kTileF = static_cast<float>(1 << TILE_SHIFT);
@@ -1219,6 +1165,13 @@ __device__ __forceinline__ void shade_rows(
     const T b2 = (py - u.ay[2]) * u.dx[2] - (px - u.ax[2]) * u.dy[2];
     if (!((b0 >= thr0) & (b1 >= thr1) & (b2 >= thr2))) continue;
     const int zi = static_cast<int>(__builtin_fmaf(fly, kTileF, c0f) + flx);
+    if (EARLY_Z) {
+      // second group only: a fragment whose triangle cannot be nearer than what the pixel already holds -- the
+      // rigorous bound against the stored depth, strictly, as in the block test -- skips the depth arithmetic (two
+      // thirds of the loop body); most of that group's fragments are hidden back faces that got through the 8x8-block
+      // test because their blocks contain background
+      if (u.z_lo > static_cast<uint32_t>(zbuf[zi] >> 32)) continue;
+    }
     if (DRTK_DBG(dbg, 4)) {
       atomicMin(&zbuf[zi], id);
       continue;
@@ -1248,7 +1201,7 @@ __device__ __forceinline__ void shade_rows(
 }
 
 // Rasterize the triangles held one per lane (own-lane state `o`): `nsteps` steps, step k = lane k of every row.
-template <typename T, int TILE_SHIFT>
+template <typename T, int TILE_SHIFT, bool EARLY_Z>
 __device__ __forceinline__ void raster_rows(
     const TriOwn<T>& o, int nsteps, int x0, int y0, unsigned long long* __restrict__ zbuf, int dbg) {
   const float x0f = static_cast<float>(x0), y0f = static_cast<float>(y0);
@@ -1263,7 +1216,7 @@ __device__ __forceinline__ void raster_rows(
       default: u = row_bcast_tri<15>(o); break;
 #undef DRTK_ROW_STEP
     }
-    shade_rows<T, TILE_SHIFT>(u, lane16_half, x0f, y0f, zbuf, dbg);
+    shade_rows<T, TILE_SHIFT, EARLY_Z>(u, lane16_half, x0f, y0f, zbuf, dbg);
   }
 }
 
@@ -1471,12 +1424,25 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
           head += cnt;
           wave_lds_sync(); // the ring slots just read may be overwritten by the next screening round
           TriSetup<T> s = {};
+          uint32_t z_lo = 0;
           if (valid) {
+            const uint4 pre = pre_n[f];
+            z_lo = pre.z;
             valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
-            if (valid && pre_n[f].w == 0u) valid = accept(s.bb_min_x, s.bb_min_y, s.bb_max_x, s.bb_max_y, 0u);
+            if (valid && pre.w == 0u) valid = accept(s.bb_min_x, s.bb_min_y, s.bb_max_x, s.bb_max_y, 0u);
           }
-          const TriOwn<T> own = DRTK_MAKE_OWN<T>(valid, s, f, x0, y0, x1, y1);
-          if (!DRTK_DBG(dbg, 1)) raster_rows<T, TILE_SHIFT>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
+          const TriOwn<T> own = make_row_state<T>(valid, s, f, z_lo, x0, y0, x1, y1);
+          if (!DRTK_DBG(dbg, 1)) {
+#ifdef DRTK_RASTER_NO_EARLY_Z
+            raster_rows<T, TILE_SHIFT, false>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
+#else
+            if (phase == 0) {
+              raster_rows<T, TILE_SHIFT, false>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
+            } else {
+              raster_rows<T, TILE_SHIFT, true>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
+            }
+#endif
+          }
         }
         if (tid == 0) DRTK_PHASE(2 + 4 * phase); // wave 0's share of the group: 2 = first group, 6 = second
         if (phase == 1) break;
