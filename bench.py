@@ -404,9 +404,6 @@ def main():
                 r.finish()
         return loss
 
-    import warnings
-
-    warnings.filterwarnings("ignore", message=".*screen_space_uv_derivative is not differentiable.*")
     if args.graph_child:
         return graph_child(step, leaves, args.steps, n_total * H * W)
     for _ in range(args.warmup):

@@ -86,27 +86,40 @@ struct TimingRec {
 };
 std::mutex g_timing_mu;
 std::vector<TimingRec> g_timing;
-thread_local int t_timing_open = -1; // index of this thread's record between its two marks
-void timing_clear_locked() {
-  for (auto& r : g_timing) {
+unsigned g_timing_generation = 0; // bumped by every begin / report: a mark that belongs to an older collection is ignored
+struct OpenMark {
+  unsigned generation;
+  int index;
+};
+thread_local OpenMark t_timing_open = {0, -1}; // this thread's record between its two marks
+void destroy_records(std::vector<TimingRec>& recs) {
+  for (auto& r : recs) {
     if (r.e0) (void)hipEventDestroy(r.e0);
     if (r.e1) (void)hipEventDestroy(r.e1);
   }
-  g_timing.clear();
+  recs.clear();
 }
 } // namespace
 
 void kernel_timing_mark(const char* name, hipStream_t stream, bool begin) {
   std::lock_guard<std::mutex> lock(g_timing_mu);
   if (begin) {
+    t_timing_open.index = -1;
+    if (g_kernel_timing_on.load(std::memory_order_relaxed) == 0) return; // the collection was closed after the launch site sampled the flag
     TimingRec r{name, nullptr, nullptr};
-    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    if (hipEventCreate(&r.e0) != hipSuccess) return;
+    if (hipEventCreate(&r.e1) != hipSuccess) {
+      (void)hipEventDestroy(r.e0);
+      return;
+    }
     (void)hipEventRecord(r.e0, stream);
     g_timing.push_back(r);
-    t_timing_open = static_cast<int>(g_timing.size()) - 1;
-  } else if (t_timing_open >= 0 && t_timing_open < static_cast<int>(g_timing.size())) {
-    (void)hipEventRecord(g_timing[t_timing_open].e1, stream);
-    t_timing_open = -1;
+    t_timing_open = {g_timing_generation, static_cast<int>(g_timing.size()) - 1};
+  } else if (t_timing_open.index >= 0) {
+    // only into the record this thread opened, and only while that collection is still the current one
+    if (t_timing_open.generation == g_timing_generation && t_timing_open.index < static_cast<int>(g_timing.size()))
+      (void)hipEventRecord(g_timing[t_timing_open.index].e1, stream);
+    t_timing_open.index = -1;
   }
 }
 
@@ -119,24 +132,38 @@ int debug_flags() {
 } // namespace drtk_amd
 
 extern "C" int drtk_amd_kernel_timing_begin(void) {
-  std::lock_guard<std::mutex> lock(drtk_amd::g_timing_mu);
-  drtk_amd::timing_clear_locked();
-  drtk_amd::g_kernel_timing_on.store(1);
+  std::vector<drtk_amd::TimingRec> stale;
+  {
+    std::lock_guard<std::mutex> lock(drtk_amd::g_timing_mu);
+    stale.swap(drtk_amd::g_timing);
+    ++drtk_amd::g_timing_generation;
+    drtk_amd::g_kernel_timing_on.store(1);
+  }
+  drtk_amd::destroy_records(stale);
   return DRTK_OK;
 }
 
 extern "C" int drtk_amd_kernel_timing_report(char* buf, size_t capacity, size_t* needed) {
   using namespace drtk_amd;
-  g_kernel_timing_on.store(0);
-  std::lock_guard<std::mutex> lock(g_timing_mu);
+  // close the collection and take its records out under the lock; the events are synchronised OUTSIDE it, so launches
+  // of other threads (timed or not) never wait behind this call's hipEventSynchronize
+  std::vector<TimingRec> recs;
+  {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    g_kernel_timing_on.store(0);
+    ++g_timing_generation;
+    recs.swap(g_timing);
+  }
   // aggregate by launch site, in order of first appearance
   std::vector<const char*> names;
   std::vector<double> total;
   std::vector<long> count;
   int status = DRTK_OK;
-  for (auto& r : g_timing) {
+  for (auto& r : recs) {
     float ms = 0.f;
-    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+    // (a record whose second mark was dropped -- its launch straddled the end of the collection -- has no end time)
+    if (hipEventQuery(r.e1) == hipErrorInvalidResourceHandle || hipEventSynchronize(r.e1) != hipSuccess ||
+        hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
       status = DRTK_ERR_LAUNCH;
       (void)hipGetLastError();
       continue;
@@ -157,7 +184,7 @@ extern "C" int drtk_amd_kernel_timing_report(char* buf, size_t capacity, size_t*
     std::snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", names[k], count[k], total[k]);
     out += line;
   }
-  timing_clear_locked();
+  destroy_records(recs);
   if (needed) *needed = out.size() + 1;
   if (buf && capacity > 0) {
     const size_t n = out.size() < capacity - 1 ? out.size() : capacity - 1;

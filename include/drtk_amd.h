@@ -219,6 +219,11 @@ int drtk_amd_interpolation_normal_matrix_values_backward(
  *   reference (:423 vs :641-897).
  * Backward: grad_levels[l] (contiguous [N,C,h,w] whatever level_sN is, zero-filled here) and grad_grid [N,H,W,2]
  * (fully written); no gradient is defined for vt_dxdy_img.
+ * FINITE TEXELS ASSUMED where a weight is exactly zero: the forward pass skips a mip level whose blend weight is
+ * exactly 0, the backward pass skips (pixel, level) pairs whose weighted upstream gradient is 0 in every channel and
+ * whole tiles without upstream gradient.  The reference evaluates 0 * texel there, so an Inf / NaN texel in a level
+ * that does not contribute (or under a zero upstream gradient) turns its output / gradient into NaN; here the
+ * result stays finite.  For finite textures the two agree exactly (tests/test_gpu_mipmap.py pins the difference).
  */
 int drtk_amd_mipmap_grid_sampler_2d(
     drtk_dtype_t dtype, const void* const* levels, const int64_t* level_h, const int64_t* level_w,
@@ -245,8 +250,10 @@ int drtk_amd_mipmap_grid_sampler_2d_backward(
  * per pixel: pixels of such a face get the non-finite quotients of that zero determinant, every other pixel is
  * unaffected.  In float32 the two 2x2 inverses are ill-conditioned for triangles seen edge-on; accuracy there is
  * that of the reference's float32 composite, not 1e-5.
- * Forward only (the reference composite is differentiable through autograd; its consumer,
- * mipmap_grid_sampler_2d, defines no gradient for this input).
+ * Forward only.  (The reference composite looks differentiable but is not: it masks the output of linalg.inv_ex in
+ * place, drtk/screen_space_uv_derivative.py:79, and backward() through it raises -- recorded from the reference in
+ * tests/golden/refpy_uv_derivative_autograd.npz; its consumer, mipmap_grid_sampler_2d, defines no gradient for this
+ * input.  The Python wrapper reproduces exactly that: part of the graph, an error only if a gradient arrives.)
  */
 int drtk_amd_screen_space_uv_derivative(
     drtk_dtype_t dtype, const void* v, int64_t v_sN, const void* vt, int64_t vt_sN, const int32_t* vi,

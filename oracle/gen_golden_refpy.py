@@ -23,6 +23,8 @@ Fixtures:
                               edge_grad_estimator + autograd: no hook; with a v_pix_img_hook that rescales the
                               gradient (and what the hook saw); partial requires_grad patterns.
   refpy_sparse_<scene>        drtk.interpolation_matrix / interpolation_normal_matrix incl. the module's own A^T A pattern builder
+  refpy_uv_derivative_autograd  what drtk.screen_space_uv_derivative does under autograd in the reference: backward() raises
+                              (in-place mask on the output of linalg.inv_ex); the message is stored.
   refpy_two_triangles         test/two_triangles.py (the reference's only script-level test) at 64x64: iteration-0
                               tensors and the loss at iterations 0, 1, 50, 100, 200 of its Adam loop.
 """
@@ -279,6 +281,40 @@ def gen_sparse(drtk):
         save(f"refpy_sparse_{tag}", arrs)
 
 
+# ------------------------------------------------------------------------- screen_space_uv_derivative and autograd
+def gen_uv_derivative_autograd(drtk):
+    """What happens in the REFERENCE when a loss is differentiated through screen_space_uv_derivative
+    (drtk/screen_space_uv_derivative.py:15-80)?  It is written as a PyTorch composite, but its last statement,
+    `vt_dxdy_img[~mask, :, :] = 0` (:79), modifies the output of `th.linalg.inv_ex` in place, and that operator's backward
+    needs its own output: `backward()` RAISES ("... modified by an inplace operation").  So upstream the function is in
+    effect forward only -- the one consumer on the path, mipmap_grid_sample, defines no gradient for vt_dxdy_img
+    (mipmap_grid_sampler_module.cpp), so nobody notices.  Recorded here (the message, and that a mask that is True
+    everywhere does not help) so that the replacement's behaviour -- forward only, an error if a gradient really
+    arrives -- is pinned against the reference's, not against what its source looks like."""
+    sys.path.insert(0, REF)
+    from drtk.screen_space_uv_derivative import screen_space_uv_derivative  # noqa: E402
+
+    sys.path.remove(REF)
+    z = load_fixture("uv_derivative_f64")
+    msgs = []
+    for all_true in (False, True):
+        names = ("v", "vt", "bary_img", "campos", "camrot", "focal")
+        leaf = {k: z["in_" + k].clone().requires_grad_(True) for k in names}
+        index = z["in_index_img"]
+        mask = th.ones_like(index, dtype=th.bool) if all_true else index != -1
+        out = screen_space_uv_derivative(leaf["v"], leaf["vt"], z["in_vi"], z["in_vti"], index, leaf["bary_img"], mask,
+                                         leaf["campos"], leaf["camrot"], leaf["focal"])
+        assert out.requires_grad
+        try:
+            out.sum().backward()
+            raise SystemExit("the reference's screen_space_uv_derivative differentiated without error: re-read this generator")
+        except RuntimeError as e:
+            msgs.append(str(e).split(". Hint")[0])
+    assert all("inplace operation" in m and "LinalgInvExBackward" in m for m in msgs), msgs
+    save("refpy_uv_derivative_autograd", {"backward_raises": np.array(True), "message": np.array(msgs[0]),
+                                          "message_all_true_mask": np.array(msgs[1])})
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs /root/reference (build container only)")
@@ -288,6 +324,7 @@ def main():
     gen_step(drtk)
     gen_two_triangles(drtk)
     gen_sparse(drtk)
+    gen_uv_derivative_autograd(drtk)
 
 
 if __name__ == "__main__":

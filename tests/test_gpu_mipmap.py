@@ -114,6 +114,31 @@ def test_masked_upstream_gradients_magnified_pixels_and_tap_counts_beyond_the_ta
             close(a, b, f"grad level {i}")
 
 
+def test_non_finite_texels_under_a_zero_weight_stay_out_of_the_result():
+    """include/drtk_amd.h, "FINITE TEXELS ASSUMED": a magnified pixel (footprint below one texel) blends level 0 with
+    weight 1 and level 1 with weight EXACTLY 0.  The reference evaluates 0 * texel, the oracle restatement with it, so a
+    NaN in level 1 poisons that pixel there; the HIP kernels skip a level of weight 0 (forward) and every (pixel, level)
+    whose weighted upstream gradient is 0 (backward), so the pixel keeps the value it has with a finite level 1 and the
+    poisoned level receives a zero gradient.  Pinned so that the difference is a documented decision, not an accident."""
+    import oracle as O
+    from drtk_amd import capi
+
+    H, W = 24, 32
+    tex, grid, vt, gout = mipmap_inputs(912, 1, 3, 32, 3, H, W, jscale=0.03)
+    vt = vt * 0.02  # every pixel magnified: level 0 only
+    grid = grid.clamp(-0.9, 0.9)
+    clean = capi.mipmap_grid_sampler_2d(dev(tex), dev(grid), dev(vt), 4, 1, 0)
+    close(clean, O.mipmap_grid_sampler_2d(tex, grid, vt, 4, 1, 0, False, False, False), "finite texture: same as the oracle")
+    bad = [tex[0], th.full_like(tex[1], float("nan")), tex[2]]
+    assert bool(th.isnan(O.mipmap_grid_sampler_2d(bad, grid, vt, 4, 1, 0, False, False, False)).any()), "the restated reference propagates 0 * NaN"
+    got = capi.mipmap_grid_sampler_2d(dev(bad), dev(grid), dev(vt), 4, 1, 0)
+    assert th.equal(got, clean), "a level of weight 0 is not read"
+    gl, gg = capi.mipmap_grid_sampler_2d_backward(dev(gout), dev(bad), dev(grid), dev(vt), 4, 1, 0)
+    gl_clean, gg_clean = capi.mipmap_grid_sampler_2d_backward(dev(gout), dev(tex), dev(grid), dev(vt), 4, 1, 0)
+    assert bool(th.isfinite(gg).all()) and th.equal(gg, gg_clean)
+    assert float(gl[1].abs().max()) == 0.0 and th.equal(gl[0], gl_clean[0])
+
+
 def test_one_texture_shared_by_all_views_is_sampled_in_place():
     """A [1,C,h,w] pyramid expanded to N views (batch stride 0) -- one texture, many cameras -- gives the results of its
     materialised copy, through the C ABI (`level_sN` = 0) and through the torch op, forward and backward; the level
@@ -268,6 +293,41 @@ def test_uv_derivative_matches_reference_composite_fixture(tag):
     with pytest.raises(NotImplementedError):
         drtk_amd.screen_space_uv_derivative(d["v"], d["vt"], d["vi"], d["vti"], d["index_img"], d["bary_img"], mask, d["campos"],
                                             d["camrot"], d["focal"], dist_mode=["fisheye"], dist_coeff=d["focal"])
+
+
+def test_uv_derivative_under_autograd_behaves_like_the_reference():
+    """The reference's composite cannot be differentiated: backward() through it raises (in-place mask on the output of
+    linalg.inv_ex -- recorded from the reference by oracle/gen_golden_refpy.py).  Same here: the result is part of the
+    graph, a loss that only hands it to mipmap_grid_sample (no gradient defined for vt_dxdy_img) is unaffected, a
+    gradient that really reaches it raises."""
+    import numpy as np
+    import drtk_amd
+    from conftest import GOLDEN as GOLDEN_DIR, load_golden
+
+    z = np.load(GOLDEN_DIR + "/refpy_uv_derivative_autograd.npz")
+    assert bool(z["backward_raises"]) and "inplace operation" in str(z["message"]) and "inplace operation" in str(z["message_all_true_mask"])
+    i, o = load_golden("uv_derivative_f32")
+    d = {k: (x.to(DEV) if isinstance(x, th.Tensor) else x) for k, x in i.items()}
+    mask = d["index_img"] != -1
+    v = d["v"].clone().requires_grad_(True)
+    vt = d["vt"].clone().requires_grad_(True)
+    jac = drtk_amd.screen_space_uv_derivative(v, vt, d["vi"], d["vti"], d["index_img"], d["bary_img"], mask, d["campos"], d["camrot"], d["focal"])
+    assert jac.requires_grad
+    close(jac, o["vt_dxdy_img"], "forward under autograd", atol=2e-6, rtol=2e-5)
+    with pytest.raises(RuntimeError, match="not differentiable"):
+        jac.sum().backward()
+    # through its consumer: gradients flow to the texture and to the uv image, none is asked of the Jacobians
+    N, H, W = d["index_img"].shape
+    tex = [th.rand(N, 3, 16 >> l, 16 >> l, device=DEV, requires_grad=True) for l in range(3)]
+    uv_img = drtk_amd.interpolate(vt[:, d["vti"].long().reshape(-1)].contiguous(), th.arange(d["vti"].numel(), dtype=th.int32, device=DEV).view(-1, 3),
+                                  d["index_img"], d["bary_img"])
+    jac = drtk_amd.screen_space_uv_derivative(v, vt, d["vi"], d["vti"], d["index_img"], d["bary_img"], mask, d["campos"], d["camrot"], d["focal"])
+    out = drtk_amd.mipmap_grid_sample(tex, (uv_img * 2 - 1).permute(0, 2, 3, 1), jac, 4, padding_mode="border")
+    out.square().sum().backward()
+    assert all(t.grad is not None and bool(th.isfinite(t.grad).all()) for t in tex) and vt.grad is not None and v.grad is None
+    # no gradient required anywhere: a plain tensor
+    with th.no_grad():
+        assert not drtk_amd.screen_space_uv_derivative(v, vt, d["vi"], d["vti"], d["index_img"], d["bary_img"], mask, d["campos"], d["camrot"], d["focal"]).requires_grad
 
 
 def test_uv_derivative_equals_finite_differences_of_the_uv_image():

@@ -220,7 +220,7 @@ def test_empty_inputs():
     assert (d == 0).all() and (b == 0).all()
 
 
-@pytest.mark.parametrize("cfg", [("10k", 4, 512, 3), ("100k", 2, 2048, 16)])
+@pytest.mark.parametrize("cfg", [("10k", 4, 512, 3), ("100k", 2, 2048, 16), ("100k", 8, 2048, 16)])
 def test_full_size_properties(cfg):
     """BASELINE.json configs at full resolution: size-independent properties instead of the
     (too slow) oracle: determinism, bary sums to one, interpolation of constant attributes is
@@ -386,6 +386,39 @@ def test_full_size_index_img_against_the_reference_built_with_its_own_fast_math_
     assert float(rel_at(differ, d_g, d_f)) <= 4 * 2.0 ** -23, (n_diff, float(rel_at(differ, d_g, d_f)))
     assert n_diff <= max(8, covered // 100000), f"{n_diff} of {covered} covered pixels change owner under --fast-math"
     print(f"[{mesh}@{res}] index_img vs the reference's --fast-math build: {n_diff} of {covered} covered px differ (all depth near-ties)")
+
+
+@pytest.mark.parametrize("mesh", ["100k", "250k"])
+def test_full_size_index_img_and_the_committed_fast_math_owner_changes(mesh):
+    """The same policy pinned by DATA (tests/golden/fastmath_owner_changes_*.npz, oracle/gen_golden_fastmath.py): the
+    fixture lists the pixels of one full benchmark view whose owner differs between the reference built strict-IEEE and
+    built with its own `-O3 --fast-math`, with both owners and depths, and carries a SHA-256 of either full index image.
+    The HIP image must BE the strict image (hash, depth hash included) and must become the fast-math image when exactly
+    the listed pixels are given the fast build's owners (hash) -- no reference library needed on the box."""
+    import hashlib
+
+    import numpy as np
+    from conftest import GOLDEN
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    z = np.load(f"{GOLDEN}/fastmath_owner_changes_{mesh}.npz")
+    res = int(z["res"])
+    nl, no = S.MESH_SIZES[mesh]
+    v, vi = S.sphere_views(1, nl, no, res, res, lobes=0.05)
+    d_g, i_g = capi.rasterize(dev(v), dev(vi), res, res)
+    d_g, i_g = d_g.cpu(), i_g.cpu()
+    sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()  # noqa: E731
+    assert sha(i_g) == str(z["sha256_index_strict"]) and sha(d_g) == str(z["sha256_depth_strict"])
+    px = th.from_numpy(z["pixels"])
+    assert 0 < px.numel() <= 8 and int(z["covered"]) == int((i_g >= 0).sum())
+    assert th.equal(i_g.flatten()[px], th.from_numpy(z["index_strict"])) and th.equal(d_g.flatten()[px], th.from_numpy(z["depth_strict"]))
+    as_fast = i_g.clone().flatten()
+    as_fast[px] = th.from_numpy(z["index_fast"])
+    assert sha(as_fast.view_as(i_g)) == str(z["sha256_index_fast"])
+    # every listed pixel is a near-tie: the two builds' depths there agree to a few float32 ulp
+    rel = (th.from_numpy(z["depth_strict"]).double() - th.from_numpy(z["depth_fast"]).double()).abs() / th.from_numpy(z["depth_fast"]).double()
+    assert float(rel.max()) <= 4 * 2.0 ** -23 and float(z["max_rel_depth_difference"]) <= 4e-7
 
 
 def rel_at(mask, a, b):

@@ -167,3 +167,25 @@ def test_wireframe_restatement_gives_the_hand_derived_known_answers():
         K.check(lambda v, vi, H, W: O.rasterize_lines(v, vi, H, W), dt)
     K.check_against_exact_model(lambda v, vi, H, W: O.rasterize_lines(v, vi, H, W), range(16))
     K.check_against_exact_model(lambda v, vi, H, W: O.rasterize_lines(v, vi, H, W), range(16, 20), th.float64)
+
+
+def test_oracle_reproduces_the_strict_image_of_the_fast_math_fixture():
+    """tests/golden/fastmath_owner_changes_100k.npz (oracle/gen_golden_fastmath.py) carries SHA-256s of the reference's
+    strict-IEEE index / depth image of one full benchmark view: the oracle restatement must produce exactly that image
+    (the GPU suite holds the HIP rasterizer to the same hashes)."""
+    import hashlib
+
+    import numpy as np
+    import oracle as O
+    from conftest import GOLDEN
+    from drtk_amd import synthetic as S
+
+    z = np.load(f"{GOLDEN}/fastmath_owner_changes_100k.npz")
+    res = int(z["res"])
+    nl, no = S.MESH_SIZES["100k"]
+    v, vi = S.sphere_views(1, nl, no, res, res, lobes=0.05)
+    d, i = O.rasterize(v, vi, res, res, nthreads=0)
+    sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()  # noqa: E731
+    assert sha(i) == str(z["sha256_index_strict"]) and sha(d) == str(z["sha256_depth_strict"])
+    px = th.from_numpy(z["pixels"])
+    assert th.equal(i.flatten()[px], th.from_numpy(z["index_strict"])) and not th.equal(i.flatten()[px], th.from_numpy(z["index_fast"]))
