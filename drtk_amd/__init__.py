@@ -3,6 +3,7 @@
 facebookresearch/DRTK on PyTorch-ROCm.  Kernels: hand-written HIP for gfx950 in
 `drtk_amd/csrc`, C ABI in `include/drtk_amd.h`."""
 from drtk_amd.edge_grad_estimator import edge_grad_estimator  # noqa: F401
+from drtk_amd.graph import capture_step  # noqa: F401
 from drtk_amd.interpolate import (  # noqa: F401
     interpolate,
     interpolate_masked,
@@ -18,7 +19,8 @@ from drtk_amd.transform import transform, transform_with_v_cam  # noqa: F401
 __version__ = "0.1.0"
 
 # The public surface.  Same names, arguments and defaults as `drtk.*` for everything on the hot path and its "next"
-# rows; `interpolate_masked` is this package's one addition (interpolate with the background written as 0).  Not
+# rows; `interpolate_masked` (interpolate with the background written as 0) and `capture_step` (a whole step as a
+# HIP graph) are this package's additions.  Not
 # provided: grid_scatter, msi, filter2d and the pure-PyTorch `*_ref` models (out of scope).
 __all__ = [
     "rasterize",
@@ -33,4 +35,5 @@ __all__ = [
     "screen_space_uv_derivative",
     "transform",
     "transform_with_v_cam",
+    "capture_step",
 ]

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
 //   * the per-pixel bary-gradient dot products run after phase 2 and read grad_out back from the
 //     LDS staging rows, which frees the registers for the prefetch.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
+__global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
@@ -582,7 +582,12 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_wide_kernel(
       //    VGPR of keys and costs no registers (128 VGPRs, 4 waves kept) -- merges the rows of the wave's 64 x 4 pixels
       //    and was also slower: 0.666 vs 0.654 ms with 16 float entries updated by read-add-write (the LDS round trip
       //    sits on every run's critical path), 0.692 with 8, 0.74 with 16 double entries and fire-and-forget ds_add_f64
-      //    (51 KB of LDS per workgroup: 3 waves per SIMD))
+      //    (51 KB of LDS per workgroup: 3 waves per SIMD).  Round 3: CARRYING the sums of the vertices two consecutive
+      //    runs share (neighbouring triangles share an edge) from run to run instead of flushing them -- which corner
+      //    continues as which decided by the scalar unit, the sums moved between the corner rows by one ds_bpermute, a
+      //    third of the atomic requests -- is correct and much slower: 0.901 vs 0.648 ms (1.096 vs 0.731 at 250k
+      //    triangles); the per-run scalar chain (vertex ids to SGPRs, nine compares, the permute's round trip) sits on
+      //    the one wave's critical path, the atomics it saves were fire-and-forget)
       if (cov != 0 && !DRTK_DBG(dbg, 1)) {
         const T* sg = s_g[wave];
         const T* sb = s_b[wave];

@@ -4,7 +4,7 @@ built with ITS OWN flags (`-O3 --fast-math`, setup.py:23-24 -> oracle/_ref/libdr
 built strict-IEEE (libdrtk_ref_strict.so -- the build the oracle and every fixture follow) disagree about the owner of
 a pixel, on one full-resolution benchmark view (drtk_amd.synthetic.sphere_views(1, ...), 2048^2).
 
-Stored: the pixels (flat indices) where index_img differs, both builds' index and depth there, the number of covered
+Stored: the projected vertices of the view (the topology is drtk_amd.synthetic.uv_sphere's, integers), the pixels (flat indices) where index_img differs, both builds' index and depth there, the number of covered
 pixels, the largest relative depth difference over the covered pixels, and a SHA-256 of either build's full index_img --
 so that the depth-ordering policy ("source-order IEEE; the shipped flags move a handful of exact near-ties") is pinned
 by DATA: a GPU test can check that the HIP image equals the strict image everywhere (hash), and becomes the fast image
@@ -50,6 +50,9 @@ def main():
             "depth_lsb_moved": np.array(int((d_s != d_f).sum())),
             "sha256_index_strict": np.array(sha(i_s)), "sha256_index_fast": np.array(sha(i_f)), "sha256_depth_strict": np.array(sha(d_s)),
             "res": np.array(res),
+            # the projected vertices themselves: torch's float32 sin / cos differ in the last bit between CPU models (the
+            # GPU box is not this container), and a last-bit change of a vertex changes which pixels are near-ties
+            "v": v[0].numpy(),
         }
         path = os.path.join(ROOT, "tests", "golden", f"fastmath_owner_changes_{mesh}.npz")
         np.savez_compressed(path, **arrs)

@@ -136,7 +136,8 @@ def test_non_finite_texels_under_a_zero_weight_stay_out_of_the_result():
     gl, gg = capi.mipmap_grid_sampler_2d_backward(dev(gout), dev(bad), dev(grid), dev(vt), 4, 1, 0)
     gl_clean, gg_clean = capi.mipmap_grid_sampler_2d_backward(dev(gout), dev(tex), dev(grid), dev(vt), 4, 1, 0)
     assert bool(th.isfinite(gg).all()) and th.equal(gg, gg_clean)
-    assert float(gl[1].abs().max()) == 0.0 and th.equal(gl[0], gl_clean[0])
+    assert float(gl[1].abs().max()) == 0.0
+    close(gl[0], gl_clean[0].cpu(), "gradient of level 0 (sums of float atomics: equal to rounding)")
 
 
 def test_one_texture_shared_by_all_views_is_sampled_in_place():

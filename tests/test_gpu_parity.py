@@ -405,7 +405,8 @@ def test_full_size_index_img_and_the_committed_fast_math_owner_changes(mesh):
     z = np.load(f"{GOLDEN}/fastmath_owner_changes_{mesh}.npz")
     res = int(z["res"])
     nl, no = S.MESH_SIZES[mesh]
-    v, vi = S.sphere_views(1, nl, no, res, res, lobes=0.05)
+    _, vi = S.uv_sphere(nl, no, lobes=0.05)
+    v = th.from_numpy(z["v"])[None]  # the fixture's own vertices: float32 trigonometry differs in the last bit between CPU models
     d_g, i_g = capi.rasterize(dev(v), dev(vi), res, res)
     d_g, i_g = d_g.cpu(), i_g.cpu()
     sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()  # noqa: E731
@@ -958,21 +959,12 @@ def test_whole_training_step_captured_through_autograd():
         th.cuda.synchronize()
         return float(loss.detach()), v_world.grad.clone(), attr.grad.clone()
 
-    side = th.cuda.Stream()
-    side.wait_stream(th.cuda.current_stream())
-    with th.cuda.stream(side):
-        for _ in range(3):
-            v_world.grad = None
-            attr.grad = None
-            step()
-    th.cuda.current_stream().wait_stream(side)
-    th.cuda.synchronize()
-    v_world.grad = None
-    attr.grad = None
-    graph = th.cuda.CUDAGraph()
-    with th.cuda.graph(graph):
-        loss = step()
+    captured = drtk_amd.capture_step(step, [v_world, attr])  # torch's capture recipe (drtk_amd/graph.py)
+    graph, loss = captured.graph, captured.outputs
     gv_static, ga_static = v_world.grad, attr.grad  # filled by every replay
+    assert gv_static is not None and ga_static is not None
+    v_world.grad = None
+    assert captured() is loss and v_world.grad is gv_static  # the helper's own replay call re-attaches the static gradients
 
     for k, move in enumerate((0.0, 0.0, 0.01, -0.02)):
         with th.no_grad():
