@@ -1156,6 +1156,22 @@ __device__ __forceinline__ void shade_rows(
   // an edge (b_k == 0) therefore also sends its wave through exact_div, which is correct for it -- only slower.
   const T b_min = u.abs_denom * T(0x1p-40);
   const unsigned long long id = static_cast<uint32_t>(u.id_tl) & ((1u << kTlShift) - 1u);
+#ifdef DRTK_AMD_ABLATION
+  if (DRTK_DBG(dbg, 512)) { // row balance of the steps: [10] += passes the wave runs (the longest row's), [11] += passes the four rows need together
+    const int need = static_cast<int>((npxf + 15.0f) * 0.0625f);
+    int mx = need;
+#pragma unroll
+    for (int o = 32; o >= 16; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    int sum = need;
+#pragma unroll
+    for (int o = 32; o >= 16; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane_id() == 0) {
+      atomicAdd(&::drtk_amd::g_phase_clocks[10], static_cast<unsigned long long>(mx));
+      atomicAdd(&::drtk_amd::g_phase_clocks[11], static_cast<unsigned long long>(sum));
+      atomicAdd(&::drtk_amd::g_phase_clocks[12], 1ull);
+    }
+  }
+#endif
   for (float ph = lane16_half; ph < npxf; ph += 16.0f) {
     const float fly = __builtin_truncf(ph * rbw);
     const float flx = __builtin_fmaf(-fly, bwf, ph - 0.5f);
@@ -1248,6 +1264,7 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
   __shared__ unsigned long long zbuf[NPIX];
   __shared__ uint32_t s_zmax[(TILE / 8) * (TILE / 8)];
   __shared__ int32_t s_idq[kRasterWaves][kIdRing];
+  __shared__ int32_t s_idk[kRasterWaves][kIdRing]; // ... and the size of what each will have to shade (sort key)
   __shared__ int s_item;
   __shared__ int s_queue[3];
 
@@ -1336,6 +1353,7 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
       const int32_t* vi_n = vi + int64_t(n) * vi_sN;
       const int nb = ss >> 3; // 8x8-pixel blocks per side of this item's rectangle
       int32_t* idq = s_idq[wave];
+      int32_t* idk = s_idk[wave];
 
       // The tile's list is partitioned by orientation (bin_fill): [positive ... | ... negative].  The
       // group that is nearer on average in this view (on a closed mesh: the visible one) is drawn first;
@@ -1370,11 +1388,15 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
         };
         // triangle f of this view on its record alone (one 16-byte load); canvases beyond 65535 pixels a side have no
         // record (.w == 0): those are tested after the set-up
-        auto pre_accept = [&](int f) -> bool {
+        // `size` = pixels of the bbox clipped to the item's rectangle, the number the row that draws it will walk
+        auto pre_accept = [&](int f, int& size) -> bool {
           const uint4 pre = pre_n[f];
-          return pre.w == 0u ||
-              accept(static_cast<int>(pre.x & 0xFFFFu), static_cast<int>(pre.y & 0xFFFFu), static_cast<int>(pre.x >> 16),
-                     static_cast<int>(pre.y >> 16), pre.z);
+          size = NPIX + 1;
+          if (pre.w == 0u) return true;
+          const int bx_min = static_cast<int>(pre.x & 0xFFFFu), by_min = static_cast<int>(pre.y & 0xFFFFu);
+          const int bx_max = static_cast<int>(pre.x >> 16), by_max = static_cast<int>(pre.y >> 16);
+          size = (min(bx_max, x1) - max(bx_min, x0) + 1) * (min(by_max, y1) - max(by_min, y0) + 1);
+          return accept(bx_min, by_min, bx_max, by_max, pre.z);
         };
         // The wave's share of the group (equal parts, so that the waves reach the barrier together), then -- with the
         // first group, whatever their orientation -- its share of the view's big triangles (more than kMaxSmallTiles
@@ -1392,12 +1414,12 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
         for (;;) {
           while (tail - head < kWave && (cursor < end || big_cursor < big_end)) {
             bool ok = false;
-            int f = 0;
+            int f = 0, size = 0;
             if (cursor < end) {
               const int i = cursor + lane;
               if (i < end) {
                 f = pairs[i];
-                ok = pre_accept(f);
+                ok = pre_accept(f, size);
               }
               cursor += kWave;
             } else {
@@ -1406,21 +1428,53 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
                 f = big_n[i];
                 const uint2 r = range_n[f];
                 const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = (r.y & ~kFacingBit) >> 16;
-                ok = tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1 && pre_accept(f);
+                ok = tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1 && pre_accept(f, size);
               }
               big_cursor += kWave;
             }
             const unsigned long long m = __ballot(ok);
-            if (ok) idq[(tail + mbcnt(m)) & (kIdRing - 1)] = f;
+            if (ok) {
+              const int slot = (tail + mbcnt(m)) & (kIdRing - 1);
+              idq[slot] = f;
+              idk[slot] = size;
+            }
             tail += __popcll(m);
           }
           const int cnt = min(kWave, tail - head);
           if (cnt == 0) break;
           wave_lds_sync();
-          // entry e of the round goes to row e % 4, lane e / 4 of the row: every step has (up to) four triangles
+          // Entry e of the round goes to row e % 4, lane e / 4 of the row: every step has (up to) four triangles, and
+          // the step lasts as long as its LARGEST one -- in list order the rows of a step were busy 68 % of its passes
+          // (100k triangles; 77 % at 250k).  So the round's entries are first sorted by the size of their clipped bbox
+          // (bitonic network over the wave, key and source lane in one word), descending: the four triangles of a step
+          // are then neighbours in size, and the invalid tail of a partial round stays at the end.
           const int e = ((lane & 15) << 2) | (lane >> 4);
           bool valid = e < cnt;
-          const int f = valid ? idq[(head + e) & (kIdRing - 1)] : 0;
+          int f;
+#ifndef DRTK_RASTER_NO_SORT
+          if (cnt > 4) {
+            const bool has = lane < cnt;
+            const int slot = (head + lane) & (kIdRing - 1);
+            const int f_nat = has ? idq[slot] : 0;
+            uint32_t p = has ? ((static_cast<uint32_t>(idk[slot]) << 6) | static_cast<uint32_t>(lane)) : static_cast<uint32_t>(lane);
+#pragma unroll
+            for (int k = 2; k <= kWave; k <<= 1) {
+#pragma unroll
+              for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t other = static_cast<uint32_t>(__shfl_xor(static_cast<int>(p), j));
+                const bool take_max = ((lane & j) == 0) == ((lane & k) == 0); // descending over the whole wave
+                p = take_max ? max(p, other) : min(p, other);
+              }
+            }
+            // lane i now holds the i-th largest entry's source lane; entry e's triangle comes from there
+            const int src = __shfl(static_cast<int>(p & 63u), e);
+            f = __shfl(f_nat, src);
+            if (!valid) f = 0;
+          } else
+#endif
+          {
+            f = valid ? idq[(head + e) & (kIdRing - 1)] : 0;
+          }
           head += cnt;
           wave_lds_sync(); // the ring slots just read may be overwritten by the next screening round
           TriSetup<T> s = {};

@@ -42,3 +42,10 @@ tot = sum(buf[i] for i in range(10))
 print(f"rasterize {e0.elapsed_time(e1) / reps:.3f} ms per call (instrumented build); workgroup-clocks per call {tot / reps / 1e6:.1f} M")
 for i, nme in enumerate(names):
     print(f"  {nme:36s} {100.0 * buf[i] / tot:5.1f} %   {buf[i] / reps / 1e6:8.2f} Mclk")
+# row balance of the raster steps (flag 512): how many 16-pixel passes the waves run against what their four rows need
+L.drtk_amd_debug_set_flags(512)
+capi.rasterize(v, vi, a.res, a.res)
+L.drtk_amd_debug_read_phases(buf)
+if buf[12]:
+    print(f"raster steps {buf[12]}: passes run {buf[10]} (mean {buf[10] / buf[12]:.2f} per step), passes needed by the four rows {buf[11]} "
+          f"(mean {buf[11] / buf[12] / 4:.2f} per row and step) -> lane-row utilisation {buf[11] / (4.0 * buf[10]):.3f}")
