@@ -1207,7 +1207,10 @@ __device__ __forceinline__ void shade_rows(
       d2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
     }
     const T depth_inverse = u.dinv0 * d0 + u.dinv1 * d1 + u.dinv2 * d2;
-    const T di = epsclamp(depth_inverse);
+    // epsclamp (:153) of a value that cannot be negative: every d_k is a quotient of b_k >= 0 (the fragment passed the
+    // coverage test) and abs_denom > 0, every dinv_k is 1 / z_k with z_k > 1e-8 (the near-plane cull, :96) -- so only the
+    // `v > eps ? v : eps` branch of the clamp exists here (a NaN sum takes eps there as well)
+    const T di = depth_inverse > Eps<T>::value() ? depth_inverse : Eps<T>::value();
     T rd = fast_rcp(di);
     if (__ballot(!fast_rcp_ok_clamped(di)) != 0) rd = exact_rcp(di);
     const float depth = static_cast<float>(rd);
@@ -1487,15 +1490,11 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
           }
           const TriOwn<T> own = make_row_state<T>(valid, s, f, z_lo, x0, y0, x1, y1);
           if (!DRTK_DBG(dbg, 1)) {
-#ifdef DRTK_RASTER_NO_EARLY_Z
-            raster_rows<T, TILE_SHIFT, false>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
-#else
             if (phase == 0) {
               raster_rows<T, TILE_SHIFT, false>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
             } else {
               raster_rows<T, TILE_SHIFT, true>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
             }
-#endif
           }
         }
         if (tid == 0) DRTK_PHASE(2 + 4 * phase); // wave 0's share of the group: 2 = first group, 6 = second
