@@ -11,12 +11,13 @@
 //                  list (this bounds bin memory at 4 entries per triangle for any input).
 //   2. bin_scan    exclusive scan of the N*tiles counters (one workgroup).
 //   3. bin_fill    second pass over the triangles writes their id into each touched tile's list.
-//   4. tile_raster one workgroup per (view, tile): the tile's packed (depth_bits<<32 | id) z-buffer
-//                  lives in LDS (64x64x8 B = 32 KiB).  Each wave takes 64 binned triangles, sets
-//                  them up one per lane, then walks them one at a time: the triangle's plane
-//                  equations are broadcast into SGPRs (v_readlane) and its bbox is covered with
-//                  64-pixel stamps, one pixel per lane, resolved with LDS 64-bit atomicMin
-//                  (ds_min_u64); the finished tile is unpacked and stored once.
+//   4. tile_raster persistent workgroups pull work items (a tile, or a sub-rectangle of a heavy tile) from a sharded
+//                  queue; the item's packed (depth_bits<<32 | id) z-buffer lives in LDS (64x64x8 B = 32 KiB).  Each
+//                  wave screens its share of the tile's list on 16-byte records, compacts the survivors, sets 64 of
+//                  them up one per lane (exact arithmetic) and shades them FOUR AT A TIME, one per 16-lane DPP row:
+//                  the plane equations reach the row by `row_newbcast`, the row walks the clipped bbox 16 pixels a
+//                  pass, resolved with LDS 64-bit atomicMin (ds_min_u64); the finished tile is unpacked, stored and
+//                  cleared in one sweep.
 //                  Counters in passes 1/3 are bumped with wave-aggregated atomics.
 //
 // HBM traffic is therefore the 8 B/px of real output plus the bins (~28 B per triangle): no
@@ -712,324 +713,6 @@ __global__ __launch_bounds__(kBlock) void bin_fill_kernel(
 }
 
 
-#ifdef DRTK_RASTER_LEGACY
-// ---- pass 4: per-tile rasterization with the z-buffer in LDS -----------------------------------
-// Wave-uniform plane equations of one triangle (broadcast out of the lane that set it up).
-template <typename T>
-struct TriUniform {
-  T ax[3], ay[3], dx[3], dy[3], s[3]; // edge k: ((py - ay) * dx - (px - ax) * dy) * s
-  T abs_denom, rdenom, dinv0, dinv1, dinv2;
-  int tl; // bit k: edge k is top-left
-};
-
-__device__ __forceinline__ int bcast(int x, int lane) {
-  return __builtin_amdgcn_readlane(x, lane);
-}
-__device__ __forceinline__ float bcast(float x, int lane) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
-}
-__device__ __forceinline__ double bcast(double x, int lane) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(u & 0xFFFFFFFFull), lane);
-  const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(u >> 32), lane);
-  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
-}
-
-// Rasterize the triangles held one-per-lane (`valid` lanes; setup `s`, id `f`) into the LDS tile:
-// the wave walks the valid lanes, broadcasts one triangle at a time into SGPRs and covers its
-// bbox ∩ tile with 64-pixel stamps whose shape (bw x floor(64 / bw), bw = the clipped bbox's width) follows the
-// bbox, so slivers and blobs both keep most lanes inside the box.  Coverage, depth and the packed
-// atomicMin are the reference's (rasterize_kernel.cu:117-161), evaluated per lane = per pixel.
-template <typename T, int TILE_SHIFT>
-__device__ __forceinline__ void raster_lanes(
-    bool valid, const TriSetup<T>& s, int f, int x0, int y0, int x1, int y1,
-    unsigned long long* __restrict__ zbuf, int dbg = 0) {
-  const int lane = lane_id();
-  // per-lane: oriented edges + clipped bbox
-  T eax[3], eay[3], edx[3], edy[3], es[3];
-  {
-    const T px[3] = {s.p1x, s.p2x, s.p0x}, py[3] = {s.p1y, s.p2y, s.p0y}; // edge k starts at p_{k+1}
-    const T qx[3] = {s.p2x, s.p0x, s.p1x}, qy[3] = {s.p2y, s.p0y, s.p1y}; // ... and ends at p_{k+2}
-    const bool c[3] = {s.c0, s.c1, s.c2};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      eax[k] = c[k] ? px[k] : qx[k];
-      eay[k] = c[k] ? py[k] : qy[k];
-      const T bx = c[k] ? qx[k] : px[k], by = c[k] ? qy[k] : py[k];
-      edx[k] = bx - eax[k];
-      edy[k] = by - eay[k];
-      es[k] = c[k] ? s.sign_denom : -s.sign_denom;
-    }
-  }
-  const int bx0 = max(s.bb_min_x, x0), bx1 = min(s.bb_max_x, x1);
-  const int by0 = max(s.bb_min_y, y0), by1 = min(s.bb_max_y, y1);
-  const int tl = (s.tl0 ? 1 : 0) | (s.tl1 ? 2 : 0) | (s.tl2 ? 4 : 0);
-  unsigned long long todo = __ballot(valid && bx0 <= bx1 && by0 <= by1);
-  if (DRTK_DBG(dbg, 1)) todo = 0;
-  while (todo) {
-    const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
-    todo &= todo - 1;
-    TriUniform<T> u;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      u.ax[k] = bcast(eax[k], j);
-      u.ay[k] = bcast(eay[k], j);
-      u.dx[k] = bcast(edx[k], j);
-      u.dy[k] = bcast(edy[k], j);
-      u.s[k] = bcast(es[k], j);
-    }
-    u.abs_denom = bcast(s.abs_denom, j);
-    u.rdenom = bcast(s.rdenom, j);
-    const bool div_ok = exact_div_ok(u.abs_denom);
-    u.dinv0 = bcast(s.dinv0, j);
-    u.dinv1 = bcast(s.dinv1, j);
-    u.dinv2 = bcast(s.dinv2, j);
-    u.tl = bcast(tl, j);
-    const int ubx0 = bcast(bx0, j), uby0 = bcast(by0, j), uby1 = bcast(by1, j);
-    const int bw = bcast(bx1, j) - ubx0 + 1;
-    const unsigned long long id = static_cast<uint32_t>(bcast(f, j));
-    // stamp shape
-    // stamp = bw x floor(64 / bw) pixels: exactly as wide as the clipped bbox (bw <= 64), so a 9-wide bbox gets 7 rows
-    // per pass instead of the 4 of a 16-wide power-of-two stamp.  lane -> (lx, ly) by one multiplication with 1 / bw:
-    // (lane + 1/2) / bw is never within 1 / (2 bw) >= 1/128 of an integer, far beyond the reciprocal's rounding
-    const float rbw = __builtin_amdgcn_rcpf(static_cast<float>(bw));
-    const int ly = static_cast<int>((static_cast<float>(lane) + 0.5f) * rbw);
-    const int lx = lane - ly * bw;
-    const int sh = __builtin_amdgcn_readfirstlane(static_cast<int>(64.5f * rbw)); // floor(64 / bw)
-    const int x = ubx0 + lx;
-    const T px = static_cast<T>(x);
-    T ex[3]; // -(px - ax) * dy part, constant over rows
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ex[k] = (px - u.ax[k]) * u.dy[k];
-    if (ly < sh && !DRTK_DBG(dbg, 2)) {
-      for (int y = uby0 + ly; y <= uby1; y += sh) {
-        const T py = static_cast<T>(y);
-        T b0 = ((py - u.ay[0]) * u.dx[0] - ex[0]) * u.s[0];
-        T b1 = ((py - u.ay[1]) * u.dx[1] - ex[1]) * u.s[1];
-        T b2 = ((py - u.ay[2]) * u.dx[2] - ex[2]) * u.s[2];
-        // coverage + top-left rule (:133-145) as ONE predicate: inside or on an edge, and not on an edge that is not
-        // top/left (the three rule bits are wave-uniform)
-        const bool inside = (b0 >= T(0)) & (b1 >= T(0)) & (b2 >= T(0));
-        const bool on_excluded_edge = (!(u.tl & 1) & (b0 == T(0))) | (!(u.tl & 2) & (b1 == T(0))) | (!(u.tl & 4) & (b2 == T(0)));
-        if (!inside | on_excluded_edge) continue;
-        if (DRTK_DBG(dbg, 4)) {
-          atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], id);
-          continue;
-        }
-        // b_k / abs_denom (:148), 1 / epsclamp(depth_inverse) (:153): the correctly rounded fast forms are evaluated
-        // unconditionally; whether any lane needs the IEEE fallback (operands outside the guarded range: denormal
-        // quotients, an all-ones significand) is ONE wave-uniform test per pass instead of a divergent branch per
-        // division -- the fallback itself is exact_div / exact_rcp as before
-        const T q0 = b0 * u.rdenom, q1 = b1 * u.rdenom, q2 = b2 * u.rdenom;
-        const bool fast_ok = div_ok & ((q0 >= DivRange<T>::tiny()) | (b0 == T(0))) & ((q1 >= DivRange<T>::tiny()) | (b1 == T(0))) &
-            ((q2 >= DivRange<T>::tiny()) | (b2 == T(0)));
-        T d0 = markstein2(b0, u.abs_denom, u.rdenom, q0);
-        T d1 = markstein2(b1, u.abs_denom, u.rdenom, q1);
-        T d2 = markstein2(b2, u.abs_denom, u.rdenom, q2);
-        if (__ballot(!fast_ok) != 0) {
-          d0 = exact_div(b0, u.abs_denom, u.rdenom, div_ok);
-          d1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
-          d2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
-        }
-        const T depth_inverse = u.dinv0 * d0 + u.dinv1 * d1 + u.dinv2 * d2;
-        const T di = epsclamp(depth_inverse);
-        T rd = fast_rcp(di);
-        if (__ballot(!fast_rcp_ok(di)) != 0) rd = exact_rcp(di);
-        const float depth = static_cast<float>(rd);
-        const unsigned long long packed = (static_cast<unsigned long long>(__float_as_uint(depth)) << 32) | id;
-        atomicMin(&zbuf[((y - y0) << TILE_SHIFT) + (x - x0)], packed);
-      }
-    }
-  }
-}
-
-// The raster loop is a long dependent chain per wave (IPC ~0.2 with 4 waves per workgroup), so the
-// workgroup is 8 waves: with the 32 KiB tile that is 4 workgroups = 32 waves per CU, the hardware maximum.
-constexpr int kRasterBlock = 512;
-
-template <typename T, int TILE_SHIFT>
-__global__ __launch_bounds__(kRasterBlock) void tile_raster_kernel(
-    const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN,
-    int H, int W, int tiles_x, int tiles_per_view, const int32_t* __restrict__ tile_offset,
-    const unsigned long long* __restrict__ tile_count, const float* __restrict__ view_stats,
-    const int32_t* __restrict__ pairs, const int32_t* __restrict__ big_count,
-    const int32_t* __restrict__ big_list, const uint2* __restrict__ tri_range, const uint4* __restrict__ tri_pre,
-    const uint32_t* __restrict__ items, int32_t* __restrict__ queue, float* __restrict__ depth_img,
-    int32_t* __restrict__ index_img, int dbg) {
-  constexpr int TILE = 1 << TILE_SHIFT;
-  constexpr int NPIX = TILE * TILE;
-  __shared__ unsigned long long zbuf[NPIX];
-  __shared__ uint32_t s_zmax[(TILE / 8) * (TILE / 8)];
-  __shared__ int s_item;
-
-  const int tid = threadIdx.x;
-  const int n_items = queue[1];
-  DRTK_PHASE_INIT();
-  for (;;) {
-    // (popping the NEXT item when this one starts, to take the atomic's round trip off the critical path, was measured
-    // slower: 0.444 vs 0.424 ms -- a workgroup that reserves an item while it is still busy delays that item, and the
-    // heavy-first order of the list only balances the tail if items are taken when they can be started)
-    if (tid == 0) s_item = atomicAdd(&queue[0], 1);
-    __syncthreads();
-    if (tid == 0) DRTK_PHASE(0); // queue pop
-    const int item_index = s_item;
-    if (item_index >= n_items) break;
-    const uint32_t item = items[item_index];
-    const int tile = item & 0xFFFFFF;
-    const int sub = (item >> 24) & 0xF, split_log = (item >> 28) & 3;
-    const int n = tile / tiles_per_view;
-    const int t_in_view = tile - n * tiles_per_view;
-    const int ty = t_in_view / tiles_x, tx = t_in_view - ty * tiles_x;
-    const int ss = TILE >> split_log; // side of this item's rectangle
-    const int x0 = (tx << TILE_SHIFT) + (sub & ((1 << split_log) - 1)) * ss;
-    const int y0 = (ty << TILE_SHIFT) + (sub >> split_log) * ss;
-    const int x1 = min(x0 + ss - 1, W - 1), y1 = min(y0 + ss - 1, H - 1);
-    if (x0 < W && y0 < H) {
-      const int rows = y1 - y0 + 1;
-      for (int i = tid; i < (ss << TILE_SHIFT); i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488
-      __syncthreads();
-      if (tid == 0) DRTK_PHASE(1); // clear
-
-      const T* v_n = v + int64_t(n) * V * 3;
-      const int32_t* vi_n = vi + int64_t(n) * vi_sN;
-      const int wave = tid / kWave, lane = tid & (kWave - 1);
-      const int nb = ss >> 3; // 8x8-pixel blocks per side of this item's rectangle
-
-      // The tile's list is partitioned by orientation (bin_fill): [positive ... | ... negative].  The
-      // group that is nearer on average in this view (on a closed mesh: the visible one) is drawn first;
-      // then the farthest depth of every 8x8 block is known (empty pixels count as infinitely far), and
-      // a triangle of the second group whose depth lower bound lies beyond the farthest depth of all
-      // blocks its clipped bbox touches cannot win a single pixel -- (depth, id) only ever decreases --
-      // so it is dropped before any fragment work.  On a closed mesh that removes the hidden half of
-      // the triangles; on any input the image is unchanged (strict comparison: ties still go by id).
-      const int begin = tile_offset[tile], end_all = tile_offset[tile + 1];
-      const int n_pos = static_cast<int>(tile_count[tile] >> 32);
-      const float* st = view_stats + 4 * n;
-      const bool pos_first = st[0] * st[3] <= st[2] * st[1]; // mean z of positive <= mean z of negative
-      for (int phase = 0; phase < 2; ++phase) {
-        if (phase == 1 && DRTK_DBG(dbg, 64)) break; // timing only: the second (mostly hidden) group is not drawn at all
-        const bool take_pos = (phase == 0) == pos_first;
-        const int g_begin = take_pos ? begin : begin + n_pos, g_end = take_pos ? begin + n_pos : end_all;
-        // the test on a triangle's pre-reject record (bin_count: clamped pixel bbox + depth lower bound): does its bbox
-        // touch this item's rectangle, and (second group) can it still win a pixel of the 8x8 blocks it touches
-        auto accept = [&](int bx_min, int by_min, int bx_max, int by_max, uint32_t z_lo_bits) -> bool {
-          if (!(bx_min <= x1 && bx_max >= x0 && by_min <= y1 && by_max >= y0)) return false;
-          if (phase == 0 || z_lo_bits == 0 || DRTK_DBG(dbg, 16)) return true;
-          const int cx0 = (max(bx_min, x0) - x0) >> 3, cx1 = (min(bx_max, x1) - x0) >> 3;
-          const int cy0 = (max(by_min, y0) - y0) >> 3, cy1 = (min(by_max, y1) - y0) >> 3;
-          if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) > 16) return true;
-          uint32_t far = 0;
-          for (int by = cy0; by <= cy1; ++by)
-            for (int bx = cx0; bx <= cx1; ++bx) far = max(far, s_zmax[by * nb + bx]);
-          return !(z_lo_bits > far);
-        };
-        const uint4* pre_n = tri_pre + int64_t(n) * F;
-        // triangle f of this view: rejected on its record alone (one 16-byte load), else set up
-        auto fetch = [&](int f, TriSetup<T>& s) -> bool {
-          const uint4 pre = pre_n[f];
-          if (pre.w != 0u &&
-              !accept(static_cast<int>(pre.x & 0xFFFFu), static_cast<int>(pre.y & 0xFFFFu), static_cast<int>(pre.x >> 16),
-                      static_cast<int>(pre.y >> 16), pre.z))
-            return false;
-          if (!tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s)) return false;
-          // canvases beyond 65535 pixels a side have no record: bbox test on the set-up triangle, no depth bound
-          return pre.w != 0u || accept(s.bb_min_x, s.bb_min_y, s.bb_max_x, s.bb_max_y, 0u);
-        };
-        // binned triangles: 64 per wave and round, set up one per lane, rasterized cooperatively;
-        // the group is cut into equal parts, one per wave, so that the waves reach the barrier together
-        const int per_wave = (g_end - g_begin + kRasterBlock / kWave - 1) / (kRasterBlock / kWave);
-        const int wave_begin = g_begin + wave * per_wave;
-        const int end = min(wave_begin + per_wave, g_end);
-        for (int i0 = wave_begin; i0 < end; i0 += kWave) {
-          const int i = i0 + lane;
-          int f = 0;
-          bool valid = false;
-          TriSetup<T> s = {};
-          if (i < end && !DRTK_DBG(dbg, 8)) {
-            f = pairs[i];
-            valid = fetch(f, s);
-          }
-          if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
-        }
-        if (tid == 0) DRTK_PHASE(2 + 4 * phase); // wave 0's share of the group: 2 = first group, 6 = second
-        if (phase == 1) break;
-
-        // big triangles (more than kMaxSmallTiles tiles): per-view list, filtered by tile range; drawn
-        // with the first group whatever their orientation
-        const int nbig = big_count[n];
-        const int32_t* big_n = big_list + int64_t(n) * F;
-        const uint2* range_n = tri_range + int64_t(n) * F;
-        const int big_per_wave = (nbig + kRasterBlock / kWave - 1) / (kRasterBlock / kWave);
-        const int big_begin = wave * big_per_wave, big_end = min(big_begin + big_per_wave, nbig);
-        for (int i0 = big_begin; i0 < big_end; i0 += kWave) {
-          const int i = i0 + lane;
-          int f = 0;
-          bool valid = false;
-          TriSetup<T> s = {};
-          if (i < big_end) {
-            f = big_n[i];
-            const uint2 r = range_n[f];
-            const int rtx0 = r.x & 0xFFFF, rtx1 = r.x >> 16, rty0 = r.y & 0xFFFF, rty1 = (r.y & ~kFacingBit) >> 16;
-            if (tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1) valid = fetch(f, s);
-          }
-          if (__ballot(valid)) raster_lanes<T, TILE_SHIFT>(valid, s, f, x0, y0, x1, y1, zbuf, dbg);
-        }
-        if (tid == 0) DRTK_PHASE(3); // big triangles
-        __syncthreads();
-        if (tid == 0) DRTK_PHASE(4); // wave 0 waiting for the other waves' first group
-        for (int bi = wave; bi < nb * nb; bi += kRasterBlock / kWave) {
-          const int bx = bi % nb, by = bi / nb;
-          uint32_t m = static_cast<uint32_t>(zbuf[(((by << 3) + (lane >> 3)) << TILE_SHIFT) + (bx << 3) + (lane & 7)] >> 32);
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) m = max(m, static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), o)));
-          if (lane == 0) s_zmax[bi] = m;
-        }
-        __syncthreads();
-        if (tid == 0) DRTK_PHASE(5); // block-farthest reduction
-      }
-      __syncthreads();
-      if (tid == 0) DRTK_PHASE(7); // wave 0 waiting for the other waves' second group
-
-      // unpack + store (rasterize_kernel.cu:402-415)
-      const int64_t img_base = int64_t(n) * H * W;
-      const bool vec_ok = (W & 3) == 0;
-      const int quads_per_row = ss >> 2;
-      for (int q = tid; q < rows * quads_per_row; q += kRasterBlock) {
-        const int row = q / quads_per_row;
-        const int col = (q - row * quads_per_row) << 2;
-        const int y = y0 + row, x = x0 + col;
-        if (x > x1) continue;
-        int32_t idx4[4];
-        float dep4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned long long pv = zbuf[(row << TILE_SHIFT) + col + j];
-          const uint32_t hi = static_cast<uint32_t>(pv >> 32);
-          dep4[j] = (hi == 0xFFFFFFFFu) ? 0.0f : __uint_as_float(hi);
-          idx4[j] = static_cast<int32_t>(static_cast<uint32_t>(pv & 0xFFFFFFFFu));
-        }
-        const int64_t o = img_base + int64_t(y) * W + x;
-        if (vec_ok) { // x % 4 == 0 and W % 4 == 0 -> x+3 < W and 16-byte aligned
-          *reinterpret_cast<int4*>(index_img + o) = make_int4(idx4[0], idx4[1], idx4[2], idx4[3]);
-          *reinterpret_cast<float4*>(depth_img + o) = make_float4(dep4[0], dep4[1], dep4[2], dep4[3]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (x + j <= x1) {
-              index_img[o + j] = idx4[j];
-              depth_img[o + j] = dep4[j];
-            }
-          }
-        }
-      }
-    }
-    if (tid == 0) DRTK_PHASE(8); // unpack + store (issue)
-    __syncthreads(); // zbuf and s_item are reused by the next item
-    if (tid == 0) DRTK_PHASE(9); // waiting for the other waves' stores
-  }
-}
-
-#else
 // ---- pass 4: per-tile rasterization with the z-buffer in LDS -----------------------------------
 // Four triangles per pass, one per 16-lane DPP row.  A wave sets 64 triangles up one per lane (gathers + exact set-up)
 // and then walks them in 16 steps: in step k row r (lanes 16r .. 16r+15) shades the triangle held by ITS lane k -- the
@@ -1322,11 +1005,7 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
       const int64_t img_base = int64_t(n) * H * W;
       const bool vec_ok = (W & 3) == 0;
       const int quads_per_row = ss >> 2;
-#ifdef DRTK_RASTER_NO_EMPTY_FASTPATH
-      if (false) {
-#else
       if ((item & kItemEmpty) && nbig == 0) {
-#endif
         // nothing can touch this tile: background straight to the images, no LDS tile, no barrier
         for (int q = tid; q < rows * quads_per_row; q += kRasterBlock) {
           const int row = q / quads_per_row;
@@ -1561,8 +1240,6 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
   }
 }
 
-#endif // DRTK_RASTER_LEGACY
-
 // Diagnostics: exact_div against the IEEE division on pseudo-random operands.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void exact_div_selftest_kernel(
@@ -1653,11 +1330,7 @@ int rasterize_impl(
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   // persistent workgroups pulling work items: as many as can be resident, never more than items
-#ifdef DRTK_RASTER_LEGACY
-  const int64_t resident = int64_t(num_compute_units()) * 4;
-#else
   const int64_t resident = int64_t(num_compute_units()) * (raster_waves_per_simd<T>() / 2);
-#endif
   const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(L.max_items, resident));
   if (L.tile_shift == 6) {
     DRTK_LAUNCH(
