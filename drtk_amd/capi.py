@@ -20,6 +20,25 @@ DRTK_F32, DRTK_F64 = 0, 1
 
 _lib_path = None
 
+_POISON = os.environ.get("DRTK_CAPI_POISON", "") not in ("", "0")
+
+
+def _out(*shape, dtype, device):
+    """Output / workspace allocation of this binding: uninitialised memory -- or, with DRTK_CAPI_POISON=1 in the
+    environment (the fuzzers and the GPU suite set it), memory pre-filled with NaN / a large negative integer / 0xA5
+    bytes, so that an element a kernel forgot to write cannot pass for a value (freshly allocated device memory reads as
+    zeros, which is a plausible image)."""
+    t = th.empty(*shape, dtype=dtype, device=device)
+    if _POISON and t.numel():
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        elif t.dtype == th.uint8:
+            t.fill_(0xA5)
+        else:
+            t.fill_(-(2 ** 30) - 7)
+    return t
+
+
 
 def use_profiling_library(path: str) -> None:
     """profiles/kernel_bench.py --flags only: bind this module to the ablation build of the same sources
@@ -175,10 +194,10 @@ def rasterize(v, vi, height, width, stream=None, workspace=None, wireframe=False
         assert depth.shape == (N, height, width) and index.shape == (N, height, width) and depth.is_contiguous() and index.is_contiguous()
         assert depth.dtype == th.float32 and index.dtype == th.int32
     else:
-        depth = th.empty(N, height, width, dtype=th.float32, device=v.device)
-        index = th.empty(N, height, width, dtype=th.int32, device=v.device)
+        depth = _out(N, height, width, dtype=th.float32, device=v.device)
+        index = _out(N, height, width, dtype=th.int32, device=v.device)
     nbytes = rasterize_lines_workspace_bytes(N, height, width) if wireframe else rasterize_workspace_bytes(N, F, height, width)
-    ws = workspace if workspace is not None else th.empty(nbytes, dtype=th.uint8, device=v.device)
+    ws = workspace if workspace is not None else _out(nbytes, dtype=th.uint8, device=v.device)
     _check(
         lib().drtk_amd_rasterize(
             ctypes.c_int(_dt(v)), _p(v), _p(vi_c), _i(N), _i(V), _i(F), _i(vi_sN), _i(height), _i(width),
@@ -195,8 +214,8 @@ def render(v, vi, index_img, stream=None):
     N, V, _ = v.shape
     H, W = index_img.shape[1:]
     vi_c, vi_sN, F = _vi(vi, N)
-    depth = th.empty(N, H, W, dtype=v.dtype, device=v.device)
-    bary = th.empty(N, 3, H, W, dtype=v.dtype, device=v.device)
+    depth = _out(N, H, W, dtype=v.dtype, device=v.device)
+    bary = _out(N, 3, H, W, dtype=v.dtype, device=v.device)
     _check(
         lib().drtk_amd_render(
             ctypes.c_int(_dt(v)), _p(v), _p(vi_c), _p(index_img), _i(N), _i(V), _i(F), _i(vi_sN), _i(H), _i(W),
@@ -213,7 +232,7 @@ def render_backward(v, vi, index_img, grad_depth_img, grad_bary_img, stream=None
     N, V, _ = v.shape
     H, W = index_img.shape[1:]
     vi_c, vi_sN, F = _vi(vi, N)
-    grad_v = th.empty(N, V, 3, dtype=v.dtype, device=v.device)
+    grad_v = _out(N, V, 3, dtype=v.dtype, device=v.device)
     _check(
         lib().drtk_amd_render_backward(
             ctypes.c_int(_dt(v)), _p(v), _p(vi_c), _p(index_img), _p(gd), _p(gb), _i(N), _i(V), _i(F), _i(vi_sN),
@@ -230,7 +249,7 @@ def interpolate(attrs, vi, index_img, bary_img, stream=None, masked=False):
     N, V, C = attrs.shape
     H, W = index_img.shape[1:]
     vi_c, vi_sN, F = _vi(vi, N)
-    out = th.empty(N, C, H, W, dtype=attrs.dtype, device=attrs.device)
+    out = _out(N, C, H, W, dtype=attrs.dtype, device=attrs.device)
     fn = lib().drtk_amd_interpolate_masked if masked else lib().drtk_amd_interpolate
     _check(
         fn(ctypes.c_int(_dt(attrs)), _p(attrs), _p(vi_c), _p(index_img), _p(bary_img), _i(N), _i(V), _i(C), _i(F),
@@ -254,8 +273,8 @@ def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires
     N, V, C = attrs.shape
     H, W = index_img.shape[1:]
     vi_c, vi_sN, F = _vi(vi, N)
-    ag = th.empty(N, V, C, dtype=attrs.dtype, device=attrs.device) if vert_requires_grad else None
-    bg = th.empty(N, 3, H, W, dtype=attrs.dtype, device=attrs.device) if bary_requires_grad else None
+    ag = _out(N, V, C, dtype=attrs.dtype, device=attrs.device) if vert_requires_grad else None
+    bg = _out(N, 3, H, W, dtype=attrs.dtype, device=attrs.device) if bary_requires_grad else None
     _check(
         lib().drtk_amd_interpolate_backward(
             ctypes.c_int(_dt(attrs)), _p(grad_out), _p(attrs), _p(vi_c), _p(index_img), _p(bary_img), _i(N), _i(V),
@@ -275,8 +294,8 @@ def interpolation_matrix(vi, index_img, bary_img, stream=None):
     row_pixels = th.nonzero(index_img.reshape(-1).ne(-1)).reshape(-1)
     R = row_pixels.numel()
     crow = th.arange(0, 3 * R + 1, 3, dtype=th.int64, device=index_img.device)
-    col = th.empty(3 * R, dtype=th.int64, device=index_img.device)
-    values = th.empty(3 * R, dtype=bary_img.dtype, device=bary_img.device)
+    col = _out(3 * R, dtype=th.int64, device=index_img.device)
+    values = _out(3 * R, dtype=bary_img.dtype, device=bary_img.device)
     _check(
         lib().drtk_amd_interpolation_matrix(
             ctypes.c_int(_dt(bary_img)), _p(vi_c), _p(index_img), _p(bary_img), _p(row_pixels), _i(R), _i(N), _i(F),
@@ -292,7 +311,7 @@ def interpolation_matrix_backward(grad_values, vi, index_img, row_pixels, stream
     row_pixels = row_pixels.contiguous()
     N, H, W = index_img.shape
     vi_c, vi_sN, F = _vi(vi, N)
-    bg = th.empty(N, 3, H, W, dtype=grad_values.dtype, device=grad_values.device)
+    bg = _out(N, 3, H, W, dtype=grad_values.dtype, device=grad_values.device)
     _check(
         lib().drtk_amd_interpolation_matrix_backward(
             ctypes.c_int(_dt(grad_values)), _p(grad_values), _p(vi_c), _p(index_img), _p(row_pixels),
@@ -317,7 +336,7 @@ def interpolation_normal_matrix_values(pair_indices, index_img, bary_img, nnz, s
     bary_img = bary_img.contiguous()
     N, H, W = index_img.shape
     pr, pair_sN, F = _pairs(pair_indices, N)
-    values = th.empty(nnz, dtype=bary_img.dtype, device=bary_img.device)
+    values = _out(nnz, dtype=bary_img.dtype, device=bary_img.device)
     _check(
         lib().drtk_amd_interpolation_normal_matrix_values(
             ctypes.c_int(_dt(bary_img)), _p(pr), _p(index_img), _p(bary_img), _i(N), _i(F), _i(pair_sN), _i(H), _i(W),
@@ -333,7 +352,7 @@ def interpolation_normal_matrix_values_backward(grad_values, pair_indices, index
     bary_img = bary_img.contiguous()
     N, H, W = index_img.shape
     pr, pair_sN, F = _pairs(pair_indices, N)
-    bg = th.empty(N, 3, H, W, dtype=bary_img.dtype, device=bary_img.device)
+    bg = _out(N, 3, H, W, dtype=bary_img.dtype, device=bary_img.device)
     _check(
         lib().drtk_amd_interpolation_normal_matrix_values_backward(
             ctypes.c_int(_dt(bary_img)), _p(grad_values), _p(pr), _p(index_img), _p(bary_img), _i(N), _i(F),
@@ -382,7 +401,7 @@ def mipmap_grid_sampler_2d(levels, grid, vt_dxdy_img, max_aniso, padding_mode=0,
     vt = vt_dxdy_img.contiguous()
     N, C = lv[0].shape[:2]
     H, W = grid.shape[1:3]
-    out = th.empty(N, C, H, W, dtype=lv[0].dtype, device=lv[0].device)
+    out = _out(N, C, H, W, dtype=lv[0].dtype, device=lv[0].device)
     _check(
         lib().drtk_amd_mipmap_grid_sampler_2d(
             ctypes.c_int(_dt(lv[0])), ptrs, lh, lw, lsn, ctypes.c_int(len(lv)), _p(grid), glayout, _p(vt), _i(N), _i(C), _i(H), _i(W),
@@ -404,7 +423,7 @@ def mipmap_grid_sampler_2d_backward(grad_out, levels, grid, vt_dxdy_img, max_ani
     N, C = lv[0].shape[:2]
     H, W = grid.shape[1:3]
     # contiguous even for an expanded pyramid, and back to back in one buffer: the call then zeroes them with one launch
-    flat = th.empty(sum(t.numel() for t in lv), dtype=lv[0].dtype, device=lv[0].device)
+    flat = _out(sum(t.numel() for t in lv), dtype=lv[0].dtype, device=lv[0].device)
     glv, off = [], 0
     for t in lv:
         glv.append(flat[off:off + t.numel()].view(t.shape))
@@ -433,7 +452,7 @@ def screen_space_uv_derivative(v, vt, vi, vti, index_img, bary_img, mask, campos
     V, T = v_c.shape[-2], vt_c.shape[-2]
     vi_c, vti_c = vi.contiguous(), vti.contiguous()
     m = None if mask is None else mask.to(th.uint8).contiguous()
-    out = th.empty(N, H, W, 2, 2, dtype=bary_img.dtype, device=bary_img.device)
+    out = _out(N, H, W, 2, 2, dtype=bary_img.dtype, device=bary_img.device)
     _check(
         lib().drtk_amd_screen_space_uv_derivative(
             ctypes.c_int(_dt(bary_img)), _p(v_c), _i(v_sN), _p(vt_c), _i(vt_sN), _p(vi_c), _p(vti_c), _p(index_img),
@@ -460,9 +479,9 @@ def edge_grad_backward(v_pix, img, index_img, vi, grad_output, max_dp_dr=1e4, st
     N, V, _ = v_pix.shape
     C, H, W = img.shape[1:]
     vi_c, vi_sN, F = _vi(vi, N)
-    out = th.empty(N, 3, H, W, dtype=v_pix.dtype, device=v_pix.device)
+    out = _out(N, 3, H, W, dtype=v_pix.dtype, device=v_pix.device)
     nbytes = edge_grad_backward_workspace_bytes(v_pix.dtype, N, H, W)
-    ws = workspace if workspace is not None else th.empty(nbytes, dtype=th.uint8, device=v_pix.device)
+    ws = workspace if workspace is not None else _out(nbytes, dtype=th.uint8, device=v_pix.device)
     _check(
         lib().drtk_amd_edge_grad_backward(
             ctypes.c_int(_dt(v_pix)), _p(v_pix), _p(img), _p(index_img), _p(vi_c), _p(grad_output), _i(N), _i(V),
@@ -483,12 +502,12 @@ def edge_grad_backward_fused(v_pix, img, index_img, vi, bary_img, grad_output, m
     N, V, _ = v_pix.shape
     C, H, W = img.shape[1:]
     vi_c, vi_sN, F = _vi(vi, N)
-    out = th.empty(N, V, 3, dtype=v_pix.dtype, device=v_pix.device)
+    out = _out(N, V, 3, dtype=v_pix.dtype, device=v_pix.device)
     nb = ctypes.c_size_t(0)
     code = DRTK_F32 if v_pix.dtype == th.float32 else DRTK_F64
     _check(lib().drtk_amd_edge_grad_backward_fused_workspace_bytes(ctypes.c_int(code), _i(N), _i(H), _i(W), ctypes.byref(nb)),
            "edge_grad_backward_fused")
-    ws = th.empty(nb.value, dtype=th.uint8, device=v_pix.device)
+    ws = _out(nb.value, dtype=th.uint8, device=v_pix.device)
     _check(
         lib().drtk_amd_edge_grad_backward_fused(
             ctypes.c_int(_dt(v_pix)), _p(v_pix), _p(img), _p(index_img), _p(vi_c), _p(bary_img), _p(grad_output),

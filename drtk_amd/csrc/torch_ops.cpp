@@ -13,6 +13,8 @@
 //
 // This file is host-only C++ (no device code); the kernels live in libdrtk_amd.so.  There is NO
 // CPU compute path: the CPU key is registered only to fail with a clear message.
+#include <cstdlib>
+#include <limits>
 #include <ATen/ATen.h>
 #include <ATen/autocast_mode.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -74,8 +76,26 @@ ViArg prep_vi(const Tensor& vi) {
   return a;
 }
 
+// Output allocation of the shim: uninitialised memory, or -- with DRTK_CAPI_POISON=1 in the environment, which the test
+// suite and the fuzzers set -- memory pre-filled with NaN / a large negative integer / 0xA5 bytes, so that an element a
+// kernel forgot to write cannot pass for a value (freshly allocated device memory reads as zeros, a plausible image:
+// DESIGN.md 3.1, round 3).  The product never pays for it: one getenv at load time.
+const bool g_poison_outputs = [] {
+  const char* e = std::getenv("DRTK_CAPI_POISON");
+  return e && e[0] && !(e[0] == '0' && !e[1]);
+}();
+Tensor out_empty(at::IntArrayRef sizes, const at::TensorOptions& opts) {
+  Tensor t = at::empty(sizes, opts);
+  if (g_poison_outputs && t.numel() > 0) {
+    if (at::isFloatingType(t.scalar_type())) t.fill_(std::numeric_limits<double>::quiet_NaN());
+    else if (t.scalar_type() == at::kByte) t.fill_(0xA5);
+    else t.fill_(-(1 << 30) - 7);
+  }
+  return t;
+}
+
 Tensor alloc_workspace(size_t bytes, const Tensor& like) {
-  return at::empty({static_cast<int64_t>(bytes)}, like.options().dtype(at::kByte));
+  return out_empty({static_cast<int64_t>(bytes)}, like.options().dtype(at::kByte));
 }
 
 [[noreturn]] void no_cpu(const char* op) {
@@ -119,8 +139,8 @@ std::vector<Tensor> rasterize_hip(
   const auto v_c = v.contiguous();
   const ViArg via = prep_vi(vi);
   const int64_t N = v.size(0), V = v.size(1), F = vi.size(1);
-  auto depth_img = at::empty({N, height, width}, v.options().dtype(at::kFloat));
-  auto index_img = at::empty({N, height, width}, v.options().dtype(at::kInt));
+  auto depth_img = out_empty({N, height, width}, v.options().dtype(at::kFloat));
+  auto index_img = out_empty({N, height, width}, v.options().dtype(at::kInt));
   size_t ws_bytes = 0;
   check_status(
       wireframe ? drtk_amd_rasterize_lines_workspace_bytes(N, height, width, &ws_bytes)
@@ -212,8 +232,8 @@ std::vector<Tensor> render_hip(const Tensor& v, const Tensor& vi, const Tensor& 
   const auto idx_c = index_img.contiguous();
   const ViArg via = prep_vi(vi);
   const int64_t N = v.size(0), V = v.size(1), F = vi.size(1), H = index_img.size(1), W = index_img.size(2);
-  auto depth_img = at::empty({N, H, W}, v.options());
-  auto bary_img = at::empty({N, 3, H, W}, v.options());
+  auto depth_img = out_empty({N, H, W}, v.options());
+  auto bary_img = out_empty({N, 3, H, W}, v.options());
   check_status(
       drtk_amd_render(
           dt, v_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), N, V, F, via.sN, H, W,
@@ -233,7 +253,7 @@ Tensor render_backward_hip(
   const int64_t N = v.size(0), V = v.size(1), F = vi.size(1), H = index_img.size(1), W = index_img.size(2);
   const auto gd = grad_depth_img.to(v.scalar_type()).contiguous();
   const auto gb = grad_bary_img.to(v.scalar_type()).contiguous();
-  auto grad_v = at::empty({N, V, 3}, v.options()); // zero-filled by the call
+  auto grad_v = out_empty({N, V, 3}, v.options()); // zero-filled by the call
   check_status(
       drtk_amd_render_backward(
           dt, v_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), gd.data_ptr(), gb.data_ptr(), N, V,
@@ -338,7 +358,7 @@ Tensor interpolate_launch(const Tensor& a, const Tensor& vi, const Tensor& index
   const auto bary_c = bary_img.contiguous();
   const ViArg via = prep_vi(vi);
   const int64_t N = a.size(0), V = a.size(1), C = a.size(2), F = vi.size(1), H = bary_img.size(2), W = bary_img.size(3);
-  auto out = at::empty({N, C, H, W}, a.options());
+  auto out = out_empty({N, C, H, W}, a.options());
   check_status(
       (masked ? drtk_amd_interpolate_masked : drtk_amd_interpolate)(
           dt, a_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), N, V, C, F, via.sN,
@@ -367,8 +387,8 @@ std::tuple<Tensor, Tensor> interpolate_backward_hip(
   const ViArg via = prep_vi(vi);
   const int64_t N = a.size(0), V = a.size(1), C = a.size(2), F = vi.size(1), H = bary_img.size(2), W = bary_img.size(3);
   // interpolate_kernel.cu:657-663
-  Tensor vert_grad = vert_requires_grad ? at::empty({N, V, C}, a.options()) : Tensor();
-  Tensor bary_grad = bary_requires_grad ? at::empty({N, 3, H, W}, bary_img.options()) : Tensor();
+  Tensor vert_grad = vert_requires_grad ? out_empty({N, V, C}, a.options()) : Tensor();
+  Tensor bary_grad = bary_requires_grad ? out_empty({N, 3, H, W}, bary_img.options()) : Tensor();
   check_status(
       drtk_amd_interpolate_backward(
           dt, go_c.data_ptr(), a_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), N, V,
@@ -500,8 +520,8 @@ Tensor4 interpolation_matrix_hip(const Tensor& vi, const Tensor& index_img, cons
   const int64_t R = row_pixels.numel();
   const auto long_opts = index_img.options().dtype(at::kLong);
   auto crow = at::arange(0, R * 3 + 1, 3, long_opts);
-  auto col = at::empty({R * 3}, long_opts);
-  auto values = at::empty({R * 3}, bary_img.options());
+  auto col = out_empty({R * 3}, long_opts);
+  auto values = out_empty({R * 3}, bary_img.options());
   check_status(
       drtk_amd_interpolation_matrix(
           dt, via.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), row_pixels.data_ptr<int64_t>(), R,
@@ -521,7 +541,7 @@ Tensor interpolation_matrix_backward_hip(
   const auto rp_c = row_pixels.contiguous();
   const ViArg via = prep_vi(vi);
   const int64_t N = index_img.size(0), H = index_img.size(1), W = index_img.size(2);
-  auto bary_grad = at::empty({N, 3, H, W}, bary_img.options()); // zero-filled by the call
+  auto bary_grad = out_empty({N, 3, H, W}, bary_img.options()); // zero-filled by the call
   check_status(
       drtk_amd_interpolation_matrix_backward(
           dt, g_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), rp_c.data_ptr<int64_t>(), rp_c.numel(), N,
@@ -560,7 +580,7 @@ Tensor normal_matrix_values_hip(
   const auto idx_c = index_img.contiguous();
   const auto bary_c = bary_img.contiguous();
   const ViArg pa = prep_pairs(pair_indices);
-  auto values = at::empty({nnz}, bary_img.options()); // zero-filled by the call
+  auto values = out_empty({nnz}, bary_img.options()); // zero-filled by the call
   check_status(
       drtk_amd_interpolation_normal_matrix_values(
           dt, pa.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), index_img.size(0), pair_indices.size(1), pa.sN,
@@ -578,7 +598,7 @@ Tensor normal_matrix_values_backward_hip(
   const auto g_c = grad_values.to(bary_img.scalar_type()).contiguous();
   const ViArg pa = prep_pairs(pair_indices);
   const int64_t N = index_img.size(0), H = index_img.size(1), W = index_img.size(2);
-  auto bary_grad = N * H * W > 0 ? at::empty({N, 3, H, W}, bary_img.options()) : at::zeros({N, 3, H, W}, bary_img.options());
+  auto bary_grad = N * H * W > 0 ? out_empty({N, 3, H, W}, bary_img.options()) : at::zeros({N, 3, H, W}, bary_img.options());
   check_status(
       drtk_amd_interpolation_normal_matrix_values_backward(
           dt, g_c.data_ptr(), pa.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), N, pair_indices.size(1), pa.sN,
@@ -620,8 +640,8 @@ NormalMatrixPattern build_normal_matrix_pattern(const Tensor& vi, int64_t num_ve
   NormalMatrixPattern out;
   if (faces.numel() == 0) {
     out.crow_indices = at::zeros({num_vertices + 1}, long_opts);
-    out.col_indices = at::empty({0}, long_opts);
-    out.pair_indices = at::empty({N, F, 9}, vi.options());
+    out.col_indices = out_empty({0}, long_opts);
+    out.pair_indices = out_empty({N, F, 9}, vi.options());
     return out;
   }
   TORCH_CHECK(
@@ -1047,7 +1067,7 @@ Tensor mipmap_grid_sampler_2d_hip(
   const GridArg ga = prep_grid(grid);
   const auto vt_c = vt_dxdy_img.contiguous();
   const int64_t N = input[0].size(0), C = input[0].size(1), H = grid.size(1), W = grid.size(2);
-  auto out = at::empty({N, C, H, W}, input[0].options());
+  auto out = out_empty({N, C, H, W}, input[0].options());
   check_status(
       drtk_amd_mipmap_grid_sampler_2d(
           dt, lv.ptrs.data(), lv.h.data(), lv.w.data(), lv.sn.data(), static_cast<int>(mipmaps), ga.t.data_ptr(), ga.layout, vt_c.data_ptr(), N,
@@ -1079,7 +1099,7 @@ std::tuple<std::vector<Tensor>, Tensor> mipmap_grid_sampler_2d_backward_hip(
       offs.push_back(total);
       total += t.numel();
     }
-    const Tensor flat = at::empty({total}, input[0].options());
+    const Tensor flat = out_empty({total}, input[0].options());
     for (size_t l = 0; l < input.size(); ++l) {
       grad_input.push_back(flat.narrow(0, offs[l], input[l].numel()).view(input[l].sizes()));
       gptrs.push_back(grad_input.back().data_ptr());
@@ -1212,7 +1232,7 @@ Tensor screen_space_uv_derivative_hip(
   const auto vi_c = vi.contiguous(), vti_c = vti.contiguous(), idx_c = index_img.contiguous(), bary_c = bary_img.contiguous();
   const auto mask_c = mask.to(at::kByte).contiguous();
   const auto cp_c = campos.contiguous(), cr_c = camrot.contiguous(), f_c = focal.contiguous();
-  auto out = at::empty({N, H, W, 2, 2}, bary_img.options());
+  auto out = out_empty({N, H, W, 2, 2}, bary_img.options());
   check_status(
       drtk_amd_screen_space_uv_derivative(
           dt, v_c.data_ptr(), v_shared ? 0 : v.size(1) * 3, vt_c.data_ptr(), vt_shared ? 0 : vt.size(1) * 2,
@@ -1284,7 +1304,7 @@ Tensor edge_grad_backward_hip(
   const auto go_c = grad_outputs.to(v_pix.scalar_type()).contiguous();
   const ViArg via = prep_vi(vi);
   const int64_t N = img.size(0), C = img.size(1), H = img.size(2), W = img.size(3), V = v_pix.size(1), F = vi.size(1);
-  auto grad_v_pix_img = at::empty({N, 3, H, W}, v_pix.options()); // fully written by the call
+  auto grad_v_pix_img = out_empty({N, 3, H, W}, v_pix.options()); // fully written by the call
   size_t ws_bytes = 0;
   check_status(drtk_amd_edge_grad_backward_workspace_bytes(dt, N, H, W, &ws_bytes), "edge_grad_estimator");
   auto ws = alloc_workspace(ws_bytes, v_pix);
@@ -1382,7 +1402,7 @@ Tensor edge_grad_fused_backward_hip(
   const auto go_c = grad_outputs.to(v_pix.scalar_type()).contiguous();
   const ViArg via = prep_vi(vi);
   const int64_t N = img.size(0), C = img.size(1), H = img.size(2), W = img.size(3), V = v_pix.size(1), F = vi.size(1);
-  auto grad_v_pix = at::empty({N, V, 3}, v_pix.options()); // zero-filled by the call
+  auto grad_v_pix = out_empty({N, V, 3}, v_pix.options()); // zero-filled by the call
   size_t ws_bytes = 0;
   check_status(drtk_amd_edge_grad_backward_fused_workspace_bytes(dt, N, H, W, &ws_bytes), "edge_grad_estimator");
   auto ws = alloc_workspace(ws_bytes, v_pix);
@@ -1489,7 +1509,7 @@ Tensor transform_pinhole_hip(
   const drtk_dtype_t dt = dtype_of(v, "transform");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(v.device());
   const TransformArgs a = transform_prep(v, campos, camrot, focal, princpt);
-  auto v_pix = at::empty({a.N, a.V, 3}, v.options());
+  auto v_pix = out_empty({a.N, a.V, 3}, v.options());
   check_status(
       drtk_amd_transform_pinhole(
           dt, a.v.data_ptr(), a.v_sN, a.campos.data_ptr(), a.camrot.data_ptr(), a.focal.data_ptr(),

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# the ctypes binding pre-fills every output it allocates with NaN / sentinels (drtk_amd/capi.py _out): an element a kernel
+# forgot to write cannot pass for a value
+os.environ.setdefault("DRTK_CAPI_POISON", "1")
+
 import numpy as np
 import pytest
 import torch as th

@@ -6,6 +6,8 @@ counts around the kernels' specialisations (1..5, 15..17, 32, 33), f32/f64, shar
 triangle soups with overdraw as well as meshes."""
 import argparse
 import os
+
+os.environ.setdefault("DRTK_CAPI_POISON", "1")  # outputs of the ctypes binding pre-filled with NaN / sentinels (drtk_amd/capi.py _out)
 import sys
 
 import torch as th

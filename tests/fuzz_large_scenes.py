@@ -8,6 +8,8 @@ test_edge_grad_sign_decisions_at_near_parallel_normals_follow_the_reference pins
 usage: python tests/fuzz_large_scenes.py [--first S] [--cases K]"""
 import argparse
 import os
+
+os.environ.setdefault("DRTK_CAPI_POISON", "1")  # outputs of the ctypes binding pre-filled with NaN / sentinels (drtk_amd/capi.py _out)
 import sys
 import time
 

@@ -6,6 +6,8 @@ smooth and incoherent uv fields, footprints from magnification to beyond the coa
 padding / interpolation mode, align_corners, force_max_aniso, clip_grad."""
 import argparse
 import os
+
+os.environ.setdefault("DRTK_CAPI_POISON", "1")  # outputs of the ctypes binding pre-filled with NaN / sentinels (drtk_amd/capi.py _out)
 import sys
 
 import torch as th

@@ -6,6 +6,8 @@ step.  Forward, grid gradient and level gradients against the oracle in all padd
 usage: python tests/fuzz_mipmap_snapped.py [--cases K]"""
 import argparse
 import os
+
+os.environ.setdefault("DRTK_CAPI_POISON", "1")  # outputs of the ctypes binding pre-filled with NaN / sentinels (drtk_amd/capi.py _out)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -5,6 +5,8 @@ tests/test_gpu_mipmap.py::test_randomised_sparse_uv_and_transform_cases).  Awkwa
 per-view topology, random foreground masks and upstream gradients."""
 import argparse
 import os
+
+os.environ.setdefault("DRTK_CAPI_POISON", "1")  # outputs of the ctypes binding pre-filled with NaN / sentinels (drtk_amd/capi.py _out)
 import sys
 
 import torch as th

@@ -8,6 +8,8 @@ handling, route selection) on the awkward shapes of tests/fuzz_all_ops.py.  Self
 usage: python tests/fuzz_python_api.py [--first S] [--cases K]"""
 import argparse
 import os
+
+os.environ.setdefault("DRTK_CAPI_POISON", "1")  # outputs of the ctypes binding pre-filled with NaN / sentinels (drtk_amd/capi.py _out)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -5,6 +5,8 @@ occur (lowest id wins).  index_img and depth_img against the oracle, bit for bit
 usage: python tests/fuzz_raster_large.py [--first S] [--cases K]"""
 import argparse
 import os
+
+os.environ.setdefault("DRTK_CAPI_POISON", "1")  # outputs of the ctypes binding pre-filled with NaN / sentinels (drtk_amd/capi.py _out)
 import sys
 import time
 

@@ -5,6 +5,8 @@ pixels and the reference's on-edge / top-left rules (rasterize_kernel.cu:69-166,
 case random floats almost never produce.  usage: python tests/fuzz_snapped.py [--first S] [--cases K]"""
 import argparse
 import os
+
+os.environ.setdefault("DRTK_CAPI_POISON", "1")  # outputs of the ctypes binding pre-filled with NaN / sentinels (drtk_amd/capi.py _out)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
