@@ -804,6 +804,13 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   }
   __syncthreads();
 
+  // (tap, level) pairs that find no window cell in this round: not sent to global memory one corner and channel at a
+  // time -- scattered float atomics of single lanes, 0.72 of this kernel's 2.2 ms on the textured benchmark although
+  // only a few per cent of the taps miss -- but remembered (per level of the pixel: did any tap miss, and where) for a
+  // further round with the windows moved onto them (below, up to DRTK_MIP_ROUNDS rounds).
+  bool miss[2] = {false, false};
+  int miss_x[2] = {INT32_MAX, INT32_MAX}, miss_y[2] = {INT32_MAX, INT32_MAX};
+  uint32_t pending = 0; // bit 2 i + s: tap i on the pixel's level s found no window cell yet (taps >= 16 are never deferred)
   if (valid) {
     T acc_x = T(0), acc_y = T(0);
     // the pixel's two levels: sizes and base pointers once, not per tap
@@ -828,7 +835,6 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
         const int h = lv_h[s], w = lv_w[s];
         const int64_t plane = lv_plane[s];
         const GlobalPtr<const T> inp = lv_inp[s];
-        const GlobalPtr<T> ginp = lv_ginp[s];
         const T alpha = s == 0 ? alpha_2 : alpha_1;
         const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
         const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
@@ -869,11 +875,14 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
               lds_add(wp + c * chan + stride, static_cast<double>(q.sw * g[c]));
               lds_add(wp + c * chan + stride + 1, static_cast<double>(q.se * g[c]));
             }
+          } else if (i < 16) {
+            miss[s] = true, pending |= 1u << (2 * i + s);
+            miss_x[s] = min(miss_x[s], q.ix_nw), miss_y[s] = min(miss_y[s], q.iy_nw);
           } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               if (c >= C) break;
-              const GlobalPtr<T> gp = ginp + c * plane;
+              const GlobalPtr<T> gp = lv_ginp[s] + c * plane;
               atomic_add_g1(gp + q.o_nw, q.nw * g[c]);
               atomic_add_g1(gp + q.o_ne, q.ne * g[c]);
               atomic_add_g1(gp + q.o_sw, q.sw * g[c]);
@@ -926,6 +935,11 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
           }
         }
         if (!DRTK_DBG(dbg, 1)) {
+          const bool defer = cell < 0 && i < 16 && (q.o_nw & q.o_ne & q.o_sw & q.o_se) != -1; // (all four corners outside the level: nothing to add anywhere)
+          if (defer) {
+            miss[s] = true, pending |= 1u << (2 * i + s);
+            miss_x[s] = min(miss_x[s], q.ix_nw), miss_y[s] = min(miss_y[s], q.iy_nw);
+          }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             if (c >= C) break;
@@ -936,8 +950,8 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
               if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * g[c]));
               if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * g[c]));
               if (q.o_se >= 0) lds_add(wp + stride + 1, static_cast<double>(q.se * g[c]));
-            } else {
-              const GlobalPtr<T> gp = ginp + c * plane;
+            } else if (!defer) {
+              const GlobalPtr<T> gp = lv_ginp[s] + c * plane;
               if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * g[c]);
               if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * g[c]);
               if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * g[c]);
@@ -978,25 +992,130 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   }
   __syncthreads();
   // flush the windows: consecutive threads = consecutive texels of a row; cells that stayed 0 cost nothing,
-  // cells outside the level were never written (only in-bounds corners are accumulated)
-  for (int l = 0; l < kWinLevels; ++l) {
-    const int d = ref + l;
-    if (d >= mipmaps || s_ox[l] == INT32_MAX || DRTK_DBG(dbg, 4)) continue;
-    const int h = s_h[d], w = s_w[d];
-    const int64_t plane = int64_t(h) * w;
-    const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
-    for (int c = 0; c < C; ++c) {
-      // two cells per lane and step (one 16-byte LDS read); a row of 32 cells = 16 consecutive lanes
-      const int stride = win_stride(l), chan = win_cells(l);
-      const double2* win2 = reinterpret_cast<const double2*>(s_win + C * win_cells_before(l) + c * chan);
-      for (int i2 = tid; i2 < (chan - kWinPad) / 2; i2 += kBlock) { // the pad cells at the end of each row are never written: 0
-        const double2 q = win2[i2];
-        const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
-        const int i = i2 * 2;
-        const int gx = s_ox[l] + i % stride, gy = s_oy[l] + i / stride;
+  // cells outside the level were never written (only in-bounds corners are accumulated).  With `rearm` the cells are
+  // zeroed as they are read: the windows serve a second round.
+  auto flush = [&](int ref_level, bool rearm) {
+    for (int l = 0; l < kWinLevels; ++l) {
+      const int d = ref_level + l;
+      if (d >= mipmaps || s_ox[l] == INT32_MAX || DRTK_DBG(dbg, 4)) continue;
+      const int h = s_h[d], w = s_w[d];
+      const int64_t plane = int64_t(h) * w;
+      const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+      for (int c = 0; c < C; ++c) {
+        // two cells per lane and step (one 16-byte LDS read); a row of 32 cells = 16 consecutive lanes
+        const int stride = win_stride(l), chan = win_cells(l);
+        double2* win2 = reinterpret_cast<double2*>(s_win + C * win_cells_before(l) + c * chan);
+        for (int i2 = tid; i2 < (chan - kWinPad) / 2; i2 += kBlock) { // the pad cells at the end of each row are never written: 0
+          const double2 q = win2[i2];
+          if (rearm && (q.x != 0.0 || q.y != 0.0)) win2[i2] = double2{0.0, 0.0};
+          const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
+          const int i = i2 * 2;
+          const int gx = s_ox[l] + i % stride, gy = s_oy[l] + i / stride;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
+          for (int j = 0; j < 2; ++j) {
+            if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
+          }
+        }
+      }
+    }
+  };
+  // Does any pixel of the tile have taps the windows did not hold?  (16 % of the tiles of the minified benchmark scenes;
+  // on the textured benchmark the atlas seam -- neighbouring pixels sample opposite ends of the texture -- and the limb,
+  // where eight anisotropic taps spread over more texels than a window is wide.)  `pending` says which.
+#ifndef DRTK_MIP_ROUNDS
+#define DRTK_MIP_ROUNDS 6 // same-box A/B (textured benchmark / kernel_bench at 1 texel per pixel / at 4): 1 round (all misses to
+#endif                    // global memory, rounds 1-2) 2.15 / 4.58 / 11.7 ms; 2: 2.00 / 3.80 / 9.85; 3: 1.95 / 3.41 / 9.10; 4: 1.94 / 3.11 / 8.63; 6: 1.97 / 2.97 / 8.09
+  // ---- further rounds: the windows are moved onto the taps that are still pending and those taps alone are accumulated
+  // (texture gradient only: the grid gradient is complete).  What is still pending after the last round -- a region of
+  // the texture or a level too many -- goes to global memory corner by corner, as all misses did before.
+  int ref_now = ref;
+  for (int round = 1;; ++round) {
+    const bool again = __syncthreads_or(pending != 0) && !DRTK_DBG(dbg, 8);
+    flush(ref_now, again);
+    if (!again) return;
+    const bool last = round >= DRTK_MIP_ROUNDS - 1;
+    __syncthreads(); // everybody has finished its flush (it reads the origins)
+    if (tid == 0) s_ref = kMaxLevels;
+    if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
+    __syncthreads();
+    {
+      const int d_min = wave_min_i32(miss[0] ? t.d1 : miss[1] ? t.d1 + 1 : kMaxLevels);
+      if ((tid & (kWave - 1)) == 0) atomicMin(&s_ref, d_min);
+    }
+    __syncthreads();
+    ref_now = s_ref;
+    {
+      int lo_x[kWinLevels], lo_y[kWinLevels];
+#pragma unroll
+      for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int l = t.d1 + s2 - ref_now;
+#pragma unroll
+        for (int k = 0; k < kWinLevels; ++k) {
+          if (miss[s2] && k == l) lo_x[k] = min(lo_x[k], miss_x[s2]), lo_y[k] = min(lo_y[k], miss_y[s2]);
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < kWinLevels; ++l) {
+        const int a = wave_min_i32(lo_x[l]), b = wave_min_i32(lo_y[l]);
+        if ((tid & (kWave - 1)) == 0 && a != INT32_MAX) {
+          atomicMin(&s_ox[l], a);
+          atomicMin(&s_oy[l], b);
+        }
+      }
+    }
+    __syncthreads();
+    miss[0] = miss[1] = false;
+    miss_x[0] = miss_x[1] = miss_y[0] = miss_y[1] = INT32_MAX;
+    if (pending != 0) {
+      uint32_t todo = pending;
+      while (todo) {
+        const int bit = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int i = bit >> 1, s2 = bit & 1;
+        T x, y;
+        tap_xy(i, x, y);
+        const int d = t.d1 + s2;
+        const int h = s_h[d], w = s_w[d];
+        const int64_t plane = int64_t(h) * w;
+        const T alpha = s2 == 0 ? alpha_2 : alpha_1;
+        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
+        const int l = d - ref_now;
+        int cell = -1;
+        const int side = win_side(l), stride = win_stride(l), chan = win_cells(l);
+        if (l >= 0 && l < kWinLevels) {
+          const int wx = q.ix_nw - s_ox[l], wy = q.iy_nw - s_oy[l];
+          if (wx >= 0 && wx < side - 1 && wy >= 0 && wy < side - 1) cell = wy * stride + wx;
+        }
+        if (cell < 0 && !last) { // stays pending: the next round's windows
+          if (s2 == 0) {
+            miss[0] = true, miss_x[0] = min(miss_x[0], q.ix_nw), miss_y[0] = min(miss_y[0], q.iy_nw);
+          } else {
+            miss[1] = true, miss_x[1] = min(miss_x[1], q.ix_nw), miss_y[1] = min(miss_y[1], q.iy_nw);
+          }
+          continue;
+        }
+        pending &= ~(1u << bit);
+        const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c >= C) break;
+          const T gc = go[c] * alpha;
+          if (gc == T(0)) continue;
+          if (cell >= 0) {
+            double* wp = s_win + C * win_cells_before(l) + c * chan + cell;
+            if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * gc));
+            if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * gc));
+            if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * gc));
+            if (q.o_se >= 0) lds_add(wp + stride + 1, static_cast<double>(q.se * gc));
+          } else {
+            const GlobalPtr<T> gp = ginp + c * plane;
+            if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * gc);
+            if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * gc);
+            if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * gc);
+            if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gc);
+          }
         }
       }
     }
