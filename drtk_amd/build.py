@@ -42,8 +42,31 @@ def _run(cmd):
     return r.stdout
 
 
-def _newer(target, deps):
-    return os.path.isfile(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
+def _digest(deps, extra=""):
+    import hashlib
+
+    h = hashlib.sha256(extra.encode())
+    for d in sorted(deps):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _newer(target, deps, extra=""):
+    """Is `target` the build of exactly these sources?  Decided by CONTENT, not by time stamps: the libraries travel
+    prebuilt (to the GPU box, between checkouts), where modification times mean nothing -- a sidecar `<target>.src`
+    holds the SHA-256 of the sources (and flags) the library was built from."""
+    side = target + ".src"
+    if not (os.path.isfile(target) and os.path.isfile(side) and all(os.path.isfile(d) for d in deps)):
+        return False
+    with open(side) as f:
+        return f.read().strip() == _digest(deps, extra)
+
+
+def _stamp(target, deps, extra=""):
+    with open(target + ".src", "w") as f:
+        f.write(_digest(deps, extra) + "\n")
 
 
 def check_no_vgpr_spills(compiler_output, what):
@@ -68,7 +91,7 @@ def check_no_vgpr_spills(compiler_output, what):
 
 def build_kernels(force=False, verbose=True):
     deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
-    if not force and _newer(LIB, deps):
+    if not force and _newer(LIB, deps, " ".join(HIP_FLAGS)):
         return LIB
     objs, cmds = [], []
     for s in KERNEL_SRCS:
@@ -83,6 +106,7 @@ def build_kernels(force=False, verbose=True):
     _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
     for o in objs:
         os.remove(o)
+    _stamp(LIB, deps, " ".join(HIP_FLAGS))
     if verbose:
         msg = "".join(outs).strip()
         print(f"[drtk_amd] built {LIB}" + (("\n" + msg) if msg else ""))
@@ -97,7 +121,7 @@ def build_ablation(force=False, verbose=True):
     and `drtk_amd_debug_set_flags` (csrc/common.hpp).  A profiling tool's library (profiles/kernel_bench.py
     --flags ...); it lives outside the package, the product never loads it and build_all() does not build it."""
     deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
-    if not force and _newer(ABLATE_LIB, deps):
+    if not force and _newer(ABLATE_LIB, deps, "ablation"):
         return ABLATE_LIB
     objs, cmds = [], []
     for s in KERNEL_SRCS:
@@ -109,6 +133,7 @@ def build_ablation(force=False, verbose=True):
     _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", ABLATE_LIB, *objs])
     for o in objs:
         os.remove(o)
+    _stamp(ABLATE_LIB, deps, "ablation")
     if verbose:
         print(f"[drtk_amd] built {ABLATE_LIB}")
     return ABLATE_LIB
@@ -137,7 +162,7 @@ def build_torch_ops(force=False, verbose=True):
     from torch.utils import cpp_extension as ce
 
     src = os.path.join(CSRC, "torch_ops.cpp")
-    deps = [src, os.path.join(INC, "drtk_amd.h"), LIB, __file__]
+    deps = [src, os.path.join(INC, "drtk_amd.h"), LIB + ".src", __file__]
     if not force and _newer(OPS, deps):
         return OPS
     libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
@@ -150,6 +175,7 @@ def build_torch_ops(force=False, verbose=True):
         "-lc10", "-ltorch_hip", "-lc10_hip", f"-Wl,-rpath,{libdir}",
     ]
     out = _run(cmd)
+    _stamp(OPS, deps)
     if verbose:
         print(f"[drtk_amd] built {OPS}" + (("\n" + out.strip()) if out.strip() else ""))
     return OPS
@@ -169,13 +195,14 @@ def build_ext_modules(force=False, verbose=True):
     for name in EXT_NAMES:
         so = os.path.join(SHIM, name + ".so")
         outs.append(so)
-        if not force and _newer(so, [src, OPS, __file__]):
+        if not force and _newer(so, [src, OPS + ".src", __file__], name):
             continue
         _run([
             os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", f"-DDRTK_EXT_NAME={name}",
             f"-I{sysconfig.get_paths()['include']}", src, "-o", so, "-Wl,--no-as-needed", f"-L{PKG}",
             "-l:drtk_amd_torch_ops.so", "-Wl,-rpath,$ORIGIN/../drtk_amd",
         ])
+        _stamp(so, [src, OPS + ".src", __file__], name)
         if verbose:
             print(f"[drtk_amd] built {so}")
     return outs
@@ -188,19 +215,18 @@ def build_all(force=False, verbose=True):
     return LIB, OPS
 
 
-def _state(target, deps):
+def _state(target, deps, extra=""):
     if not os.path.isfile(target):
         return "missing"
-    present = [d for d in deps if os.path.isfile(d)]
-    return "up to date" if len(present) == len(deps) and _newer(target, deps) else "stale"
+    return "up to date" if _newer(target, deps, extra) else "stale"
 
 
 def dry_run():
     """What build_all() would do, without compiling anything."""
     kdeps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
-    odeps = [os.path.join(CSRC, "torch_ops.cpp"), os.path.join(INC, "drtk_amd.h"), LIB, __file__]
-    for target, deps in ((LIB, kdeps), (OPS, odeps)):
-        print(f"[drtk_amd] {target}: {_state(target, deps)}")
+    odeps = [os.path.join(CSRC, "torch_ops.cpp"), os.path.join(INC, "drtk_amd.h"), LIB + ".src", __file__]
+    for target, deps, extra in ((LIB, kdeps, " ".join(HIP_FLAGS)), (OPS, odeps, "")):
+        print(f"[drtk_amd] {target}: {_state(target, deps, extra)}")
 
 
 if __name__ == "__main__":
