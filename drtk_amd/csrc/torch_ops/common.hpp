@@ -1,0 +1,92 @@
+// Shared host-side helpers of the torch-operator shim (csrc/torch_ops/*.cpp): dtype / stream / status plumbing between
+// at::Tensor and the C ABI of include/drtk_amd.h, the stride-0 `vi` broadcast, output allocation (optionally poisoned).
+#pragma once
+#include <cstdlib>
+#include <limits>
+#include <ATen/ATen.h>
+#include <ATen/autocast_mode.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/library.h>
+
+#include <array>
+#include <list>
+#include <mutex>
+#include <unordered_map>
+
+#include "drtk_amd.h"
+
+namespace drtk_amd_torch {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::tensor_list;
+
+inline drtk_dtype_t dtype_of(const Tensor& t, const char* op) {
+  switch (t.scalar_type()) {
+    case at::kFloat:
+      return DRTK_F32;
+    case at::kDouble:
+      return DRTK_F64;
+    default:
+      // src/include/kernel_utils.h:35-57 : float and double only
+      TORCH_CHECK(false, "\"", op, "\" not implemented for '", toString(t.scalar_type()), "'");
+  }
+}
+
+inline drtk_stream_t current_stream(const Tensor& t) {
+  return static_cast<drtk_stream_t>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
+
+inline void check_status(int status, const char* op) {
+  TORCH_CHECK(status == DRTK_OK, op, "(): ", drtk_amd_status_string(status), " [drtk_amd status ", status, "]");
+}
+
+// vi arrives as [N,F,3]; the Python wrappers build it with a stride-0 expand from [F,3]
+// (drtk/rasterize.py:61-62).  Keep that broadcast instead of materialising N copies.
+struct ViArg {
+  Tensor holder;
+  const int32_t* ptr;
+  int64_t sN;
+};
+inline ViArg prep_vi(const Tensor& vi) {
+  ViArg a;
+  if (vi.size(0) > 1 && vi.stride(0) == 0) {
+    a.holder = vi.select(0, 0).contiguous();
+    a.sN = 0;
+  } else {
+    a.holder = vi.contiguous();
+    a.sN = vi.size(1) * 3;
+  }
+  a.ptr = a.holder.data_ptr<int32_t>();
+  return a;
+}
+
+// Output allocation of the shim: uninitialised memory, or -- with DRTK_CAPI_POISON=1 in the environment, which the test
+// suite and the fuzzers set -- memory pre-filled with NaN / a large negative integer / 0xA5 bytes, so that an element a
+// kernel forgot to write cannot pass for a value (freshly allocated device memory reads as zeros, a plausible image:
+// DESIGN.md 3.1, round 3).  The product never pays for it: one getenv at load time.
+inline const bool g_poison_outputs = [] {
+  const char* e = std::getenv("DRTK_CAPI_POISON");
+  return e && e[0] && !(e[0] == '0' && !e[1]);
+}();
+inline Tensor out_empty(at::IntArrayRef sizes, const at::TensorOptions& opts) {
+  Tensor t = at::empty(sizes, opts);
+  if (g_poison_outputs && t.numel() > 0) {
+    if (at::isFloatingType(t.scalar_type())) t.fill_(std::numeric_limits<double>::quiet_NaN());
+    else if (t.scalar_type() == at::kByte) t.fill_(0xA5);
+    else t.fill_(-(1 << 30) - 7);
+  }
+  return t;
+}
+
+inline Tensor alloc_workspace(size_t bytes, const Tensor& like) {
+  return out_empty({static_cast<int64_t>(bytes)}, like.options().dtype(at::kByte));
+}
+
+[[noreturn]] inline void no_cpu(const char* op) {
+  TORCH_CHECK(false, op, "(): drtk_amd implements the MI355X (HIP) path only; got CPU tensors");
+}
+
+} // namespace drtk_amd_torch

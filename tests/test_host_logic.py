@@ -31,8 +31,10 @@ def test_c_abi_exports_every_declared_symbol():
     exported = sorted(set(re.findall(r" T (drtk_amd_\w+)", syms)))
     assert exported == declared, set(exported) ^ set(declared)
     assert "debug" not in syms
-    for f in os.listdir(os.path.join(ROOT, "drtk_amd", "csrc")):
-        src = open(os.path.join(ROOT, "drtk_amd", "csrc", f)).read()
+    csrc = os.path.join(ROOT, "drtk_amd", "csrc")
+    for path in [os.path.join(d, f) for d, _, files in os.walk(csrc) for f in files]:
+        f = os.path.relpath(path, csrc)
+        src = open(path).read()
         assert not re.search(r"\bdbg\s*&|debug_flags\(\)\s*(&|>>)", src.replace("debug_flags() >> 10", "")) , f"{f}: phase switch outside DRTK_DBG()"
     assert b"gfx950" in capi.lib().drtk_amd_version()
     assert capi.lib().drtk_amd_status_string(0) == b"ok"
@@ -545,7 +547,7 @@ print(drtk.__file__); print("ok")
 
 
 def test_sampler_inputs_that_are_read_in_place_and_those_that_are_copied():
-    """Host logic of the sampler's strided inputs (capi._grid_layout / _level_table; torch_ops.cpp's prep_grid /
+    """Host logic of the sampler's strided inputs (capi._grid_layout / _level_table; csrc/torch_ops/mipmap.cpp's prep_grid /
     prep_levels decide the same way): which layouts go to the kernels as they are, with which strides, and which are
     made contiguous first."""
     from drtk_amd import capi
