@@ -39,18 +39,28 @@ __device__ __forceinline__ T quotient(T a, T b) {
   }
 }
 
+template <typename T>
+struct TriVerts { // the three pixel-space vertices of one triangle
+  T p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z;
+};
+
+template <typename T>
+__device__ __forceinline__ TriVerts<T> load_tri_verts(const T* __restrict__ v_n, int32_t vi0, int32_t vi1, int32_t vi2) {
+  const T* q0 = v_n + 3 * (int64_t)vi0;
+  const T* q1 = v_n + 3 * (int64_t)vi1;
+  const T* q2 = v_n + 3 * (int64_t)vi2;
+  return TriVerts<T>{q0[0], q0[1], q0[2], q1[0], q1[1], q1[2], q2[0], q2[1], q2[2]};
+}
+
 template <typename T, bool EXACT = true>
-__device__ __forceinline__ void render_pix(
-    const T* __restrict__ v_n, int32_t vi0, int32_t vi1, int32_t vi2, int x, int y, RenderPix<T>& r) {
+__device__ __forceinline__ void render_math(
+    const TriVerts<T>& q, int32_t vi0, int32_t vi1, int32_t vi2, int x, int y, RenderPix<T>& r) {
   r.vi0 = vi0;
   r.vi1 = vi1;
   r.vi2 = vi2;
-  const T* q0 = v_n + 3 * (int64_t)r.vi0;
-  const T* q1 = v_n + 3 * (int64_t)r.vi1;
-  const T* q2 = v_n + 3 * (int64_t)r.vi2;
-  const T p0x = q0[0], p0y = q0[1], p0z = q0[2];
-  const T p1x = q1[0], p1y = q1[1], p1z = q1[2];
-  const T p2x = q2[0], p2y = q2[1], p2z = q2[2];
+  const T p0x = q.p0x, p0y = q.p0y, p0z = q.p0z;
+  const T p1x = q.p1x, p1y = q.p1y, p1z = q.p1z;
+  const T p2x = q.p2x, p2y = q.p2y, p2z = q.p2z;
   r.v01x = p1x - p0x;
   r.v01y = p1y - p0y;
   r.v02x = p2x - p0x;
@@ -76,6 +86,12 @@ __device__ __forceinline__ void render_pix(
   r.depth_inverse = r.dinv0 * r.b0 + r.dinv1 * r.b1 + r.dinv2 * r.b2;
   r.depth_inverse_eps = epsclamp(r.depth_inverse);
   r.depth = quotient<EXACT>(T(1.0), r.depth_inverse_eps);
+}
+
+template <typename T, bool EXACT = true>
+__device__ __forceinline__ void render_pix(
+    const T* __restrict__ v_n, int32_t vi0, int32_t vi1, int32_t vi2, int x, int y, RenderPix<T>& r) {
+  render_math<T, EXACT>(load_tri_verts<T>(v_n, vi0, vi1, vi2), vi0, vi1, vi2, x, y, r);
 }
 
 template <typename T>
@@ -117,20 +133,48 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
   const int y = static_cast<int>(pix0 / W);
   const int x0 = static_cast<int>(pix0 - int64_t(y) * W);
 
-  T d[VEC], b0[VEC], b1[VEC], b2[VEC];
+  // Every memory round trip of the lane's VEC pixels is issued as ONE batch -- the faces of all of them, then their nine
+  // vertices -- instead of one `if (covered) { face -> vertices -> arithmetic }` block per pixel: a conditional load
+  // compiles to a branch with its own s_waitcnt, i.e. 2 VEC dependent round trips per lane after the index load
+  // (0.166 -> 0.157 ms at the benchmark shape, same box).  To make the loads unconditional a background pixel reads the
+  // triangle of a covered pixel of its lane, or of its wave (its results are discarded); a wave with no covered pixel
+  // stores zeros.  Measured on top of this and NOT kept: the six IEEE divisions per pixel (11 instructions each)
+  // replaced by the rasterizer's correctly rounded fast forms (hardware reciprocal + Markstein corrections, one
+  // wave-uniform IEEE fallback) -- bit-identical, a third fewer instructions, and no faster: 0.166 ms, the registers of
+  // the second code path take the kernel from 8 to 6 waves per SIMD and the kernel is bound by latency, not by issue.
+  bool fg[VEC];
+  int32_t sub = -1;
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    if (tr[j] != -1) {
-      RenderPix<T> r;
-      const int32_t* face = vi_n + int64_t(tr[j]) * 3;
-      render_pix<T>(v_n, face[0], face[1], face[2], x0 + j, y, r);
-      b0[j] = r.dinv0 * r.b0 * r.depth;
-      b1[j] = r.dinv1 * r.b1 * r.depth;
-      b2[j] = r.dinv2 * r.b2 * r.depth;
-      d[j] = r.depth;
-    } else {
-      b0[j] = b1[j] = b2[j] = d[j] = T(0);
+  for (int j = VEC - 1; j >= 0; --j) {
+    fg[j] = tr[j] != -1;
+    sub = fg[j] ? tr[j] : sub;
+  }
+  const unsigned long long any = __ballot(sub != -1);
+  T d[VEC], b0[VEC], b1[VEC], b2[VEC];
+  if (any != 0) {
+    const int32_t wave_sub = __builtin_amdgcn_readlane(sub, __builtin_amdgcn_readfirstlane(__builtin_ctzll(any)));
+    if (sub == -1) sub = wave_sub;
+    int32_t f0[VEC], f1[VEC], f2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int32_t* face = vi_n + int64_t(fg[j] ? tr[j] : sub) * 3;
+      f0[j] = face[0], f1[j] = face[1], f2[j] = face[2];
     }
+    TriVerts<T> q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) q[j] = load_tri_verts<T>(v_n, f0[j], f1[j], f2[j]);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      RenderPix<T> r;
+      render_math<T>(q[j], f0[j], f1[j], f2[j], x0 + j, y, r);
+      b0[j] = fg[j] ? r.dinv0 * r.b0 * r.depth : T(0);
+      b1[j] = fg[j] ? r.dinv1 * r.b1 * r.depth : T(0);
+      b2[j] = fg[j] ? r.dinv2 * r.b2 * r.depth : T(0);
+      d[j] = fg[j] ? r.depth : T(0);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) b0[j] = b1[j] = b2[j] = d[j] = T(0);
   }
   if constexpr (VEC == 4) {
     using V4 = typename Vec4<T>::type;

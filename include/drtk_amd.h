@@ -5,7 +5,7 @@
  * dispatcher, whose CUDA-key implementations are the C++ host launchers cited on every entry
  * below.  Each function here replaces exactly one of those launchers (same inputs, outputs and
  * semantics, contiguous layouts, raw device pointers, an explicit HIP stream) so that the
- * torch-op shim (drtk_amd/csrc/torch_ops/*.cpp), a ctypes caller or a C program can all drive the
+ * torch-op shim (drtk_amd/csrc/torch_ops/<op>.cpp), a ctypes caller or a C program can all drive the
  * same kernels.  INTEGRATION.md shows the binding a reference maintainer would add.
  *
  * Conventions
