@@ -141,7 +141,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
   // stores zeros.  Measured on top of this and NOT kept: the six IEEE divisions per pixel (11 instructions each)
   // replaced by the rasterizer's correctly rounded fast forms (hardware reciprocal + Markstein corrections, one
   // wave-uniform IEEE fallback) -- bit-identical, a third fewer instructions, and no faster: 0.166 ms, the registers of
-  // the second code path take the kernel from 8 to 6 waves per SIMD and the kernel is bound by latency, not by issue.
+  // the second code path take the kernel from 8 to 6 waves per SIMD; and fetching a triangle only where it differs from
+  // the previous pixel's (a third of the gathers, but one conditional block per pixel again): 0.160 ms = the old kernel.
+  // 0.150-0.155 ms is 20 B/px at 4.4-4.5 TB/s: the kernel sits at what a mixed read/write stream reaches here.
   bool fg[VEC];
   int32_t sub = -1;
 #pragma unroll
