@@ -637,7 +637,17 @@ __device__ __forceinline__ int wave_max_i32(int v) {
              max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-constexpr int kTileW = 16;  // pixel tile
+// Pixel tile: kTileW x kTileH pixels, one thread each.  16 x 16 is a sweet spot, same-box A/B on the textured benchmark /
+// kernel_bench at 1 and 4 texels per pixel: 16 x 32 (8 waves per workgroup over the same 48 KB of windows, twice the
+// waves per CU) 3.11 / 4.61 / 10.8 ms against 1.94 / 2.99 / 8.13 -- the taller tile's taps spread over more texels than a
+// window holds, and its misses cost rounds; 16 x 8: 2.9 ms -- the per-tile costs (window init + flush scan, five
+// barriers) are paid twice as often.
+constexpr int kTileW = 16;
+#ifndef DRTK_MIP_TILE_H
+#define DRTK_MIP_TILE_H 16
+#endif
+constexpr int kTileH = DRTK_MIP_TILE_H;
+constexpr int kMipBlock = kTileW * kTileH;
 #ifndef DRTK_MIP_WIN
 #define DRTK_MIP_WIN 32
 #endif
@@ -676,7 +686,7 @@ constexpr int kWinCells = win_cells_before(kWinLevels);
 // PAD / ALIGN: padding mode and align_corners as compile-time constants (the coordinate pipeline of every tap branches on
 // them: SQ counters of the runtime-parameter version showed 490 scalar and 950 vector instructions per wave).
 template <typename T, int PAD, bool ALIGN>
-__global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
+__global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
     const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   const int n = blockIdx.y;
   const int tile = tile_index(strip);
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileW + tid / kTileW;
+  const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileH + tid / kTileW;
   const bool valid = px < W && py < H;
   const int64_t HW = int64_t(H) * W;
   const int64_t index = int64_t(n) * HW + int64_t(py) * W + px;
@@ -729,7 +739,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
   {
     double2* w2 = reinterpret_cast<double2*>(s_win);
     const double2 z = {0.0, 0.0};
-    for (int i = tid; i < C * kWinCells / 2; i += kBlock) w2[i] = z;
+    for (int i = tid; i < C * kWinCells / 2; i += kMipBlock) w2[i] = z;
   }
   __syncthreads();
 
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_tiled_kernel(
         // two cells per lane and step (one 16-byte LDS read); a row of 32 cells = 16 consecutive lanes
         const int stride = win_stride(l), chan = win_cells(l);
         double2* win2 = reinterpret_cast<double2*>(s_win + C * win_cells_before(l) + c * chan);
-        for (int i2 = tid; i2 < (chan - kWinPad) / 2; i2 += kBlock) { // the pad cells at the end of each row are never written: 0
+        for (int i2 = tid; i2 < (chan - kWinPad) / 2; i2 += kMipBlock) { // the pad cells at the end of each row are never written: 0
           const double2 q = win2[i2];
           if (rearm && (q.x != 0.0 || q.y != 0.0)) win2[i2] = double2{0.0, 0.0};
           const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
@@ -1229,11 +1239,11 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   if (make_grid_layout(gl, grid_layout, grid, H, W, es) != DRTK_OK || make_grid_layout(ggl, grad_grid_layout, grad_grid, H, W, es) != DRTK_OK)
     return DRTK_ERR_INVALID_ARGUMENT;
   if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
-    const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileW));
+    const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
 #define TILED(PAD, ALIGN)                                                                                                \
   DRTK_LAUNCH(                                                                                                           \
       (mipmap_backward_tiled_kernel<float, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
-      dim3(kBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const float*>(grad_out),                 \
+      dim3(kMipBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const float*>(grad_out),              \
       static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
       force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
     if (align_corners) {
