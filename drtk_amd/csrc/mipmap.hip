@@ -363,6 +363,10 @@ template <typename T>
 using Pair = typename PairOf<T>::type;
 
 constexpr int kChBlock = 4; // channels accumulated in registers per sweep over the taps
+// (Round 3, measured and not kept: the bilinear forward's taps in groups of 2 or 4 -- geometry of the group first, the
+// texel loads of its interior (tap, level) pairs in flight together, products in tap order, bit-identical -- to cut the
+// per-pixel chain quad -> texels -> products -> next tap: 2.01 / 2.09 ms against 0.76 on the textured benchmark.  The
+// group's quads and texels take the kernel from 110 to 258 / 434 registers, and this kernel lives on occupancy.)
 
 // PAD: the padding mode as a compile-time constant (see mipmap_backward_tiled_kernel).
 template <typename T, int MODE, int PAD>
