@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--cpu-sample-views", type=int, default=None, help="views timed on the CPU (0 = skip)")
     ap.add_argument("--kernel-steps", type=int, default=5, help="extra steps run under the per-kernel HIP-event timing")
     ap.add_argument("--no-graph", action="store_true", help="skip the captured-graph timing of the same step")
+    ap.add_argument("--reduce-after-backward", action="store_true",
+                    help="N > 1: ONE all-reduce of all shared gradients after the backward pass instead of one per shared tensor launched from inside it (A/B of the overlap)")
     ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)  # internal: this process only captures + replays the step
     a = ap.parse_args()
     if a.workload == "textured" and a.config == 3:
@@ -266,6 +268,15 @@ class _MeanSquare(th.autograd.Function):
         return x * (g * (2.0 / x.numel()))
 
 
+_JSON_FD = 1  # main() replaces it by a private duplicate of the real stdout
+
+
+def emit_line(obj):
+    """The one JSON line of this process, on the REAL stdout (see main(): descriptor 1 itself is pointed at stderr)."""
+    sys.stdout.flush()
+    os.write(_JSON_FD, (json.dumps(obj) + "\n").encode())
+
+
 def timed_loop(step, steps, dev, world):
     """The contract's timing: barrier + synchronize, EXACTLY `steps` steps, barrier + synchronize, wall clock, MAX over
     ranks.  Beside it every step is bracketed by a pair of HIP events on the stream the step runs on (hipEvent,
@@ -315,19 +326,30 @@ def graph_child(step, leaves, steps, pixels):
         g.replay()
     th.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({
+    emit_line({
         "value": round(pixels * steps / el / 1e6, 2), "ms_per_step": round(el / steps * 1e3, 4), "loss": round(float(g_loss.detach()), 6),
         "note": "the identical step captured with torch.cuda.graph and replayed (same kernels, no host launch / autograd bookkeeping "
-                "between them), in a child process; reported beside the eager headline, never as `value`"}), flush=True)
+                "between them), in a child process; reported beside the eager headline, never as `value`"})
 
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL 2.26 prints a five-line version banner to
+    # file descriptor 1 when its communicator is created, on every rank -- so descriptor 1 is pointed at stderr for the
+    # whole run and the line goes out through a private duplicate of the real stdout.
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     from drtk_amd import dist as ddist
     from drtk_amd import synthetic as S
     from drtk_amd.transform import transform
 
-    rank, world, local_rank = ddist.init_from_env()
+    # DRTK_SINGLE_RANK_GROUP: test-only -- a ONE-rank process group, so that the multi-rank code path (reducers, the max over
+    # ranks, the all_reduce block of the line) runs against RCCL on a one-GPU box (tests/test_gpu_bench_contract.py)
+    single_rank_group = os.environ.get("DRTK_SINGLE_RANK_GROUP") == "1"
+    rank, world, local_rank = ddist.init_from_env(single_rank_group=single_rank_group)
+    grouped = world > 1 or single_rank_group
     if args.gpus != world:
         # Never re-exec or spawn from here: say how to launch instead (a mislabelled n_gpus would poison a scaling curve).
         raise SystemExit(
@@ -360,12 +382,14 @@ def main():
         tex = [t.half().requires_grad_(True) for t in S.texture_pyramid(1, 3, args.tex, device=dev)]  # shared fp16 texture pyramid
         # two collectives per step: the fp16 leaves (uv attributes + every mip level) as ONE group staged in float32 --
         # their gradients are accumulated, summed over the ranks and only then rounded to fp16 -- and the vertices
-        reducers = [ddist.SharedGradReducer([v_world, [vt] + tex], dtype=th.float32)]
+        reducers = [ddist.SharedGradReducer([v_world, [vt] + tex], dtype=th.float32, overlap=not args.reduce_after_backward)]
     else:
         attr = S.random_attributes(1, v_world.shape[0], C, seed=0, device=dev)[:1].contiguous()
         attr = attr.clone().requires_grad_(True)        # shared across views and ranks
-        reducers = [ddist.SharedGradReducer([v_world, attr])]
+        reducers = [ddist.SharedGradReducer([v_world, attr], overlap=not args.reduce_after_backward)]
 
+    for r in reducers:
+        r.run_single_rank = single_rank_group
     leaves = [p for r in reducers for p in r.params]
 
     def step(fused_mask=False, reduce=True):
@@ -408,12 +432,12 @@ def main():
         return graph_child(step, leaves, args.steps, n_total * H * W)
     for _ in range(args.warmup):
         step()
-    elapsed, loss = timed_loop(step, args.steps, dev, world)
+    elapsed, loss = timed_loop(step, args.steps, dev, 2 if grouped else 1)
     median_step_ms = timed_loop.last_median_ms
     ms_per_step = elapsed / args.steps * 1e3
     mpix = n_total * H * W * args.steps / elapsed / 1e6
     comm = None
-    if world > 1:
+    if grouped:
         per = [r.timings_ms() for r in reducers]
         if all(t is not None for t in per):
             comm = (sum(t[0] for t in per), sum(t[1] for t in per))
@@ -469,7 +493,7 @@ def main():
     # Measured in a fresh CHILD process (started here, never exec'ed over this one) while this process idles: a capture
     # that goes wrong takes down the process it runs in, and the headline must not depend on it.
     graph = None
-    if world == 1 and not args.no_graph:
+    if world == 1 and not grouped and not args.no_graph:
         import subprocess
 
         th.cuda.synchronize()
@@ -652,8 +676,8 @@ def main():
             "path_roofline": path,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        emit_line(result)
+    if grouped:
         th.distributed.barrier()
         th.distributed.destroy_process_group()
 

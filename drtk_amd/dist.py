@@ -19,13 +19,14 @@ import torch as th
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False) -> Tuple[int, int, int]:
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (as set by
-    torch.distributed.run).  Returns (rank, world_size, local_rank); a no-op for world size 1."""
+    torch.distributed.run).  Returns (rank, world_size, local_rank); a no-op for world size 1 unless
+    `single_rank_group` asks for a one-rank process group (tests/test_gpu_rccl_single_rank.py: RCCL on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         if backend is None:
             # DRTK_DIST_BACKEND=gloo lets the multi-rank code path be exercised on a single-GPU box
             backend = os.environ.get("DRTK_DIST_BACKEND") or ("nccl" if th.cuda.is_available() else "gloo")
@@ -143,6 +144,9 @@ class SharedGradReducer:
         self._staged_dirty = False  # staged segments still hold the last round's reduced sums (readable until the next round)
         self._wait_events = None
         self.enabled = True  # False: hooks and finish() do nothing (a rank stepping on its own, e.g. for profiling)
+        # True: a process group of ONE rank still issues its collectives (the sum over one rank is the identity) -- how
+        # tests/test_gpu_rccl_single_rank.py runs the real call sequence against RCCL on a one-GPU box
+        self.run_single_rank = False
         for i, p in enumerate(self.params):
             self._handles.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_leaf_grad(i)))
         self.zero_grad()
@@ -154,7 +158,7 @@ class SharedGradReducer:
         return len(self.group_members) if self.overlap else 1
 
     def _active(self) -> bool:
-        return self.enabled and dist.is_initialized() and dist.get_world_size() > 1
+        return self.enabled and dist.is_initialized() and (dist.get_world_size() > 1 or self.run_single_rank)
 
     def upcast(self, p: th.Tensor) -> th.Tensor:
         """`p` in the buffer's dtype for use in the forward pass.  For a staged parameter (stored in another dtype) the

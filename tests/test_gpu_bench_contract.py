@@ -32,8 +32,10 @@ def _run(cmd, extra_env=None):
     env.update(extra_env or {})
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert r.returncode == 0, f"{' '.join(cmd)} exited {r.returncode}\n{r.stderr[-3000:]}"
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}:\n{r.stdout[-2000:]}"
+    # stdout carries the JSON line and NOTHING else (RCCL's version banner, printed to descriptor 1 when a communicator is
+    # created, used to land here: bench.py points descriptor 1 at stderr and writes its line to a duplicate of the real one)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), f"expected ONE JSON line and nothing else on stdout, got {len(lines)}:\n{r.stdout[-2000:]}"
     return json.loads(lines[0])
 
 
@@ -122,4 +124,18 @@ def test_two_ranks_under_torch_distributed_run():
     ar = d["all_reduce"]
     assert ar["bytes"] == 4 * d["config"]["vertices"] * (3 + d["config"]["channels"]) and ar["collectives_per_step"] == 2
     assert ar["staging_dtype"] == "float32"
+    assert ar["ms_launch_to_done"] > 0 and ar["ms_exposed_on_main_stream"] >= 0
+
+
+def test_one_rank_process_group_over_rccl():
+    """The multi-rank code path of bench.py -- reducers launched from the backward pass, the max over ranks of the timing,
+    the all_reduce block of the line, barrier and teardown -- against RCCL itself (backend "nccl"), which the two-rank
+    gloo leg above cannot reach on a one-GPU box: a process group of ONE rank (DRTK_SINGLE_RANK_GROUP, test-only)."""
+    env = {"DRTK_SINGLE_RANK_GROUP": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+           "MASTER_PORT": str(_free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0", "DRTK_DIST_BACKEND": ""}
+    d = _run([sys.executable, "bench.py", "--gpus", "1", *SMALL, "--no-graph", "--cpu-sample-views", "0"], env)
+    _check_common(d, 1)
+    ar = d["all_reduce"]
+    assert ar is not None and ar["collectives_per_step"] == 2 and ar["staging_dtype"] == "float32"
+    assert ar["bytes"] == 4 * d["config"]["vertices"] * (3 + d["config"]["channels"])
     assert ar["ms_launch_to_done"] > 0 and ar["ms_exposed_on_main_stream"] >= 0
