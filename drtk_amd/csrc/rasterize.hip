@@ -928,7 +928,10 @@ __device__ __forceinline__ void raster_rows(
 #ifndef DRTK_RASTER_WAVES_PER_SIMD
 #define DRTK_RASTER_WAVES_PER_SIMD 6
 #endif
-constexpr int kRasterBlock = 512;
+#ifndef DRTK_RASTER_BLOCK
+#define DRTK_RASTER_BLOCK 512 // 256 (4 waves per item, 4 items per CU by LDS; DRTK_RASTER_BLOCKS_PER_CU=4): 0.305 / 0.375 ms against
+#endif                        // 0.305 / 0.36 at 100k / 250k triangles -- a wave-group holds ~3.4 triangles either way
+constexpr int kRasterBlock = DRTK_RASTER_BLOCK;
 constexpr int kRasterWaves = kRasterBlock / kWave;
 template <typename T>
 constexpr int raster_waves_per_simd() { // double: twice the registers per value -> 2 workgroups per CU, no spilling
@@ -1330,7 +1333,11 @@ int rasterize_impl(
     DRTK_RETURN_IF_LAUNCH_FAILED();
   }
   // persistent workgroups pulling work items: as many as can be resident, never more than items
+#ifdef DRTK_RASTER_BLOCKS_PER_CU
+  const int64_t resident = int64_t(num_compute_units()) * DRTK_RASTER_BLOCKS_PER_CU;
+#else
   const int64_t resident = int64_t(num_compute_units()) * (raster_waves_per_simd<T>() / 2);
+#endif
   const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(L.max_items, resident));
   if (L.tile_shift == 6) {
     DRTK_LAUNCH(
