@@ -438,6 +438,13 @@ def main():
     mpix = n_total * H * W * args.steps / elapsed / 1e6
     comm = None
     if grouped:
+        # the collectives' own times come from ONE extra step with the reducers' event bracketing on (every rank runs it);
+        # the timed region above runs without those events
+        for r in reducers:
+            r.record_timings = True
+        step()
+        for r in reducers:
+            r.record_timings = False
         per = [r.timings_ms() for r in reducers]
         if all(t is not None for t in per):
             comm = (sum(t[0] for t in per), sum(t[1] for t in per))
@@ -668,8 +675,8 @@ def main():
                 "bytes": nbytes, "collectives_per_step": sum(r.collectives_per_step() for r in reducers),
                 "staging_dtype": str(reducers[0].flat.dtype).replace("torch.", ""),
                 "ms_launch_to_done": round(comm[0], 4), "ms_exposed_on_main_stream": round(comm[1], 4),
-                "note": "last timed step, rank 0: side-stream time from each collective's launch to its completion (sum), and how "
-                        "long the main stream then waited for them"},
+                "note": "one extra step after the timed region, rank 0: side-stream time from each collective's launch to its "
+                        "completion (sum), and how long the main stream then waited for them"},
             "graph_step": graph,
             "extensions": ext,
             "roofline": roofline,

@@ -147,6 +147,10 @@ class SharedGradReducer:
         # True: a process group of ONE rank still issues its collectives (the sum over one rank is the identity) -- how
         # tests/test_gpu_rccl_single_rank.py runs the real call sequence against RCCL on a one-GPU box
         self.run_single_rank = False
+        # True: bracket every collective (and finish()'s wait) with HIP events for timings_ms().  Off by default: an event
+        # record is a barrier packet on its stream, six of them per step are measurable on a 5 ms step (bench.py switches
+        # it on for one extra step after its timed region)
+        self.record_timings = False
         for i, p in enumerate(self.params):
             self._handles.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_leaf_grad(i)))
         self.zero_grad()
@@ -248,10 +252,11 @@ class SharedGradReducer:
             cur = th.cuda.current_stream(self.flat.device)
             self.stream.wait_stream(cur)  # the gradient is written on the stream autograd runs on
             with th.cuda.stream(self.stream):
-                ev0 = th.cuda.Event(enable_timing=True)
-                ev0.record()
+                if self.record_timings:
+                    ev0 = th.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    self._events.append([ev0, None])
                 self._pending[key] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
-                self._events.append([ev0, None])
         else:
             self._pending[key] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
 
@@ -281,15 +286,18 @@ class SharedGradReducer:
             with th.cuda.stream(self.stream):
                 for k, work in enumerate(self._pending.values()):
                     work.wait()
-                    ev1 = th.cuda.Event(enable_timing=True)
-                    ev1.record()
-                    if k < len(self._events):
+                    if self.record_timings and k < len(self._events):
+                        ev1 = th.cuda.Event(enable_timing=True)
+                        ev1.record()
                         self._events[k][1] = ev1
-            w0, w1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-            w0.record(cur)
-            cur.wait_stream(self.stream)
-            w1.record(cur)
-            self._wait_events = (w0, w1)
+            if self.record_timings:
+                w0, w1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+                w0.record(cur)
+                cur.wait_stream(self.stream)
+                w1.record(cur)
+                self._wait_events = (w0, w1)
+            else:
+                cur.wait_stream(self.stream)
         else:
             for work in self._pending.values():
                 work.wait()
@@ -309,8 +317,9 @@ class SharedGradReducer:
 
     def timings_ms(self):
         """(sum over this step's collectives of launch -> completion on the side stream, time the main stream spent
-        waiting for them in finish()) in milliseconds; synchronises.  None on CPU / single rank."""
-        if not (self.cuda and self._events and all(e[1] is not None for e in self._events)):
+        waiting for them in finish()) in milliseconds; synchronises.  None on CPU / single rank, or when the step ran
+        without `record_timings`."""
+        if not (self.cuda and self._events and self._wait_events and all(e[1] is not None for e in self._events)):
             return None
         th.cuda.synchronize(self.flat.device)
         total = sum(e0.elapsed_time(e1) for e0, e1 in self._events)

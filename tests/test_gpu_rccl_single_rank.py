@@ -65,6 +65,7 @@ v = v0.clone().requires_grad_(True)
 a16 = attr0.half().requires_grad_(True)
 red = ddist.SharedGradReducer([v, [a16]], dtype=th.float32)
 red.run_single_rank = True
+red.record_timings = True
 assert red.collectives_per_step() == 2 and red.flat.dtype == th.float32
 for it in range(2):  # a second step on the same reducer: buffers re-armed, events reused
     red.zero_grad()
