@@ -279,20 +279,20 @@ def emit_line(obj):
 
 def timed_loop(step, steps, dev, world):
     """The contract's timing: barrier + synchronize, EXACTLY `steps` steps, barrier + synchronize, wall clock, MAX over
-    ranks.  Beside it every step is bracketed by a pair of HIP events on the stream the step runs on (hipEvent,
+    ranks.  Beside it every step lies between two HIP events on the stream the step runs on (hipEvent,
     median): the median tells what a step costs when nothing disturbs it, the wall clock is what `value` is made of."""
     from drtk_amd import dist as ddist
 
-    evs = [(th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    evs = [th.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # one per step BOUNDARY (an event record is a barrier packet)
     ddist.barrier_and_sync(dev)
     t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()
+    evs[0].record()
+    for i in range(steps):
         loss = step()
-        e1.record()
+        evs[i + 1].record()
     ddist.barrier_and_sync(dev)
     elapsed = time.perf_counter() - t0
-    per_step = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
         t = th.tensor([elapsed, median_ms], dtype=th.float64, device=dev)
