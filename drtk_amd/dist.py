@@ -61,11 +61,14 @@ class _StagedCast(th.autograd.Function):
     def backward(ctx, g):
         r = ctx.reducer
         if r._active():
-            # the whole gradient of this pass (autograd has summed every use of the cast tensor): accumulate it unrounded
+            # the gradient of THIS cast tensor (autograd has summed its uses): accumulate it unrounded.  The leaf is not
+            # marked ready here -- it may be cast a second time, or reach the loss directly as well (`p.float()`); its own
+            # post-accumulate hook fires once every path into it has run (with an undefined gradient when upcast() was the
+            # only one), and that is where the segment is completed and the group launched (_on_leaf_grad)
+            r._check_not_in_flight(ctx.index)
             r._begin_round()
             r.segments[ctx.index].add_(g.reshape(-1))
             r._staged_seen.add(ctx.index)
-            r._on_grad_ready(ctx.index)
             return None, None, None  # the leaf's .grad is written once, by finish(), from the reduced sum
         return g.to(ctx.dtype), None, None
 
@@ -167,7 +170,10 @@ class SharedGradReducer:
     def upcast(self, p: th.Tensor) -> th.Tensor:
         """`p` in the buffer's dtype for use in the forward pass.  For a staged parameter (stored in another dtype) the
         gradient of the returned tensor is accumulated into the flat buffer unrounded and reduced there; `p.grad` is
-        written once by `finish()`.  With the reducer inactive (one rank) this is `p.to(dtype)` with the usual gradient."""
+        written once by `finish()`.  With the reducer inactive (one rank) this is `p.to(dtype)` with the usual gradient.
+        May be called several times per step for the same leaf, and the leaf may ALSO be used directly (`p.float()`):
+        every cast's gradient is added to the segment, the direct part (rounded to the leaf's dtype by autograd) is added
+        when the leaf's own gradient hook fires, and only then does the leaf count as ready."""
         i = next((k for k, q in enumerate(self.params) if q is p), None)
         assert i is not None, "upcast(): not one of this reducer's tensors"
         return p if self.direct[i] else _StagedCast.apply(p, self, i)
@@ -217,18 +223,31 @@ class SharedGradReducer:
             self._finished = False
 
     def _on_leaf_grad(self, i: int) -> None:
-        # a leaf fed through upcast() still sees its (undefined) gradient arrive: that pass was already accounted for
-        if i not in self._staged_seen:
-            self._on_grad_ready(i)
+        # Runs after EVERY path into the leaf has been differentiated.  A leaf fed through upcast() arrives here with an
+        # undefined gradient when the casts were its only uses; if it ALSO reached the loss directly, that part sits in
+        # `.grad` (rounded to the leaf's dtype by autograd) and is moved into the segment beside the unrounded part.
+        if i in self._staged_seen and self._active():
+            self._absorb_direct_use(i)
+        self._on_grad_ready(i)
 
-    def _on_grad_ready(self, i: int) -> None:
-        if not self._active() or self._defer:
-            return
+    def _absorb_direct_use(self, i: int) -> None:
+        p = self.params[i]
+        if p.grad is not None:
+            self._check_not_in_flight(i)
+            self.segments[i].add_(p.grad.reshape(-1).to(self.flat.dtype))
+            p.grad = None
+
+    def _check_not_in_flight(self, i: int) -> None:
         if self.group_of[i] in self._pending:
             raise RuntimeError(
                 "SharedGradReducer: a second backward pass reached a gradient whose all-reduce was already launched this "
                 "round -- it would add un-reduced local gradients to the reduced sum.  Call finish() after every backward "
                 "pass, or run the passes to be accumulated under `with reducer.no_sync():`")
+
+    def _on_grad_ready(self, i: int) -> None:
+        if not self._active() or self._defer:
+            return
+        self._check_not_in_flight(i)
         self._begin_round()
         self._ready.add(i)
         if self.overlap:
@@ -240,6 +259,7 @@ class SharedGradReducer:
         """Bring parameter i's segment up to date with its gradient, whichever way that gradient was delivered."""
         p, seg = self.params[i], self.segments[i]
         if i in self._staged_seen:
+            self._absorb_direct_use(i)  # (normally done by the leaf's hook already; under no_sync() it is done here)
             return  # accumulated unrounded by upcast()'s backward
         if p.grad is None:
             if self.direct[i]:

@@ -28,7 +28,7 @@ class CapturedStep:
 
 
 def capture_step(step: Callable[[], object], leaves: Iterable[th.Tensor], warmup: int = 3,
-                 stream: Optional["th.cuda.Stream"] = None) -> CapturedStep:
+                 stream: Optional["th.cuda.Stream"] = None, reducers: Iterable = ()) -> CapturedStep:
     """Record `step()` -- forward, loss AND `backward()` -- into a HIP graph.
 
     step     a function without arguments that runs one whole step on static input tensors (update them IN PLACE
@@ -38,24 +38,36 @@ def capture_step(step: Callable[[], object], leaves: Iterable[th.Tensor], warmup
              the captured backward pass allocates them from the graph's private pool (torch's capture recipe), and stay
              attached afterwards.
     warmup   eager runs on a side stream before the capture (allocator and autograd warm-up, as torch prescribes).
+    stream   the side stream of the warm-up runs AND of the capture (default: a new one).
+    reducers `SharedGradReducer`s attached to the leaves.  Their gradient hooks would launch all-reduces on the reducer's
+             own stream from inside the warm-up and the captured backward pass -- work the capture cannot join, so it
+             fails -- and are therefore switched off (`enabled = False`) for the duration of this call and restored after.
 
     Multi-GPU: capture the LOCAL step only and run `SharedGradReducer.finish()` after each replay; a collective inside
-    the captured region is not supported here.
+    the captured region is not supported here.  A reducer that is not passed in `reducers` must be disabled by the caller.
     """
     leaves = list(leaves)
     assert leaves and all(p.is_cuda and p.is_leaf for p in leaves), "capture_step(): leaves must be CUDA leaf tensors"
-    side = stream if stream is not None else th.cuda.Stream(device=leaves[0].device)
-    side.wait_stream(th.cuda.current_stream(leaves[0].device))
-    with th.cuda.stream(side):
-        for _ in range(max(warmup, 1)):
-            for p in leaves:
-                p.grad = None
-            step()
-    th.cuda.current_stream(leaves[0].device).wait_stream(side)
-    th.cuda.synchronize(leaves[0].device)
-    for p in leaves:
-        p.grad = None
-    graph = th.cuda.CUDAGraph()
-    with th.cuda.graph(graph):
-        outputs = step()
+    reducers = list(reducers)
+    was_enabled = [r.enabled for r in reducers]
+    for r in reducers:
+        r.enabled = False
+    try:
+        side = stream if stream is not None else th.cuda.Stream(device=leaves[0].device)
+        side.wait_stream(th.cuda.current_stream(leaves[0].device))
+        with th.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                for p in leaves:
+                    p.grad = None
+                step()
+        th.cuda.current_stream(leaves[0].device).wait_stream(side)
+        th.cuda.synchronize(leaves[0].device)
+        for p in leaves:
+            p.grad = None
+        graph = th.cuda.CUDAGraph()
+        with th.cuda.graph(graph, stream=side):
+            outputs = step()
+    finally:
+        for r, e in zip(reducers, was_enabled):
+            r.enabled = e
     return CapturedStep(graph, outputs, leaves)

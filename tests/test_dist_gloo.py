@@ -157,6 +157,21 @@ def _worker(rank, world, port, out_dir):
     i16 = next(k for k, q in enumerate(red.params) if q is attr16)
     out.update({"a16_f32_sum": red.segments[i16].clone().view_as(attr16), "a16_grad": attr16.grad.clone(),
                 "extra16_grad": extra16.grad.clone(), "a16_input": attr16.detach().float()})
+    for h in red._handles:
+        h.remove()
+
+    # (g) a staged leaf that reaches the loss through upcast() TWICE and directly (`p.float()`) as well: every part of
+    # its gradient must arrive in the reduced sum, and the collective is launched once, after the last of them
+    w16 = th.full((5,), 0.5, dtype=th.float16, requires_grad=True)
+    red = ddist.SharedGradReducer([w16], dtype=th.float32)
+    launched = []
+    launch = red._launch
+    red._launch = lambda g, launch=launch: (launched.append(g), launch(g))[1]
+    s = float(rank + 1)
+    ((red.upcast(w16) ** 2).sum() * s + (red.upcast(w16) * 2.0).sum() + (w16.float() * 3.0).sum()).backward()
+    assert launched == [0] and w16.grad is None  # launched from the leaf's hook, the direct part moved into the segment
+    red.finish()
+    out.update({"mixed_grad": w16.grad.clone(), "mixed_f32": red.segments[0].clone()})
     ddist.barrier_and_sync()
     th.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     th.distributed.destroy_process_group()
@@ -224,3 +239,75 @@ def test_two_ranks_match_single_process(tmp_path):
         assert float((r["a16_f32_sum"] - a_in.grad).abs().max()) <= tol
         assert r["a16_grad"].dtype == th.float16 and th.equal(r["a16_grad"], r["a16_f32_sum"].half())
         assert th.equal(r["extra16_grad"], th.full((3,), 3.0, dtype=th.float16))
+        # (g) sum over ranks r of  2 * 0.5 * (r + 1)  +  2  +  3   =  (1 + 2) + 2 * 5
+        assert th.equal(r["mixed_f32"], th.full((5,), 13.0)) and th.equal(r["mixed_grad"], th.full((5,), 13.0, dtype=th.float16))
+
+
+def _shard_worker(rank, world, port, out_dir, n_views, H, W):
+    """One rank of a view-sharded step: BASELINE configs[3]'s partitioning (contiguous blocks of views, shared world-space
+    vertices and attributes, two collectives in the fixed order) at reduced resolution."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    th.set_num_threads(1)
+    from backends import OracleBackend, make_ops
+
+    from drtk_amd import dist as ddist
+    from drtk_amd import synthetic as S
+
+    ddist.init_from_env(backend="gloo")
+    v_world, vi = S.uv_sphere(12, 14)
+    cams = S.ring_cameras(n_views, W, H)
+    attr = S.random_attributes(1, v_world.shape[0], 5, seed=3)[:1].contiguous()
+    v_world = v_world.double().requires_grad_(True)  # float64: the comparison below is about the SHARDING, at 1e-6
+    attr = attr.double().requires_grad_(True)
+    cams = tuple(t.double() for t in cams)
+    views = ddist.shard_views(n_views, rank, world)
+    red = ddist.SharedGradReducer([v_world, attr])
+    launched = []
+    launch = red._launch
+    red._launch = lambda g, launch=launch: (launched.append(g), launch(g))[1]
+    loss = _local_step(make_ops(OracleBackend(1)), v_world, attr, vi, cams, views, H, W) if len(views) else 0.0
+    red.finish()
+    th.save({"views": list(views), "v": v_world.grad.clone(), "a": attr.grad.clone(), "loss": loss, "launched": launched},
+            os.path.join(out_dir, f"r{rank}.pt"))
+    ddist.barrier_and_sync()
+    th.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,n_views", [(8, 64), (8, 3), (4, 11), (8, 13)],
+                         ids=["configs3_64_views_over_8", "3_views_over_8_five_empty_shards", "11_views_over_4", "13_views_over_8"])
+def test_view_sharding_at_world_sizes_4_and_8(tmp_path, world, n_views):
+    """BASELINE configs[3]'s sharding (64 views -> 8 per rank) at reduced resolution, a batch smaller than the world
+    (five ranks own nothing and run no backward pass) and uneven remainders: every rank ends with the same gradients,
+    they equal the single-process gradients to 1e-6, and every rank issued the same two collectives in the same order."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from backends import OracleBackend, make_ops
+
+    from drtk_amd import synthetic as S
+
+    H, W = 24, 32
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path), n_views, H, W), nprocs=world, join=True)
+    res = [th.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    assert sorted(sum((r["views"] for r in res), [])) == list(range(n_views))
+    sizes = [len(r["views"]) for r in res]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    if n_views == 64:
+        assert sizes == [8] * 8
+    if n_views == 3:
+        assert sizes == [1, 1, 1, 0, 0, 0, 0, 0]
+    for r in res:
+        assert r["launched"] == [1, 0]  # attributes' group first, vertices last -- from hooks or, on an empty shard, finish()
+        assert th.equal(r["v"], res[0]["v"]) and th.equal(r["a"], res[0]["a"])
+    th.set_num_threads(4)
+    v_world, vi = S.uv_sphere(12, 14)
+    cams = tuple(t.double() for t in S.ring_cameras(n_views, W, H))
+    attr = S.random_attributes(1, v_world.shape[0], 5, seed=3)[:1].contiguous().double().requires_grad_(True)
+    v_world = v_world.double().requires_grad_(True)
+    loss = _local_step(make_ops(OracleBackend(1)), v_world, attr, vi, cams, range(n_views), H, W)
+    assert abs(loss - sum(r["loss"] for r in res)) <= 1e-9 * abs(loss)
+    for got, want in ((res[0]["v"], v_world.grad), (res[0]["a"], attr.grad)):
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
