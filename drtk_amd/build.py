@@ -158,6 +158,41 @@ def build_variant(out, defines, verbose=True):
     return out
 
 
+FASTMATH_DEPTH_LIB = os.path.join(PKG, "libdrtk_amd_depth_fastmath.so")
+
+
+def build_depth_fastmath(force=False, verbose=True):
+    """drtk_amd/libdrtk_amd_depth_fastmath.so -- the whole C ABI with the rasterizer's depth evaluated in the order the
+    reference's host path has when built with its own flags (-O3 --fast-math: csrc/rasterize.hip,
+    DRTK_DEPTH_FASTMATH_ORDER).  An OFFERED variant for callers who need index_img bit-equal to the reference as
+    setup.py builds it; the default library keeps the source order (strict IEEE), the torch-operator shim links the
+    default, and nothing loads this one unless asked (drtk_amd.capi.use_depth_order("fastmath") before the first call,
+    or DRTK_AMD_DEPTH_ORDER=fastmath in the environment).  Pinned by tests/test_gpu_parity.py::
+    test_depth_fastmath_variant_reproduces_the_reference_as_built."""
+    deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
+    extra = " ".join(HIP_FLAGS) + " -DDRTK_DEPTH_FASTMATH_ORDER"
+    if not force and _newer(FASTMATH_DEPTH_LIB, deps, extra):
+        return FASTMATH_DEPTH_LIB
+    # only rasterize.hip differs: the other objects are compiled once more all the same (a library is ONE consistent set
+    # of flags; ~1 min side by side)
+    objs, cmds = [], []
+    for s in KERNEL_SRCS:
+        o = os.path.join(CSRC, s + ".fastmath.o")
+        objs.append(o)
+        cmds.append([HIPCC, *HIP_FLAGS, "-DDRTK_DEPTH_FASTMATH_ORDER", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, s), "-o", o])
+    with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
+        outs = list(ex.map(_run, cmds))
+    for s, out in zip(KERNEL_SRCS, outs):
+        check_no_vgpr_spills(out, s + " (depth-order variant)")
+    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", FASTMATH_DEPTH_LIB, *objs])
+    for o in objs:
+        os.remove(o)
+    _stamp(FASTMATH_DEPTH_LIB, deps, extra)
+    if verbose:
+        print(f"[drtk_amd] built {FASTMATH_DEPTH_LIB}")
+    return FASTMATH_DEPTH_LIB
+
+
 OPS_DIR = os.path.join(CSRC, "torch_ops")
 OPS_SRCS = ["rasterize.cpp", "render.cpp", "interpolate.cpp", "interp_matrix.cpp", "mipmap.cpp", "edge_grad.cpp", "transform.cpp"]
 
@@ -228,6 +263,7 @@ def build_ext_modules(force=False, verbose=True):
 
 def build_all(force=False, verbose=True):
     build_kernels(force=force, verbose=verbose)
+    build_depth_fastmath(force=force, verbose=verbose)
     build_torch_ops(force=force, verbose=verbose)
     build_ext_modules(force=force, verbose=verbose)
     return LIB, OPS
@@ -253,6 +289,9 @@ if __name__ == "__main__":
     elif "--variant" in sys.argv:  # python drtk_amd/build.py --variant out.so DEFINE[=value] ...
         i = sys.argv.index("--variant")
         build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    elif "--depth-order" in sys.argv:  # python drtk_amd/build.py --depth-order fastmath
+        assert sys.argv[sys.argv.index("--depth-order") + 1] == "fastmath", "--depth-order fastmath (the default library IS the strict order)"
+        build_depth_fastmath(force="--force" in sys.argv)
     elif "--ablation" in sys.argv:
         build_ablation(force="--force" in sys.argv)
     else:

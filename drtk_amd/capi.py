@@ -49,9 +49,22 @@ def use_profiling_library(path: str) -> None:
     _lib_path = path
 
 
+def use_depth_order(order: str) -> None:
+    """Bind this module to the build variant whose rasterizer evaluates depth in the order of the reference AS BUILT by its
+    setup.py (`-O3 --fast-math`): `order="fastmath"` -> drtk_amd/libdrtk_amd_depth_fastmath.so (drtk_amd/build.py
+    build_depth_fastmath); `"strict"` is the default library.  Must be called before the first C-ABI call of the
+    process; DRTK_AMD_DEPTH_ORDER=fastmath in the environment does the same.  The torch operators always use the default."""
+    global _lib_path
+    assert order in ("strict", "fastmath"), order
+    assert _lib is None, "the C-ABI library is already loaded"
+    _lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdrtk_amd_depth_fastmath.so") if order == "fastmath" else None
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
+        if _lib_path is None and os.environ.get("DRTK_AMD_DEPTH_ORDER", "") == "fastmath":
+            use_depth_order("fastmath")
         path = _lib_path or native_library_paths()[0]
         if not os.path.isfile(path):
             raise ImportError(f"{path} is missing: run `python {os.path.join(os.path.dirname(path), 'build.py')}`")

@@ -446,24 +446,41 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
   }
 }
 
-// Backward, wide-channel fast path (vertex + bary gradients, C % 16 == 0, 16-byte aligned rows).
+// Backward, wide-channel path: the vertex gradient (with or without the bary gradient) for any C % 4 == 0, C >= 8,
+// f32, 16-byte aligned attribute rows.  (Round 4: rounds 1-3 had this pipeline for C % 16 == 0 with both gradients only;
+// every other shape fell back to the generic kernel above.)
 //
-// Same tiling and phase structure as interpolate_backward_kernel<.., 16>, but written so that no
-// memory round trip is ever waited for in isolation (the generic kernel's phase 1 is a chain of up
-// to nine dependent global waits per row -- index, corners, bary, then go/attribute loads per
-// 4-channel block -- and PMC shows its waves parked on s_waitcnt 72 % of their life):
-//   * the triangle and corner ids of all four rows are fetched once, up front;
-//   * every global load of a row (16 grad_out planes, 3 bary planes, 12 attribute float4) is issued
-//     in one batch, and the NEXT row's grad_out/bary batch is issued before the current row's
-//     phase 2, so it lands while the wave is busy in LDS;
-//   * the per-pixel bary-gradient dot products run after phase 2 and read grad_out back from the
-//     LDS staging rows, which frees the registers for the prefetch.
-template <typename T>
+// Same tiling as interpolate_backward_kernel -- a workgroup owns 64 x 16 pixels, each wave walks 4 adjacent rows of 64
+// pixels, lane = pixel in phase 1, lane = (corner, channel) in phase 2 -- but written so that no memory round trip is
+// ever waited for in isolation (the generic kernel's phase 1 is a chain of up to nine dependent global waits per row --
+// index, corners, bary, then go/attribute loads per 4-channel block -- and PMC shows its waves parked on s_waitcnt
+// 72 % of their life):
+//   * ROW-outer, channel-chunk-inner: index, corner ids and barycentrics of a row are fetched and staged ONCE, whatever
+//     C is, and the bary gradient of a pixel accumulates in registers over all chunks in the reference's channel order
+//     (interpolate_kernel.cu:238-246) and is stored once -- a chunk-outer loop re-reads 16 B/px and read-modify-writes
+//     24 B/px of bary_grad per extra chunk, i.e. costs more per channel at C = 64 than at C = 16;
+//   * channels go in chunks of 16 with a last chunk of 4, 8 or 12 (scatter_runs folds 12 / 24 (corner, channel) pairs
+//     into 4 / 2 pixel slices of the wave, so the lanes stay busy);
+//   * every global load of a step (<= 16 grad_out planes, first half of the attribute rows) is issued in one batch, and
+//     the NEXT step's grad_out planes (next chunk of this row, or first chunk + barycentrics of the next row) are
+//     requested before the current step's phase 2, so they land while the wave is busy in LDS;
+//   * the per-pixel bary-gradient dot products run after phase 2 and read grad_out back from the LDS staging rows, which
+//     frees the registers for the prefetch.
+//   * TABLE (round 4): the run sums do not go to global memory run by run but into a table of the WORKGROUP in LDS --
+//     2^log2_slots vertices x C double accumulators, filled by all four waves with ds_add_f64, slots looked up once per
+//     row by the lanes that start a run -- and the tile's 64 x 16 pixels cost one global atomic per vertex and channel at
+//     the end.  Per-run atomics are what the counters show as write traffic beyond bary_grad (864 MB against 403 MB at
+//     the bench shape), and on rows that are not a multiple of 64 bytes (C = 12, 24) they are several times slower still.
+//     A vertex that finds no slot keeps the direct atomics.
+#ifndef DRTK_INTERP_WIDE_ONLY
+#define DRTK_INTERP_WIDE_ONLY false
+#endif
+template <typename T, bool HAS_BARY, bool TABLE>
 __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
-    int dbg, int strip) {
+    int dbg, int strip, int log2_slots) {
   using V4 = typename Vec4<T>::type;
   constexpr int CH = 16;
   constexpr int kWaves = kBlock / kWave;
@@ -472,6 +489,10 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
   __shared__ __attribute__((aligned(16))) T s_g[kWaves][CH * kRunPad];
   __shared__ __attribute__((aligned(16))) T s_b[kWaves][3 * kRunPad];
   __shared__ int32_t s_vid[kWaves][3 * kRunPad];
+  __shared__ int32_t s_slot[TABLE ? kWaves : 1][TABLE ? 3 * kRunPad : 1];
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_table_raw[]; // TABLE: [slots][C] doubles, then [slots] keys
+  TableAcc* const t_vals = reinterpret_cast<TableAcc*>(s_table_raw);
+  int32_t* const t_keys = reinterpret_cast<int32_t*>(t_vals + (TABLE ? (size_t(C) << log2_slots) : 0));
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -486,7 +507,11 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
   T* attr_grad_n = attr_grad + int64_t(n) * V * C;
   const T* go_n = grad_out + int64_t(n) * C * HW;
   const T* bary_n = bary_img + int64_t(n) * 3 * HW;
-  T* bgrad_n = bary_grad + int64_t(n) * 3 * HW;
+  T* bgrad_n = HAS_BARY ? bary_grad + int64_t(n) * 3 * HW : nullptr;
+  if constexpr (TABLE) {
+    for (int i = threadIdx.x; i < (C << log2_slots); i += kBlock) t_vals[i] = 0;
+    for (int i = threadIdx.x; i < (1 << log2_slots); i += kBlock) t_keys[i] = -1;
+  }
 
   auto load_tr = [&](int ps) -> int32_t {
     const int y = y0 + ps;
@@ -501,113 +526,201 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
   };
 
   // A wave whose 64 x 4 pixels are all background (43 % of them at the benchmark's coverage) has nothing to
-  // scatter: it zeroes its part of bary_grad and leaves.
+  // scatter: it zeroes its part of bary_grad and leaves (TABLE: stays for the barriers of a tile that has foreground).
+  bool wave_fg;
   {
     int32_t t4[kPasses];
 #pragma unroll
     for (int ps = 0; ps < kPasses; ++ps) t4[ps] = load_tr(ps);
     const bool any_fg = (t4[0] & t4[1] & t4[2] & t4[3]) != -1;
-    if (__ballot(any_fg) == 0) {
+    wave_fg = __ballot(any_fg) != 0;
+    bool tile_fg = wave_fg;
+    if constexpr (TABLE) tile_fg = __syncthreads_or(wave_fg) != 0; // (also orders the table's zero-fill before its first use)
+    if (!wave_fg) {
+      if constexpr (HAS_BARY) {
+        int yz = y0; // (recomputed from a laundered copy: kept from the index loads above, the row predicates were spilled)
+        asm volatile("" : "+v"(yz));
 #pragma unroll
-      for (int ps = 0; ps < kPasses; ++ps) {
-        const int y = y0 + ps;
-        if (x < W && y < H) {
-          T* bgp = bgrad_n + int64_t(y) * W + x;
-          bgp[0] = T(0), bgp[HW] = T(0), bgp[2 * HW] = T(0);
+        for (int ps = 0; ps < kPasses; ++ps) {
+          const int y = yz + ps;
+          if (x < W && y < H) {
+            T* bgp = bgrad_n + int64_t(y) * W + x;
+            bgp[0] = T(0), bgp[HW] = T(0), bgp[2 * HW] = T(0);
+          }
         }
       }
-      return;
+      if (!TABLE || !tile_fg) return;
     }
   }
 
-  for (int c0 = 0; c0 < C; c0 += CH) {
-    T G[CH], B[3];
-    auto load_row = [&](int ps, bool cov) { // grad_out + bary of row ps; zeros where uncovered
-      const int64_t pix = int64_t(y0 + ps) * W + x;
+  if (wave_fg) {
+  T G[CH], B[3];
+  // grad_out planes c0 .. c0 + cc - 1 of row ps (cc = 4, 8, 12 or 16: wave-uniform); zeros where uncovered
+  // Loads of a row's operands: UNCONDITIONAL per lane (the offset of a lane off the canvas is clamped; what an uncovered
+  // pixel reads is never used: phase 2 flushes covered runs only and restarts its sums at every run head, the bary
+  // gradient is computed for covered pixels only), skipped for a row with no covered pixel at all (wave-uniform).  A
+  // per-lane `covered ? load : 0` puts every group of loads into its own exec-masked region with its own s_waitcnt --
+  // the prefetch became four dependent round trips (0.65 -> 0.72 ms at C = 16 when the tail chunks were introduced).
+  // Plane bases are wave-uniform and the in-plane offset is a 32-bit lane value (H W < 2^31): SGPR base + VGPR offset.
+  // The 16 + 3 plane loads of a row go through BUFFER loads: one descriptor per plane (wave-uniform: SGPRs) and ONE
+  // 32-bit byte offset register for all of them (H W < 2^30 on this path, checked by the launcher; a lane off the canvas
+  // is out of the plane's range and reads 0).  As global loads the compiler built a 64-bit address per load and, at the
+  // register bound, recycled registers that were still load destinations as address temporaries -- an s_waitcnt
+  // vmcnt(0) in the middle of the batch.
+  const uint32_t plane_bytes = static_cast<uint32_t>(HW * int64_t(sizeof(T)));
+  auto plane_load = [&](const T* plane, uint32_t byte_offset) -> T {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(plane), 0, static_cast<int>(plane_bytes), 0x00020000);
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, byte_offset, 0, 0));
+  };
+  auto row_offset = [&](int ps) -> uint32_t { // beyond the plane for a lane off the canvas
+    return (x < W && y0 + ps < H) ? static_cast<uint32_t>((y0 + ps) * W + x) * static_cast<uint32_t>(sizeof(T)) : plane_bytes;
+  };
+  // one call site, one offset register for grad_out and barycentrics (with an offset of its own the bary loads got a
+  // freshly written register, and the compiler waited for the grad_out loads before writing it)
+  auto load_row = [&](int ps, int c0, int cc, bool row_any, bool with_bary) {
+    if (!row_any) return;
+    const uint32_t bo = row_offset(ps);
 #pragma unroll
-      for (int c = 0; c < CH; ++c) G[c] = cov ? go_n[int64_t(c0 + c) * HW + pix] : T(0);
+    for (int q = 0; q < CH / 4; ++q) {
+      if (4 * q < cc) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) B[k] = cov ? bary_n[int64_t(k) * HW + pix] : T(0);
-    };
-    // rotating state: row ps (tr, v*), row ps+1 (tr_n, vn*), row ps+2 (tr_nn)
-    int32_t tr = load_tr(0), tr_n = load_tr(1), tr_nn = -1;
-    int32_t v0, v1, v2, vn0 = 0, vn1 = 0, vn2 = 0;
-    load_face(tr, v0, v1, v2);
-    load_row(0, tr != -1);
+        for (int c = 4 * q; c < 4 * q + 4; ++c) G[c] = plane_load(go_n + int64_t(c0 + c) * HW, bo);
+      }
+    }
+    if (with_bary) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) B[k] = plane_load(bary_n + int64_t(k) * HW, bo);
+    }
+  };
+  // rotating state: row ps (tr, v*), row ps+1 (tr_n, vn*), row ps+2 (tr_nn)
+  int32_t tr = load_tr(0), tr_n = load_tr(1), tr_nn = -1;
+  int32_t v0, v1, v2, vn0 = 0, vn1 = 0, vn2 = 0;
+  load_face(tr, v0, v1, v2);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) G[c] = T(0);
+  B[0] = B[1] = B[2] = T(0);
+  load_row(0, 0, min(CH, C), __ballot(tr != -1) != 0, true);
+  // ONE loop over (row, chunk) steps, rows outer: as two nested loops the compiler kept ~45 more values live across the
+  // inner one (173 instead of 128 VGPRs: spills at 4 waves per SIMD)
+  unsigned long long heads = 0, cov = 0;
+  T bg0 = T(0), bg1 = T(0), bg2 = T(0);
+  int ps = 0, c0 = 0;
 #pragma unroll 1
-    for (int ps = 0; ps < kPasses; ++ps) {
-      const int y = y0 + ps;
-      const int64_t pix = int64_t(y) * W + x;
-      const bool covered = tr != -1;
-      // 0. the two CONDITIONAL fetches of the rows ahead come first: `cond ? load : default` compiles to a branch around the
-      //    load with an s_waitcnt vmcnt(0) inside it; issued after the next row's 19 loads (as they used to be) that wait
-      //    held the wave until all of them had landed, before the phase 2 they were meant to fly under (0.659 -> 0.650 ms;
-      //    making the two fetches unconditional instead cost registers and was slower, 0.675)
+  for (;;) {
+    const bool covered = tr != -1;
+    if (c0 == 0) {
+      // 0. the two CONDITIONAL fetches of the rows ahead come first: `cond ? load : default` compiles to a branch around
+      //    the load with an s_waitcnt vmcnt(0) inside it; issued after the next row's 19 loads (as they used to be) that
+      //    wait held the wave until all of them had landed, before the phase 2 they were meant to fly under (0.659 ->
+      //    0.650 ms; making the two fetches unconditional instead cost registers and was slower, 0.675)
       if (ps + 1 < kPasses) {
         load_face(tr_n, vn0, vn1, vn2);
         tr_nn = load_tr(ps + 2);
       }
-      // 1. stage this row
-#pragma unroll
-      for (int c = 0; c < CH; ++c) s_g[wave][c * kRunPad + lane] = G[c];
+      // 1. what the row's chunks share: barycentrics, corner ids, run structure
 #pragma unroll
       for (int k = 0; k < 3; ++k) s_b[wave][k * kRunPad + lane] = B[k];
       s_vid[wave][0 * kRunPad + lane] = v0;
       s_vid[wave][1 * kRunPad + lane] = v1;
       s_vid[wave][2 * kRunPad + lane] = v2;
-      unsigned long long heads, cov;
       run_masks(tr, heads, cov);
-      // 2. first half of the attribute rows of this row's triangles (consumed after phase 2)
-      constexpr int QH = CH / 8; // float4 per corner and half
-      const T* a0 = attrs_n + int64_t(v0) * C + c0;
-      const T* a1 = attrs_n + int64_t(v1) * C + c0;
-      const T* a2 = attrs_n + int64_t(v2) * C + c0;
-      V4 A0[QH], A1[QH], A2[QH];
+      bg0 = bg1 = bg2 = T(0);
+      if constexpr (TABLE) {
+        // table slots of the row's runs, looked up by the lanes that START a covered run (phase 2 reads them there)
+        int s0 = -1, s1 = -1, s2 = -1;
+        if (covered && ((heads >> lane) & 1ull) && !DRTK_DBG(dbg, 2)) {
+          s0 = table_slot_rt(t_keys, v0, log2_slots);
+          s1 = table_slot_rt(t_keys, v1, log2_slots);
+          s2 = table_slot_rt(t_keys, v2, log2_slots);
+        }
+        s_slot[wave][0 * kRunPad + lane] = s0;
+        s_slot[wave][1 * kRunPad + lane] = s1;
+        s_slot[wave][2 * kRunPad + lane] = s2;
+      }
+    }
+    const int cc = min(CH, C - c0); // 4, 8, 12 or 16
+    const bool last_chunk = c0 + CH >= C;
+    // 2. stage this chunk's grad_out
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) {
+      if (4 * q < cc) {
+#pragma unroll
+        for (int c = 4 * q; c < 4 * q + 4; ++c) s_g[wave][c * kRunPad + lane] = G[c];
+      }
+    }
+    // 3. first half of the attribute rows of this row's triangles (consumed after phase 2)
+    const T* a0 = attrs_n + int64_t(v0) * C + c0;
+    const T* a1 = attrs_n + int64_t(v1) * C + c0;
+    const T* a2 = attrs_n + int64_t(v2) * C + c0;
+#ifndef DRTK_INTERP_QA
+#define DRTK_INTERP_QA 1
+#endif
+    constexpr int QA = DRTK_INTERP_QA, QD = CH / 4 - QA; // float4 per corner requested before / after phase 2
+    V4 A0[QA], A1[QA], A2[QA];
+    if constexpr (HAS_BARY) {
       if (covered) {
 #pragma unroll
-        for (int q = 0; q < QH; ++q) {
-          A0[q] = *reinterpret_cast<const V4*>(a0 + 4 * q);
-          A1[q] = *reinterpret_cast<const V4*>(a1 + 4 * q);
-          A2[q] = *reinterpret_cast<const V4*>(a2 + 4 * q);
+        for (int q = 0; q < QA; ++q) {
+          if (4 * q < cc) {
+            A0[q] = *reinterpret_cast<const V4*>(a0 + 4 * q);
+            A1[q] = *reinterpret_cast<const V4*>(a1 + 4 * q);
+            A2[q] = *reinterpret_cast<const V4*>(a2 + 4 * q);
+          }
         }
       }
-      // 3. the next row's operands (and the ids of the row after it) fly under phase 2
-      if (ps + 1 < kPasses) load_row(ps + 1, tr_n != -1);
-      wave_lds_sync();
-      // 4. phase 2: run sums per (corner, channel) lane -> one 64-byte atomic request per corner and run
-      //    (a per-vertex LDS table in front of the atomics was measured slower here, twice: 1.01 vs 0.83 ms in round 1;
-      //    1.07 vs 0.65 ms in round 2 with a float table and slots looked up at run heads only -- the flush it saves is
-      //    0.11 ms, but the table's bookkeeping takes the kernel from 126 to 171 VGPRs, i.e. from 4 to 2 waves per SIMD.
-      //    A per-wave cache keyed by TRIANGLE instead -- the run loop is scalar, so the lookup is one v_cmp + s_ff1 on a
-      //    VGPR of keys and costs no registers (128 VGPRs, 4 waves kept) -- merges the rows of the wave's 64 x 4 pixels
-      //    and was also slower: 0.666 vs 0.654 ms with 16 float entries updated by read-add-write (the LDS round trip
-      //    sits on every run's critical path), 0.692 with 8, 0.74 with 16 double entries and fire-and-forget ds_add_f64
-      //    (51 KB of LDS per workgroup: 3 waves per SIMD).  Round 3: CARRYING the sums of the vertices two consecutive
-      //    runs share (neighbouring triangles share an edge) from run to run instead of flushing them -- which corner
-      //    continues as which decided by the scalar unit, the sums moved between the corner rows by one ds_bpermute, a
-      //    third of the atomic requests -- is correct and much slower: 0.901 vs 0.648 ms (1.096 vs 0.731 at 250k
-      //    triangles); the per-run scalar chain (vertex ids to SGPRs, nine compares, the permute's round trip) sits on
-      //    the one wave's critical path, the atomics it saves were fire-and-forget)
-      if (cov != 0 && !DRTK_DBG(dbg, 1)) {
-        const T* sg = s_g[wave];
-        const T* sb = s_b[wave];
-        scatter_runs<T>(
-            heads, cov, nullptr, s_vid[wave], 3 * CH, CH, static_cast<TableAcc*>(nullptr), 0, attr_grad_n, C, c0,
-            [sg, sb](int k, int c, int g4, T* xv) {
-              const V4 a = *reinterpret_cast<const V4*>(sg + c * kRunPad + 4 * g4);
-              const V4 b = *reinterpret_cast<const V4*>(sb + k * kRunPad + 4 * g4);
-              xv[0] = a.x * b.x, xv[1] = a.y * b.y, xv[2] = a.z * b.z, xv[3] = a.w * b.w;
-            }, dbg);
-      }
-      // 5. bary gradient: interpolate_kernel.cu:238-246 accumulation order (channels ascending)
-      T bg0 = T(0), bg1 = T(0), bg2 = T(0);
+    }
+    // 4. the next step's operands fly under phase 2: the next chunk of this row, or the first chunk (and the
+    //    barycentrics) of the next row
+    //    (ONE load site for both cases: with two, the compiler loaded into temporaries and copied them into G behind an
+    //    s_waitcnt vmcnt(0) straight after the loads -- the prefetch waited for itself)
+    {
+      const int n_ps = last_chunk ? ps + 1 : ps, n_c0 = last_chunk ? 0 : c0 + CH;
+      const bool n_any = last_chunk ? (ps + 1 < kPasses && __ballot(tr_n != -1) != 0) : cov != 0;
+      load_row(n_ps, n_c0, min(CH, C - n_c0), n_any, last_chunk);
+    }
+    wave_lds_sync();
+    // 5. phase 2: run sums per (corner, channel) lane -> one 64-byte atomic request per corner and run
+    //    (a per-vertex LDS table in front of the atomics was measured slower here, twice: 1.01 vs 0.83 ms in round 1;
+    //    1.07 vs 0.65 ms in round 2 with a float table and slots looked up at run heads only -- the flush it saves is
+    //    0.11 ms, but the table's bookkeeping takes the kernel from 126 to 171 VGPRs, i.e. from 4 to 2 waves per SIMD.
+    //    A per-wave cache keyed by TRIANGLE instead -- the run loop is scalar, so the lookup is one v_cmp + s_ff1 on a
+    //    VGPR of keys and costs no registers (128 VGPRs, 4 waves kept) -- merges the rows of the wave's 64 x 4 pixels
+    //    and was also slower: 0.666 vs 0.654 ms with 16 float entries updated by read-add-write (the LDS round trip
+    //    sits on every run's critical path), 0.692 with 8, 0.74 with 16 double entries and fire-and-forget ds_add_f64
+    //    (51 KB of LDS per workgroup: 3 waves per SIMD).  Round 3: CARRYING the sums of the vertices two consecutive
+    //    runs share (neighbouring triangles share an edge) from run to run instead of flushing them -- which corner
+    //    continues as which decided by the scalar unit, the sums moved between the corner rows by one ds_bpermute, a
+    //    third of the atomic requests -- is correct and much slower: 0.901 vs 0.648 ms (1.096 vs 0.731 at 250k
+    //    triangles); the per-run scalar chain (vertex ids to SGPRs, nine compares, the permute's round trip) sits on
+    //    the one wave's critical path, the atomics it saves were fire-and-forget)
+    if (cov != 0 && !DRTK_DBG(dbg, 1)) {
+      const T* sg = s_g[wave];
+      const T* sb = s_b[wave];
+      scatter_runs<T, TableAcc, DRTK_INTERP_WIDE_ONLY, TABLE, 16>(
+          heads, cov, TABLE ? s_slot[wave] : nullptr, s_vid[wave], 3 * cc, cc, t_vals, C, attr_grad_n, C, c0,
+          [sg, sb](int k, int c, int g4, T* xv) {
+            const V4 a = *reinterpret_cast<const V4*>(sg + c * kRunPad + 4 * g4);
+            const V4 b = *reinterpret_cast<const V4*>(sb + k * kRunPad + 4 * g4);
+            xv[0] = a.x * b.x, xv[1] = a.y * b.y, xv[2] = a.z * b.z, xv[3] = a.w * b.w;
+          }, dbg, 0, 1, TABLE ? c0 : 0);
+    }
+    // 6. bary gradient: interpolate_kernel.cu:238-246 accumulation order (channels ascending, over all chunks)
+    if constexpr (HAS_BARY) {
       if (covered && !DRTK_DBG(dbg, 8)) {
-        V4 D0[QH], D1[QH], D2[QH]; // second half: requested now, used after the first half's products
+        V4 D0[QD], D1[QD], D2[QD]; // the rest: requested now, used after the first part's products
+        // (row addresses rebuilt from laundered ids: carried over phase 2 as three 64-bit pointers they were spilled)
+        int32_t w0 = v0, w1 = v1, w2 = v2;
+        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
+        const T* d0 = attrs_n + int64_t(w0) * C + c0;
+        const T* d1 = attrs_n + int64_t(w1) * C + c0;
+        const T* d2 = attrs_n + int64_t(w2) * C + c0;
 #pragma unroll
-        for (int q = 0; q < QH; ++q) {
-          D0[q] = *reinterpret_cast<const V4*>(a0 + 4 * (QH + q));
-          D1[q] = *reinterpret_cast<const V4*>(a1 + 4 * (QH + q));
-          D2[q] = *reinterpret_cast<const V4*>(a2 + 4 * (QH + q));
+        for (int q = 0; q < QD; ++q) {
+          if (4 * (QA + q) < cc) {
+            D0[q] = *reinterpret_cast<const V4*>(d0 + 4 * (QA + q));
+            D1[q] = *reinterpret_cast<const V4*>(d1 + 4 * (QA + q));
+            D2[q] = *reinterpret_cast<const V4*>(d2 + 4 * (QA + q));
+          }
         }
         auto dot4 = [&](int q4, const V4& u0, const V4& u1, const V4& u2) {
           const T g0 = s_g[wave][(4 * q4 + 0) * kRunPad + lane], g1 = s_g[wave][(4 * q4 + 1) * kRunPad + lane];
@@ -618,21 +731,44 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
           bg0 += g3 * u0.w, bg1 += g3 * u1.w, bg2 += g3 * u2.w;
         };
 #pragma unroll
-        for (int q = 0; q < QH; ++q) dot4(q, A0[q], A1[q], A2[q]);
+        for (int q = 0; q < QA; ++q) {
+          if (4 * q < cc) dot4(q, A0[q], A1[q], A2[q]);
+        }
 #pragma unroll
-        for (int q = 0; q < QH; ++q) dot4(QH + q, D0[q], D1[q], D2[q]);
-      }
-      if (x < W && y < H) { // channel chunks accumulate in ascending order, like the reference's loop
-        T* bgp = bgrad_n + pix;
-        if (c0 == 0) {
-          bgp[0] = bg0, bgp[HW] = bg1, bgp[2 * HW] = bg2;
-        } else if (covered) {
-          bgp[0] += bg0, bgp[HW] += bg1, bgp[2 * HW] += bg2;
+        for (int q = 0; q < QD; ++q) {
+          if (4 * (QA + q) < cc) dot4(QA + q, D0[q], D1[q], D2[q]);
         }
       }
-      wave_lds_sync();
+    }
+    wave_lds_sync(); // the next step overwrites the staging rows
+    c0 += CH;
+    if (last_chunk) {
+      if constexpr (HAS_BARY) {
+        const int y = y0 + ps;
+        if (x < W && y < H) {
+          T* bgp = bgrad_n + int64_t(y) * W + x;
+          bgp[0] = bg0, bgp[HW] = bg1, bgp[2 * HW] = bg2;
+        }
+      }
       tr = tr_n, v0 = vn0, v1 = vn1, v2 = vn2;
       tr_n = tr_nn;
+      c0 = 0;
+      if (++ps == kPasses) break;
+    }
+  }
+  } // wave_fg
+  if constexpr (TABLE) {
+    // the tile's vertices to global memory: consecutive lanes = consecutive channels of a vertex (one request per 16)
+    __syncthreads();
+    if (!DRTK_DBG(dbg, 16)) {
+      for (int e = threadIdx.x; e < (C << log2_slots); e += kBlock) {
+        const int sl = e / C, c = e - sl * C;
+        const int32_t key = t_keys[sl];
+        if (key >= 0) {
+          const T xv = static_cast<T>(t_vals[e]);
+          if (xv != T(0)) atomic_add_global(attr_grad_n + int64_t(key) * C + c, xv);
+        }
+      }
     }
   }
 }
@@ -694,13 +830,43 @@ int interpolate_backward_impl(
       vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad,  \
       debug_flags(), strip)
   const bool small_c = C <= 4;
-  // float only: the double instantiation would need > 256 VGPRs for the same pipeline
-  const bool wide = sizeof(T) == 4 && attr_grad && bary_grad && cvec && (C % 16 == 0) && !DRTK_DBG(debug_flags(), 128);
+  // wide path: the vertex gradient (+ bary gradient) for any C % 4 == 0, C >= 8.  float only: the double instantiation
+  // would need > 256 VGPRs for the same pipeline
+  const bool wide = sizeof(T) == 4 && attr_grad && cvec && C >= 8 && HW < (int64_t(1) << 30) && !DRTK_DBG(debug_flags(), 128);
+  // (the bary gradient alone stays with the generic kernel: no scatter, covered pixels only -- 0.95 of the HBM peak on
+  // SURVEY 8d's bytes at the bench coverage; a forward-shaped streaming kernel with four pixels per lane, which cannot
+  // skip the background of a partly covered quad, was measured slower: 0.55 vs 0.40 ms at C = 16)
   if (wide) {
     if constexpr (sizeof(T) == 4) {
-      DRTK_LAUNCH(
-          (interpolate_backward_wide_kernel<T>), grid, block, 0, stream, grad_out, attrs, vi, index_img, bary_img,
-          V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip);
+      // the workgroup's vertex table: as many slots as fit DRTK_INTERP_TABLE_BYTES of LDS (the staging rows take 27 KB; 4
+      // workgroups per CU leave 40 KB each), at most 128, at least 16 -- else per-run atomics as before
+#ifndef DRTK_INTERP_TABLE_BYTES
+#define DRTK_INTERP_TABLE_BYTES 12800
+#endif
+      // -- and only where the rows of attr_grad are not made of whole 64-byte segments (C = 12, 20, 24, 28, ...): there the
+      // per-run atomics are several times slower (8 x 2048^2, both gradients: C = 12 0.92 -> 0.65 ms, C = 24 1.30 -> 1.04
+      // with the table), while on aligned rows (C = 8, 16, 32, 64) the table's lookups and barriers cost more than the
+      // fire-and-forget atomics they replace (C = 16: 0.63 -> 0.70 ms)
+      int log2_slots = 7;
+      while (log2_slots > 0 && (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) > DRTK_INTERP_TABLE_BYTES) --log2_slots;
+      const size_t row_bytes = sizeof(T) * C;
+      const bool rows_aligned = row_bytes % 64 == 0 || 64 % row_bytes == 0;
+#ifdef DRTK_INTERP_NO_TABLE
+      const bool table = false;
+#else
+      const bool table = log2_slots >= 4 && !rows_aligned && !DRTK_DBG(debug_flags(), 4096);
+#endif
+      const size_t lds = table ? (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) : 0;
+#define WIDE(HB, TB)                                                                                                      \
+  DRTK_LAUNCH(                                                                                                            \
+      (interpolate_backward_wide_kernel<T, HB, TB>), grid, block, lds, stream, grad_out, attrs, vi, index_img, bary_img, \
+      V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots)
+      if (bary_grad) {
+        if (table) WIDE(true, true); else WIDE(true, false);
+      } else {
+        if (table) WIDE(false, true); else WIDE(false, false);
+      }
+#undef WIDE
     }
   } else if (small_c && !DRTK_DBG(debug_flags(), 128)) {
 #define SMALL(HV, HB, CN)                                                                                                   \

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "segscatter.hpp" // wave_lds_sync
 
 namespace drtk_amd {
 namespace {
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
       lv_inp[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]);
       lv_ginp[s] = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * lv_plane[s]);
     }
-    for (int i = 0; (live[0] || live[1]) && i < t.n; ++i) {
+    for (int i = 0; (live[0] || live[1]) && i < t.n && !DRTK_DBG(dbg, 32); ++i) {
       T x, y;
       tap_xy(i, x, y);
 #pragma unroll
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
           const T fy1 = iy_se - q.iy, fy0 = q.iy - q.iy_nw, fx1 = ix_se - q.ix, fx0 = q.ix - q.ix_nw;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            if (c >= C) break;
+            if (c >= C || DRTK_DBG(dbg, 16)) break;
             const T gOut = g[c];
             // with a zero upstream gradient every term is +-0 * finite: the texels count as 0
             const T v_nw = gOut != T(0) ? top[c].x : T(0), v_ne = gOut != T(0) ? top[c].y : T(0);
@@ -1136,6 +1137,383 @@ __global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
   }
 }
 
+// ---- Backward, bilinear, f32, any C: WAVE-PRIVATE windows (round 4) -------------------------------------------------
+// mipmap_backward_tiled_kernel above is bound by its chain of dependent round trips at 3 waves per SIMD: 48 KB of
+// workgroup-shared windows and 157 VGPRs hold the occupancy there, and every phase of a tile (window placement, taps,
+// flush, each further round) is fenced by workgroup barriers -- 0.85 of its 1.95 ms remain with no accumulation at all
+// (profiles/r03/mipmap_pmc_sq.txt).  Here a WAVE owns its 16 x 4 pixels and a window of its own:
+//   * no workgroup barrier after the level table is staged: placement, taps, flush and the further rounds of a wave are
+//     ordered by the wave's own LDS counter, so 20+ independent waves per CU overlap each other's round trips;
+//   * kWaveCells cells per channel (double accumulators, ds_add_f64) shaped like the bounding box of the wave's taps --
+//     2 KB per channel and wave instead of 16 KB per channel and workgroup; channels go in blocks of four, so any C runs
+//     here (the level pair, tap geometry and grid gradient of a pixel are per block; the reference's sums regrouped);
+//   * per-level sizes and pointers are re-read from the LDS table inside the tap loop instead of being carried in
+//     registers; taps that touch the border of a level (not all four corners inside) go straight to global memory.
+// Taps that find no cell stay pending and get the window in a further round, exactly as in the tiled kernel.
+#ifndef DRTK_MIP_WAVE_CELLS
+#define DRTK_MIP_WAVE_CELLS 256
+#endif
+constexpr int kWaveCells = DRTK_MIP_WAVE_CELLS; // window cells per channel and wave, both levels together
+constexpr int kWaveWinW = 32;                   // widest window row (the flush walks two rows of <= 32 cells per step)
+#ifndef DRTK_MIP_WAVE_OCC
+#define DRTK_MIP_WAVE_OCC 3
+#endif
+
+__device__ __forceinline__ void wave_minmax2(int x, int y, bool on, int& x0, int& y0, int& x1, int& y1) {
+  x0 = wave_min_i32(on ? x : INT32_MAX), y0 = wave_min_i32(on ? y : INT32_MAX);
+  x1 = wave_max_i32(on ? x : INT32_MIN), y1 = wave_max_i32(on ? y : INT32_MIN);
+}
+
+template <typename T, int PAD, bool ALIGN>
+__global__ __launch_bounds__(kMipBlock, DRTK_MIP_WAVE_OCC) void mipmap_backward_wave_kernel(
+    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
+    const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
+  constexpr int padding = PAD;
+  constexpr bool align_corners = ALIGN;
+  static_assert(kTileW == 16 && kWave == 64, "a wave covers 16 x 4 pixels");
+  __shared__ double s_f[kTapTab * kTapTab];
+  __shared__ const void* s_ptr[kMaxLevels];
+  __shared__ void* s_grad[kMaxLevels];
+  __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  __shared__ long long s_sn[kMaxLevels];
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_win_raw[]; // [wave][channel of the block][kWaveCells] doubles
+  const int tid = threadIdx.x;
+  const int wave = tid / kWave, lane = tid & (kWave - 1);
+  const int CB = C < kChBlock ? C : kChBlock; // channels per block
+  double* const win = reinterpret_cast<double*>(s_win_raw) + wave * CB * kWaveCells;
+  stage_tap_table(s_f);
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w, s_sn); // the kernel's only workgroup barrier
+  for (int i = lane; i < CB * kWaveCells; i += kWave) win[i] = 0.0; // every flush leaves the window zeroed again
+
+  const int n = blockIdx.y;
+  const int tile = tile_index(strip);
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int px = tx * kTileW + (lane & (kTileW - 1)), py = ty * kTileH + wave * (kWave / kTileW) + lane / kTileW;
+  const bool valid = px < W && py < H;
+  const int64_t HW = int64_t(H) * W;
+  const int64_t pix = int64_t(py) * W + px;
+  const int64_t index = int64_t(n) * HW + pix;
+  PixelUV<T> uv = {};
+  if (valid) uv = load_pixel_uv<T>(grid, gl, vt, n, pix, index);
+  const int n_lv = mipmaps > 1 ? 2 : 1;
+  Taps<T> t = {};
+  bool have_taps = false;
+  T acc_x = T(0), acc_y = T(0);
+  auto tap_xy = [&](int i, T& x, T& y) {
+    const double f = tap_f(s_f, i, t.n);
+    x = t.u + static_cast<T>(t.du * f);
+    y = t.v + static_cast<T>(t.dv * f);
+  };
+  auto texel_floor = [&](T coord, int size) -> int { // (as in the tiled kernel: any origin is correct)
+    T unused;
+    const T c = unnormalize(coord, size, align_corners, &unused);
+    const T lo = padding == 0 ? T(-1) : T(0);
+    return static_cast<int>(floor(fmin(fmax(c, lo), static_cast<T>(size - 1))));
+  };
+
+  for (int c0 = 0; c0 < C; c0 += kChBlock) {
+    const int cc = min(kChBlock, C - c0);
+    T go[kChBlock] = {T(0), T(0), T(0), T(0)};
+    if (valid) {
+      const T* gout_px = grad_out + (int64_t(n) * C + c0) * HW + pix;
+#pragma unroll
+      for (int c = 0; c < kChBlock; ++c) {
+        if (c < cc) go[c] = gout_px[int64_t(c) * HW];
+      }
+    }
+    const bool has_go = go[0] != T(0) || go[1] != T(0) || go[2] != T(0) || go[3] != T(0);
+    if (__ballot(has_go) == 0) continue; // masked background: nothing to add anywhere, grid gradient +0
+    if (has_go && !have_taps) {
+      t = setup_taps<T>(uv, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+      have_taps = true;
+    }
+    const T alpha_1 = has_go ? t.a / t.n : T(0);
+    const T alpha_2 = has_go ? static_cast<T>((1.0 - t.a) / t.n) : T(0);
+    bool live[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const T alpha = s == 0 ? alpha_2 : alpha_1;
+      live[s] = false;
+#pragma unroll
+      for (int c = 0; c < kChBlock; ++c) live[s] = live[s] || (go[c] * alpha != T(0));
+      live[s] = live[s] && s < n_lv;
+    }
+    // ---- window placement: the finest live level of the wave and the next one, each window the bounding box of the
+    // north-west texels of the wave's first and last taps (the taps of a pixel are collinear), clipped to its share of
+    // the cells.  Wave-uniform values, no LDS.
+    int ref, ox[2], oy[2], ww[2], wh[2], base[2];
+    auto place = [&](const bool (&on)[2], const int (&lo_x)[2], const int (&lo_y)[2], const int (&hi_x)[2], const int (&hi_y)[2]) {
+      // lane values: per level s of the pixel, the extreme north-west texels it needs (on[s]); d = t.d1 + s
+      ref = wave_min_i32(on[0] ? t.d1 : on[1] ? t.d1 + 1 : kMaxLevels);
+      int x0[2], y0[2], x1[2], y1[2];
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const bool m0 = on[0] && t.d1 - ref == l, m1 = on[1] && t.d1 + 1 - ref == l;
+        const int lx = min(m0 ? lo_x[0] : INT32_MAX, m1 ? lo_x[1] : INT32_MAX), ly = min(m0 ? lo_y[0] : INT32_MAX, m1 ? lo_y[1] : INT32_MAX);
+        const int hx = max(m0 ? hi_x[0] : INT32_MIN, m1 ? hi_x[1] : INT32_MIN), hy = max(m0 ? hi_y[0] : INT32_MIN, m1 ? hi_y[1] : INT32_MIN);
+        x0[l] = wave_min_i32(lx), y0[l] = wave_min_i32(ly), x1[l] = wave_max_i32(hx), y1[l] = wave_max_i32(hy);
+      }
+      const bool both = x0[1] != INT32_MAX;
+      const int budget[2] = {both ? kWaveCells - kWaveCells / 4 : kWaveCells, kWaveCells / 4};
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        ox[l] = x0[l], oy[l] = y0[l];
+        base[l] = l == 0 ? 0 : budget[0];
+        if (x0[l] == INT32_MAX) {
+          ww[l] = wh[l] = 0;
+          continue;
+        }
+        // + 2: the east / south corners of the extreme taps; at least two columns, at most a flush row
+        const long long need_w = static_cast<long long>(x1[l]) - x0[l] + 2, need_h = static_cast<long long>(y1[l]) - y0[l] + 2;
+        ww[l] = static_cast<int>(need_w < kWaveWinW ? need_w : kWaveWinW);
+        const int rows = budget[l] / ww[l];
+        wh[l] = static_cast<int>(need_h < rows ? need_h : rows);
+      }
+    };
+    {
+      bool on[2] = {live[0], live[1]};
+      int lo_x[2] = {INT32_MAX, INT32_MAX}, lo_y[2] = {INT32_MAX, INT32_MAX}, hi_x[2] = {INT32_MIN, INT32_MIN}, hi_y[2] = {INT32_MIN, INT32_MIN};
+      if (live[0] || live[1]) {
+        for (int e = 0; e < 2; ++e) {
+          T x, y;
+          tap_xy(e == 0 ? 0 : t.n - 1, x, y);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            if (!live[s]) continue;
+            const int fx = texel_floor(x, s_w[t.d1 + s]), fy = texel_floor(y, s_h[t.d1 + s]);
+            lo_x[s] = min(lo_x[s], fx), lo_y[s] = min(lo_y[s], fy), hi_x[s] = max(hi_x[s], fx), hi_y[s] = max(hi_y[s], fy);
+          }
+        }
+      }
+      place(on, lo_x, lo_y, hi_x, hi_y);
+    }
+    // window cell of a tap's north-west corner on level d (the other three are +1 in x / y), or -1
+    auto cell_of = [&](int d, int ix_nw, int iy_nw, int& stride) -> int {
+      const int l = d - ref;
+      stride = 0;
+      if (l < 0 || l > 1) return -1;
+      const int wx = ix_nw - ox[l], wy = iy_nw - oy[l];
+      stride = ww[l];
+      return (wx >= 0 && wx < ww[l] - 1 && wy >= 0 && wy < wh[l] - 1) ? base[l] + wy * ww[l] + wx : -1;
+    };
+    // the wave's windows to global memory; every cell is left zero.  Two rows of <= 32 cells per step: lanes of a half
+    // wave = consecutive texels of a row, so the atomics of a row form one or two requests.
+    auto flush = [&]() {
+      wave_lds_sync();
+      if (DRTK_DBG(dbg, 4)) return;
+#pragma unroll 1
+      for (int l = 0; l < 2; ++l) {
+        if (ww[l] == 0) continue;
+        const int d = ref + l;
+        const int w_tex = s_w[d];
+        const int64_t plane = int64_t(s_h[d]) * w_tex;
+        const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C + c0) * plane);
+        const int col = lane & (kWaveWinW - 1), half = lane / kWaveWinW;
+        for (int r = half; r < wh[l]; r += kWave / kWaveWinW) {
+          if (col < ww[l]) {
+            double* wp = win + base[l] + r * ww[l] + col;
+            const int64_t o = int64_t(oy[l] + r) * w_tex + ox[l] + col;
+            for (int c = 0; c < cc; ++c) {
+              const double q = wp[c * kWaveCells];
+              if (q != 0.0) {
+                wp[c * kWaveCells] = 0.0;
+                atomic_add_g1(ginp + c * plane + o, static_cast<T>(q));
+              }
+            }
+          }
+        }
+      }
+      wave_lds_sync();
+    };
+
+    bool miss[2] = {false, false};
+    int miss_x0[2] = {INT32_MAX, INT32_MAX}, miss_y0[2] = {INT32_MAX, INT32_MAX}, miss_x1[2] = {INT32_MIN, INT32_MIN}, miss_y1[2] = {INT32_MIN, INT32_MIN};
+    uint32_t pending = 0; // bit 2 i + s: tap i on the pixel's level s found no window cell yet (taps >= 16 are never deferred)
+    auto note_miss = [&](int s, int ix_nw, int iy_nw) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k == s) {
+          miss[k] = true;
+          miss_x0[k] = min(miss_x0[k], ix_nw), miss_y0[k] = min(miss_y0[k], iy_nw);
+          miss_x1[k] = max(miss_x1[k], ix_nw), miss_y1[k] = max(miss_y1[k], iy_nw);
+        }
+      }
+    };
+    wave_lds_sync(); // (the zero-fill before the first block)
+    if (live[0] || live[1]) {
+      for (int i = 0; i < t.n; ++i) {
+        T x, y;
+        tap_xy(i, x, y);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (!live[s]) continue;
+          const int d = t.d1 + s;
+          const int h = s_h[d], w = s_w[d];
+          const int plane = h * w; // < 2^31, checked by fill_table()
+          const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]) + int64_t(c0) * plane;
+          const T alpha = s == 0 ? alpha_2 : alpha_1;
+          const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
+          const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
+          T g[kChBlock];
+#pragma unroll
+          for (int c = 0; c < kChBlock; ++c) g[c] = c < cc ? go[c] * alpha : T(0);
+          T gix = T(0), giy = T(0);
+          if ((q.o_nw | q.o_ne | q.o_sw | q.o_se) >= 0) {
+            // interior tap (nearly all): 2 cc 8-byte texel loads, 4 cc window adds, the grid-gradient products
+            Pair<T> top[kChBlock], bot[kChBlock];
+#pragma unroll
+            for (int c = 0; c < kChBlock; ++c) {
+              top[c] = bot[c] = Pair<T>{T(0), T(0)};
+              if (c < cc && !DRTK_DBG(dbg, 2)) {
+                top[c] = *(GlobalPtr<const Pair<T>>)(inp + c * plane + q.o_nw);
+                bot[c] = *(GlobalPtr<const Pair<T>>)(inp + c * plane + q.o_sw);
+              }
+            }
+            int stride;
+            const int cell = cell_of(d, q.ix_nw, q.iy_nw, stride);
+            if (DRTK_DBG(dbg, 1)) {
+            } else if (cell >= 0) {
+              double* wp = win + cell;
+#pragma unroll
+              for (int c = 0; c < kChBlock; ++c) {
+                if (c >= cc) break;
+                lds_add(wp + c * kWaveCells, static_cast<double>(q.nw * g[c]));
+                lds_add(wp + c * kWaveCells + 1, static_cast<double>(q.ne * g[c]));
+                lds_add(wp + c * kWaveCells + stride, static_cast<double>(q.sw * g[c]));
+                lds_add(wp + c * kWaveCells + stride + 1, static_cast<double>(q.se * g[c]));
+              }
+            } else if (i < 16) {
+              pending |= 1u << (2 * i + s);
+              note_miss(s, q.ix_nw, q.iy_nw);
+            } else {
+              const GlobalPtr<T> gp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C + c0) * plane);
+#pragma unroll
+              for (int c = 0; c < kChBlock; ++c) {
+                if (c >= cc) break;
+                atomic_add_g1(gp + c * plane + q.o_nw, q.nw * g[c]);
+                atomic_add_g1(gp + c * plane + q.o_ne, q.ne * g[c]);
+                atomic_add_g1(gp + c * plane + q.o_sw, q.sw * g[c]);
+                atomic_add_g1(gp + c * plane + q.o_se, q.se * g[c]);
+              }
+            }
+            const T fy1 = iy_se - q.iy, fy0 = q.iy - q.iy_nw, fx1 = ix_se - q.ix, fx0 = q.ix - q.ix_nw;
+#pragma unroll
+            for (int c = 0; c < kChBlock; ++c) {
+              if (c >= cc) break;
+              const T gOut = g[c];
+              // with a zero upstream gradient every term is +-0 * finite: the texels count as 0
+              const T v_nw = gOut != T(0) ? top[c].x : T(0), v_ne = gOut != T(0) ? top[c].y : T(0);
+              const T v_sw = gOut != T(0) ? bot[c].x : T(0), v_se = gOut != T(0) ? bot[c].y : T(0);
+              gix -= v_nw * fy1 * gOut;
+              giy -= v_nw * fx1 * gOut;
+              gix += v_ne * fy1 * gOut;
+              giy -= v_ne * fx0 * gOut;
+              gix -= v_sw * fy0 * gOut;
+              giy += v_sw * fx1 * gOut;
+              gix += v_se * fy0 * gOut;
+              giy += v_se * fx0 * gOut;
+            }
+          } else {
+            // a tap on the border of its level: corner by corner, straight to global memory (the reference's form)
+            const GlobalPtr<T> gp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C + c0) * plane);
+#pragma unroll 1
+            for (int c = 0; c < cc; ++c) {
+              const T gOut = g[c];
+              if (gOut == T(0)) continue; // every term below would be +-0 * finite
+              const GlobalPtr<const T> p = inp + c * plane;
+              T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
+              if (!DRTK_DBG(dbg, 2)) {
+                if (q.o_nw >= 0) v_nw = p[q.o_nw];
+                if (q.o_ne >= 0) v_ne = p[q.o_ne];
+                if (q.o_sw >= 0) v_sw = p[q.o_sw];
+                if (q.o_se >= 0) v_se = p[q.o_se];
+              }
+              if (!DRTK_DBG(dbg, 1)) {
+                if (q.o_nw >= 0) atomic_add_g1(gp + c * plane + q.o_nw, q.nw * gOut);
+                if (q.o_ne >= 0) atomic_add_g1(gp + c * plane + q.o_ne, q.ne * gOut);
+                if (q.o_sw >= 0) atomic_add_g1(gp + c * plane + q.o_sw, q.sw * gOut);
+                if (q.o_se >= 0) atomic_add_g1(gp + c * plane + q.o_se, q.se * gOut);
+              }
+              if (q.o_nw >= 0) {
+                gix -= v_nw * (iy_se - q.iy) * gOut;
+                giy -= v_nw * (ix_se - q.ix) * gOut;
+              }
+              if (q.o_ne >= 0) {
+                gix += v_ne * (iy_se - q.iy) * gOut;
+                giy -= v_ne * (q.ix - q.ix_nw) * gOut;
+              }
+              if (q.o_sw >= 0) {
+                gix -= v_sw * (q.iy - q.iy_nw) * gOut;
+                giy += v_sw * (ix_se - q.ix) * gOut;
+              }
+              if (q.o_se >= 0) {
+                gix += v_se * (q.iy - q.iy_nw) * gOut;
+                giy += v_se * (q.ix - q.ix_nw) * gOut;
+              }
+            }
+          }
+          acc_x += q.mx * gix;
+          acc_y += q.my * giy;
+        }
+      }
+    }
+    flush();
+    // ---- further rounds: the window moves onto the taps that are still pending (texture gradient only: the grid
+    // gradient of the block is complete); what is pending after the last round goes to global memory
+#ifndef DRTK_MIP_WAVE_ROUNDS
+#define DRTK_MIP_WAVE_ROUNDS 6
+#endif
+    for (int round = 1; __ballot(pending != 0) != 0 && !DRTK_DBG(dbg, 8); ++round) {
+      const bool last = round >= DRTK_MIP_WAVE_ROUNDS - 1;
+      place(miss, miss_x0, miss_y0, miss_x1, miss_y1);
+      miss[0] = miss[1] = false;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) miss_x0[k] = miss_y0[k] = INT32_MAX, miss_x1[k] = miss_y1[k] = INT32_MIN;
+      uint32_t todo = pending;
+      while (todo) {
+        const int bit = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int i = bit >> 1, s2 = bit & 1;
+        T x, y;
+        tap_xy(i, x, y);
+        const int d = t.d1 + s2;
+        const int h = s_h[d], w = s_w[d];
+        const int plane = h * w;
+        const T alpha = s2 == 0 ? alpha_2 : alpha_1;
+        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners); // (interior: only those are deferred)
+        int stride;
+        const int cell = cell_of(d, q.ix_nw, q.iy_nw, stride);
+        if (cell < 0 && !last) { // stays pending: the next round's window
+          note_miss(s2, q.ix_nw, q.iy_nw);
+          continue;
+        }
+        pending &= ~(1u << bit);
+        const GlobalPtr<T> gp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C + c0) * plane);
+#pragma unroll
+        for (int c = 0; c < kChBlock; ++c) {
+          if (c >= cc) break;
+          const T gc = go[c] * alpha;
+          if (cell >= 0) {
+            double* wp = win + cell + c * kWaveCells;
+            lds_add(wp, static_cast<double>(q.nw * gc));
+            lds_add(wp + 1, static_cast<double>(q.ne * gc));
+            lds_add(wp + stride, static_cast<double>(q.sw * gc));
+            lds_add(wp + stride + 1, static_cast<double>(q.se * gc));
+          } else {
+            atomic_add_g1(gp + c * plane + q.o_nw, q.nw * gc);
+            atomic_add_g1(gp + c * plane + q.o_ne, q.ne * gc);
+            atomic_add_g1(gp + c * plane + q.o_sw, q.sw * gc);
+            atomic_add_g1(gp + c * plane + q.o_se, q.se * gc);
+          }
+        }
+      }
+      flush();
+    }
+  }
+  if (valid) store_grid_grad<T>(grad_grid, ggl, n, pix, acc_x, acc_y);
+}
+
 int fill_table(
     LevelTable& lv, const void* const* levels, void* const* grad_levels, const int64_t* level_h,
     const int64_t* level_w, const int64_t* level_sN, int mipmaps, int64_t N, int64_t C) {
@@ -1242,6 +1620,33 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   GridLayout gl, ggl;
   if (make_grid_layout(gl, grid_layout, grid, H, W, es) != DRTK_OK || make_grid_layout(ggl, grad_grid_layout, grad_grid, H, W, es) != DRTK_OK)
     return DRTK_ERR_INVALID_ARGUMENT;
+  // bilinear f32: C <= 4 takes the workgroup-tiled kernel, wider textures (neural textures, 8-16 channels) the
+  // wave-private one in blocks of four channels -- before round 4 they fell to the direct kernel, bound by the float-atomic
+  // request rate.  (-DDRTK_MIP_BACKWARD_WAVE_ALL: the wave kernel for every C, for A/B; at C = 3 it is slower than the
+  // tiled one -- 2.52 against 1.95 ms on the textured benchmark at the same 3 waves per SIMD.)
+#ifdef DRTK_MIP_BACKWARD_WAVE_ALL
+  constexpr int64_t kWaveFromC = 1;
+#else
+  constexpr int64_t kWaveFromC = 5;
+#endif
+  if (interpolation_mode == 0 && C >= kWaveFromC && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
+    const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
+    const size_t lds = sizeof(double) * (C < kChBlock ? C : kChBlock) * kWaveCells * (kMipBlock / kWave);
+#define WAVEK(PAD, ALIGN)                                                                                               \
+  DRTK_LAUNCH(                                                                                                          \
+      (mipmap_backward_wave_kernel<float, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      dim3(kMipBlock), lds, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid), gl,  \
+      static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, force_max_aniso != 0,        \
+      clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
+    if (align_corners) {
+      if (padding_mode == 0) WAVEK(0, true); else if (padding_mode == 1) WAVEK(1, true); else WAVEK(2, true);
+    } else {
+      if (padding_mode == 0) WAVEK(0, false); else if (padding_mode == 1) WAVEK(1, false); else WAVEK(2, false);
+    }
+#undef WAVEK
+    DRTK_RETURN_IF_LAUNCH_FAILED();
+    return DRTK_OK;
+  }
   if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
 #define TILED(PAD, ALIGN)                                                                                                \

@@ -814,7 +814,9 @@ using TriOwn = TriRow<T>;
 
 // One step: every row shades the triangle `u` it was handed.  Coverage, depth and the packed atomicMin are the
 // reference's (rasterize_kernel.cu:117-161), evaluated per lane = per pixel.
-template <typename T, int TILE_SHIFT, bool EARLY_Z>
+// STRIDE = lanes that share the triangle: 16 (one DPP row per triangle, `lane16_half` = lane % 16 + 1/2) or the whole
+// workgroup (cooperative pass over a large triangle, `lane16_half` = thread id + 1/2).
+template <typename T, int TILE_SHIFT, bool EARLY_Z, int STRIDE = 16>
 __device__ __forceinline__ void shade_rows(
     const TriRow<T>& u, float lane16_half, float x0f, float y0f, unsigned long long* __restrict__ zbuf, int dbg) {
   constexpr float kTileF = static_cast<float>(1 << TILE_SHIFT);
@@ -840,7 +842,7 @@ __device__ __forceinline__ void shade_rows(
   const T b_min = u.abs_denom * T(0x1p-40);
   const unsigned long long id = static_cast<uint32_t>(u.id_tl) & ((1u << kTlShift) - 1u);
 #ifdef DRTK_AMD_ABLATION
-  if (DRTK_DBG(dbg, 512)) { // row balance of the steps: [10] += passes the wave runs (the longest row's), [11] += passes the four rows need together
+  if (STRIDE == 16 && DRTK_DBG(dbg, 512)) { // row balance of the steps: [10] += passes the wave runs (the longest row's), [11] += passes the four rows need together
     const int need = static_cast<int>((npxf + 15.0f) * 0.0625f);
     int mx = need;
 #pragma unroll
@@ -855,7 +857,7 @@ __device__ __forceinline__ void shade_rows(
     }
   }
 #endif
-  for (float ph = lane16_half; ph < npxf; ph += 16.0f) {
+  for (float ph = lane16_half; ph < npxf; ph += static_cast<float>(STRIDE)) {
     const float fly = __builtin_truncf(ph * rbw);
     const float flx = __builtin_fmaf(-fly, bwf, ph - 0.5f);
     const T px = static_cast<T>(bx0f + flx), py = static_cast<T>(by0f + fly);
@@ -889,7 +891,18 @@ __device__ __forceinline__ void shade_rows(
       d1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
       d2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
     }
+#ifdef DRTK_DEPTH_FASTMATH_ORDER
+    // Build variant (python drtk_amd/build.py --depth-order fastmath; never the default): the depth as the reference's
+    // host path evaluates it WHEN BUILT WITH ITS OWN FLAGS (setup.py:22-24: -O3 --fast-math, GCC 11.4 on x86-64; SURVEY
+    // App. A.1 step 8, from the disassembly): one IEEE reciprocal r = 1 / |den| per triangle and
+    // s = ((e1 dinv1 + e0 dinv0) + e2 dinv2) r  instead of three quotients e_k / |den| -- the last bits of 40 % of the
+    // depths move, and with them the owner of a handful of near-tie pixels per view
+    // (tests/golden/fastmath_owner_changes_*.npz).  No FMA there either.
+    (void)d0, (void)d1, (void)d2;
+    const T depth_inverse = ((b1 * u.dinv1 + b0 * u.dinv0) + b2 * u.dinv2) * u.rdenom;
+#else
     const T depth_inverse = u.dinv0 * d0 + u.dinv1 * d1 + u.dinv2 * d2;
+#endif
     // epsclamp (:153) of a value that cannot be negative: every d_k is a quotient of b_k >= 0 (the fragment passed the
     // coverage test) and abs_denom > 0, every dinv_k is 1 / z_k with z_k > 1e-8 (the near-plane cull, :96) -- so only the
     // `v > eps ? v : eps` branch of the clamp exists here (a NaN sum takes eps there as well)
@@ -938,6 +951,29 @@ constexpr int raster_waves_per_simd() { // double: twice the registers per value
   return sizeof(T) == 4 ? DRTK_RASTER_WAVES_PER_SIMD : 2;
 }
 constexpr int kIdRing = 128; // accepted triangle ids waiting for set-up, per wave (power of two, >= 2 * kWave - 1)
+// Cooperative pass.  A 16-lane row walks its triangle's clipped bbox 16 pixels a pass, whatever the size: a triangle that
+// fills the 64 x 64 tile is 256 passes on ONE row while -- in a tile that holds two or four such triangles and nothing
+// else (close-ups, low-poly meshes at high resolution, screen-filling quads) -- the other rows and the other seven waves
+// have nothing to do (round 4, profiles/r04/raster_regimes.json: 1.4-3.4x the bench scene's time per covered pixel).  A
+// triangle whose clipped bbox has at least kCoopMin pixels is therefore not queued in the wave's ring but in a list of
+// the workgroup, and after the rounds ALL waves shade it together, 512 pixels a pass, its row state -- set up once, by
+// one lane -- read from LDS.  Same fragments, same packed minimum: the image cannot change.
+#ifndef DRTK_RASTER_COOP_MIN
+#define DRTK_RASTER_COOP_MIN 256
+#endif
+#ifndef DRTK_RASTER_COOP_MIN_DENSE
+#define DRTK_RASTER_COOP_MIN_DENSE 1024
+#endif
+#ifndef DRTK_RASTER_COOP_DENSE
+#define DRTK_RASTER_COOP_DENSE 64
+#endif
+// ... where the rows would idle, that is: in a tile whose list is long (kCoopDense entries, both groups) the ordinary
+// path already keeps all 32 rows of the workgroup busy, and moving its larger triangles (the 600-pixel bounding boxes
+// at the centre of the benchmark's sphere) to the cooperative pass only adds the pass's own costs (measured: +12 % on
+// the bench scene with one threshold of 512 for every tile) -- there the threshold is kCoopMinDense.
+constexpr int kCoopMin = DRTK_RASTER_COOP_MIN, kCoopMinDense = DRTK_RASTER_COOP_MIN_DENSE, kCoopDense = DRTK_RASTER_COOP_DENSE;
+constexpr int kCoopBatch = 64; // triangles set up together, one per lane of the waves' first lanes, and parked in LDS
+constexpr int kCoopMax = 256; // entries per item and phase; what does not fit takes the ordinary path
 
 template <typename T, int TILE_SHIFT>
 __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile_raster_kernel(
@@ -956,6 +992,11 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
   __shared__ int32_t s_idk[kRasterWaves][kIdRing]; // ... and the size of what each will have to shade (sort key)
   __shared__ int s_item;
   __shared__ int s_queue[3];
+  __shared__ int32_t s_coop[kCoopMax];
+  __shared__ int s_ncoop;
+  constexpr int kTriWords = sizeof(TriRow<T>) / 4;
+  static_assert(sizeof(TriRow<T>) % 4 == 0, "TriRow is parked in LDS word by word");
+  __shared__ uint32_t s_tri[kCoopMin > 0 ? kCoopBatch * kTriWords : 1];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid & (kWave - 1);
@@ -977,6 +1018,7 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
   };
   if (tid == 0) {
     s_queue[0] = blockIdx.x % kQueueShards, s_queue[1] = 0;
+    s_ncoop = 0;
     pop();
   }
   for (int i = tid; i < NPIX; i += kRasterBlock) zbuf[i] = ~0ull; // rasterize_kernel.cu:484-488; every item leaves the tile cleared
@@ -1095,6 +1137,7 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
         int big_cursor = wave * big_per_wave;
         const int big_end = min(big_cursor + big_per_wave, phase == 0 ? nbig : 0);
         int head = 0, tail = 0; // ring positions (wave-uniform)
+        const int coop_min = end_all - begin >= kCoopDense ? kCoopMinDense : kCoopMin; // (the tile's whole list, both groups)
         if (DRTK_DBG(dbg, 8)) cursor = end, big_cursor = big_end;
         for (;;) {
           while (tail - head < kWave && (cursor < end || big_cursor < big_end)) {
@@ -1116,6 +1159,21 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
                 ok = tx >= rtx0 && tx <= rtx1 && ty >= rty0 && ty <= rty1 && pre_accept(f, size);
               }
               big_cursor += kWave;
+            }
+            if (kCoopMin > 0) { // large in this item's rectangle: to the workgroup's list (size == NPIX + 1: no record)
+              const bool coop = ok && size >= coop_min && size <= NPIX;
+              const unsigned long long mc = __ballot(coop);
+              if (mc != 0) {
+                const int leader = __builtin_ctzll(mc);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_ncoop, __popcll(mc));
+                base = __shfl(base, leader);
+                const int slot = base + mbcnt(mc);
+                if (coop && slot < kCoopMax) {
+                  s_coop[slot] = f;
+                  ok = false;
+                }
+              }
             }
             const unsigned long long m = __ballot(ok);
             if (ok) {
@@ -1180,6 +1238,52 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
           }
         }
         if (tid == 0) DRTK_PHASE(2 + 4 * phase); // wave 0's share of the group: 2 = first group, 6 = second
+        if (kCoopMin > 0) {
+          __syncthreads(); // every wave has screened its share: the list is complete
+          const int ncoop = min(s_ncoop, kCoopMax);
+          int t_here = tid;
+          asm volatile("" : "+v"(t_here)); // made here: hoisted out of the item loop, `first` holds a register for the whole kernel
+          const float x0f = static_cast<float>(x0), y0f = static_cast<float>(y0), first = static_cast<float>(t_here) + 0.5f;
+          for (int b0 = 0; b0 < ncoop; b0 += kCoopBatch) {
+            // set-up of a batch: wave w takes entries b0 + 8 w .. + 7, one per lane (every wave runs the set-up code once
+            // per batch instead of once per triangle); the row states are parked in LDS, from where every lane of the
+            // workgroup reads the triangle it is about to shade (one address per instruction: a broadcast)
+            if (b0 > 0) __syncthreads(); // the previous batch has been read
+            const int nb_here = min(kCoopBatch, ncoop - b0);
+            constexpr int kPerWave = kCoopBatch / kRasterWaves;
+            const int e = wave * kPerWave + lane;
+            if (lane < kPerWave && e < nb_here) {
+              const int f = s_coop[b0 + e];
+              const uint4 pre = pre_n[f];
+              TriSetup<T> s = {};
+              const bool valid = tri_setup<T>(v_n, vi_n + int64_t(f) * 3, H, W, s);
+              const TriRow<T> o = make_row_state<T>(valid, s, f, pre.z, x0, y0, x1, y1);
+              uint32_t w[kTriWords];
+              __builtin_memcpy(w, &o, sizeof(o));
+#pragma unroll
+              for (int j = 0; j < kTriWords; ++j) s_tri[e * kTriWords + j] = w[j];
+            }
+            __syncthreads();
+            for (int i = 0; i < nb_here; ++i) {
+              uint32_t w[kTriWords];
+#pragma unroll
+              for (int j = 0; j < kTriWords; ++j) w[j] = s_tri[i * kTriWords + j];
+              TriRow<T> u;
+              __builtin_memcpy(&u, w, sizeof(u));
+              if (!DRTK_DBG(dbg, 1)) {
+                if (phase == 0) {
+                  shade_rows<T, TILE_SHIFT, false, kRasterBlock>(u, first, x0f, y0f, zbuf, dbg);
+                } else {
+                  shade_rows<T, TILE_SHIFT, true, kRasterBlock>(u, first, x0f, y0f, zbuf, dbg);
+                }
+              }
+            }
+          }
+          if (ncoop > 0) {
+            __syncthreads(); // all reads of the list done before it is reset (the barriers below order the reset before the next pushes)
+            if (tid == 0) s_ncoop = 0;
+          }
+        }
         if (phase == 1) break;
         __syncthreads();
         if (tid == 0) DRTK_PHASE(4); // wave 0 waiting for the other waves' first group
@@ -1187,14 +1291,16 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
         // the maximum over each group of 8 lanes (xor 1, xor 2 within quads, mirror of the 8-lane half row: DPP, no LDS)
         for (int by = wave; by < nb; by += kRasterWaves) {
           uint32_t m = 0;
+          int l_here = lane;
+          asm volatile("" : "+v"(l_here)); // the LDS addresses below are made here (hoisted out of the item loop they are spilled)
           if (lane < ss) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) m = max(m, static_cast<uint32_t>(zbuf[(((by << 3) + r) << TILE_SHIFT) + lane] >> 32));
+            for (int r = 0; r < 8; ++r) m = max(m, static_cast<uint32_t>(zbuf[(((by << 3) + r) << TILE_SHIFT) + l_here] >> 32));
           }
           m = max(m, static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0xB1, 0xF, 0xF, true)));  // quad_perm [1,0,3,2]
           m = max(m, static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0x4E, 0xF, 0xF, true)));  // quad_perm [2,3,0,1]
           m = max(m, static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m), 0x141, 0xF, 0xF, true))); // row_half_mirror
-          if ((lane & 7) == 0 && lane < ss) s_zmax[by * nb + (lane >> 3)] = m;
+          if ((lane & 7) == 0 && lane < ss) s_zmax[by * nb + (l_here >> 3)] = m;
         }
         __syncthreads();
         if (tid == 0) DRTK_PHASE(5); // block-farthest reduction

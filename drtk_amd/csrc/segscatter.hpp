@@ -72,6 +72,24 @@ __device__ __forceinline__ int table_slot(int32_t* keys, int32_t vid) {
   return -1;
 }
 
+// The same with a table size chosen at run time (2^log2_slots entries): interpolate backward's workgroup-shared table,
+// whose rows hold all C components of a vertex and whose size follows from the LDS it may take.
+__device__ __forceinline__ int table_slot_rt(int32_t* keys, int32_t vid, int log2_slots) {
+  const uint32_t mask = (1u << log2_slots) - 1u;
+  uint32_t h = (static_cast<uint32_t>(vid) * 2654435761u) >> (32 - log2_slots);
+#pragma unroll 1
+  for (int probe = 0; probe < kTableProbes; ++probe) {
+    const int32_t cur = keys[h];
+    if (cur == vid) return static_cast<int>(h);
+    if (cur == -1) {
+      const int32_t old = atomicCAS(&keys[h], -1, vid);
+      if (old == -1 || old == vid) return static_cast<int>(h);
+    }
+    h = (h + 1) & mask;
+  }
+  return -1;
+}
+
 // heads  bit p set  <=>  pixel p starts a new run (p == 0 or triangle differs from pixel p-1)
 // cov    bit p set  <=>  pixel p is covered (index != -1); constant within a run
 // slot   LDS [3][kRunPad] table slot of every pixel's triangle corners (-1: use `vid` + global atomic)
@@ -96,11 +114,19 @@ using TableAcc = double;
 
 // A = type of the table entries: TableAcc where entries are updated with LDS atomics (J <= 32), or T itself where the
 // J > 32 path's plain read-modify-write applies (see `exclusive` below).
-template <typename T, typename A = TableAcc, typename Val4Fn>
+// WIDE_ONLY: always take the one-slice form (lanes j >= J idle), whatever J is -- for callers that cannot afford the
+// registers of both forms in one kernel.  SLICE_MAX_J: the sliced form for J <= SLICE_MAX_J only (interpolate backward's
+// wide kernel: 16 -- its 8-channel chunks, J = 24, measured faster on the one-slice form than in two slices of 32 pixels:
+// 0.53 vs 0.56 ms at C = 8; its 4-channel tails, J = 12, faster in four slices: 0.95 vs 1.00 ms at C = 20).
+// SHARED_TABLE: the table is shared by the waves of the workgroup -- its entries are updated with LDS atomics even on the
+// one-slice form (whose plain read-modify-write is only safe for a wave-private table); `tab_off` is added to the
+// component index of a table entry (a table whose rows hold all C_total components while the call scatters the chunk
+// that starts at c_base: tab_off = c_base).
+template <typename T, typename A = TableAcc, bool WIDE_ONLY = false, bool SHARED_TABLE = false, int SLICE_MAX_J = 32, typename Val4Fn>
 __device__ __forceinline__ void scatter_runs(
     unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
     int CC, A* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0,
-    int c_off = 0, int c_step = 1) {
+    int c_off = 0, int c_step = 1, int tab_off = 0) {
   const int lane = lane_id();
   using LdsPtr = __attribute__((address_space(3))) A*;
   // `exclusive`: no two lanes of one call target the same table entry (one run at a time, and the
@@ -114,18 +140,21 @@ __device__ __forceinline__ void scatter_runs(
     const int s = slot ? slot[k * kRunPad + start] : -1; // slot == nullptr: no table, always direct
     if (s < -1) return;                                   // -2: this corner receives nothing in this run
     if (s >= 0) {
-      if (exclusive) {
-        LdsPtr q = (LdsPtr)(vals + s * stride + c);
+      if (exclusive && !SHARED_TABLE) {
+        LdsPtr q = (LdsPtr)(vals + s * stride + tab_off + c);
         *q = *q + static_cast<A>(acc);
       } else {
-        lds_atomic_add(vals + s * stride + c, static_cast<A>(acc));
+        lds_atomic_add(vals + s * stride + tab_off + c, static_cast<A>(acc));
       }
     }
     if (s < 0) { // table full for this vertex: direct global atomic (rare)
+      // (rows of C_total elements that are not a multiple of 64 bytes -- C = 12, 24 -- make these atomics several times
+      // slower: interpolate backward's flush 0.51 ms at C = 12 against 0.125 at C = 16, 8 x 2048^2.  Sending the lanes of
+      // even and odd 64-byte segments in two instructions did not help (measured, round 4): it is not the straddling)
       atomic_add_global(dst_n + int64_t(vid[k * kRunPad + start]) * C_total + c_base + c, acc);
     }
   };
-  if (J > 32) {
+  if (WIDE_ONLY || J > SLICE_MAX_J) {
     // one slice of 64 pixels: run boundaries are wave-uniform -> scalar tests, no divergence
     for (int j0 = 0; j0 < J; j0 += kWave) {
       const int j = j0 + lane;

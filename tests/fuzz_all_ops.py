@@ -27,13 +27,22 @@ def _close(a, ref, what, atol=1e-5, rtol=1e-5):
     assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
 
 
-def make_case(seed):
+# channel counts of the wide interpolate-backward path (any C % 4 == 0, C >= 8: chunks of 16 + a tail of 4 / 8 / 12) and
+# their neighbours; drawn instead of the list below with `make_case(seed, wide_channels=True)` / `--wide-channels`.  A
+# separate list so that the cases of the plain seeds -- among them the harvested regression seeds of
+# test_edge_grad_sign_decisions_at_near_parallel_normals_follow_the_reference -- stay what they were.
+WIDE_CHANNELS = [8, 12, 16, 20, 24, 28, 32, 36, 48, 64, 7, 13, 18, 30]
+
+
+def make_case(seed, wide_channels=False):
     g = th.Generator().manual_seed(seed)
     r = lambda lo, hi: int(th.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
     N = r(1, 3)
     H = [1, 2, 7, 16, 17, 33, 64, 65, 100, 129, 200][r(0, 10)]
     W = [1, 3, 4, 5, 8, 63, 64, 66, 100, 127, 130, 256, 258, 323][r(0, 13)]
     C = [1, 2, 3, 4, 5, 8, 15, 16, 17, 32, 33][r(0, 10)]
+    if wide_channels:
+        C = WIDE_CHANNELS[int(th.randint(0, len(WIDE_CHANNELS), (1,), generator=th.Generator().manual_seed(seed + 77)))]
     dtype = th.float64 if r(0, 3) == 0 else th.float32
     kind = r(0, 2)
     if kind == 0:  # triangle soup with overdraw, slivers, ties
@@ -129,10 +138,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--wide-channels", action="store_true", help="channel counts from WIDE_CHANNELS (8 ... 64)")
     a = ap.parse_args()
     bad = 0
     for seed in range(a.first, a.first + a.cases):
-        c = make_case(seed)
+        c = make_case(seed, wide_channels=a.wide_channels)
         try:
             run_case(c)
         except AssertionError as e:

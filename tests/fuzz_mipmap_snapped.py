@@ -15,6 +15,7 @@ import torch as th  # noqa: E402
 
 import fuzz_all_ops as FA  # noqa: E402,F401  (import paths)
 import oracle as O  # noqa: E402
+from f64_distance import assert_within_f64_distance  # noqa: E402
 from drtk_amd import capi  # noqa: E402
 
 DEV = "cuda:0"
@@ -57,21 +58,17 @@ def run_case(c):
                 wl, wg = O.mipmap_grid_sampler_2d_backward(c["gout"], c["levels"], c["grid"], c["jac"], *args)
                 gl, gg = capi.mipmap_grid_sampler_2d_backward(d(c["gout"]), [d(t) for t in c["levels"]], d(c["grid"]), d(c["jac"]), *args)
                 FA._close(gg, wg, f"grad grid padding={padding} mode={mode} flags={align, force, clip}", atol=1e-4)
-                # level gradients are sums of thousands of signed terms per texel on the coarse levels (a 2x1 level
-                # collects every tap of every pixel): f32 accumulation noise scales with what was SUMMED, not with the
-                # result, which cancellation makes small -- so a few ulps of the accumulated magnitude (the oracle's
-                # backward of |grad_out|) are allowed on top of the 1e-5 bar.  A flipped cell / tap count is 0.1 - 1.
+                # level gradients: against the same sums carried in double, as near as the oracle's own float32 run up to a
+                # factor (tests/f64_distance.py).  A coarse level is a handful of texels that each collect thousands of
+                # signed terms (a 1 x 1 level: every tap of every pixel), so the magnitude that was ACCUMULATED -- the
+                # oracle's backward of |grad_out| -- enters the bound as well; a flipped cell / tap count is 0.1 - 1.
+                # (The inputs are exactly representable, so the double run takes the same cells and tap counts.)
                 al, _ = O.mipmap_grid_sampler_2d_backward(c["gout"].abs(), c["levels"], c["grid"], c["jac"], *args)
-                # ... and the oracle's OWN float32 evaluation sits that far from the same sums carried in double (the
-                # inputs are exactly representable, so the double run takes the same cells and tap counts): seed 340826,
-                # bicubic, a 1x1 level collecting 874 pixels x 4 taps x 16 weights: oracle f32 vs f64 6.5e-5, kernel vs
-                # oracle f32 6.9e-5 against 6.8e-5 from the magnitude term alone -- twice that distance is allowed too
                 dd = lambda t: t.double()  # noqa: E731
                 wl64, _ = O.mipmap_grid_sampler_2d_backward(dd(c["gout"]), [dd(t) for t in c["levels"]], dd(c["grid"]), dd(c["jac"]), *args)
                 for k, (a, b) in enumerate(zip(gl, wl)):
-                    own = float((b.double() - wl64[k]).abs().max())
-                    FA._close(a, b, f"grad level {k} padding={padding} mode={mode} flags={align, force, clip}",
-                              atol=1e-5 + max(4e-7 * float(al[k].abs().max()), 2.0 * own))  # (3e-7 until seed 4385, bicubic, direct kernel: a 1x1 level at 1.18x that bound)
+                    assert_within_f64_distance(a, b, wl64[k], f"grad level {k} padding={padding} mode={mode} flags={align, force, clip}",
+                                               acc_magnitude=float(al[k].abs().max()))
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -15,6 +15,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 
 DEV = "cuda:0"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from f64_distance import assert_within_f64_distance  # noqa: E402
+
+# screen_space_uv_derivative: quantiles of the per-pixel error against the double result, the kernel's within this factor
+# of the reference composite's own (the same principle as tests/f64_distance.py, on a distribution instead of a maximum;
+# measured over 197 cases the log10 ratio of the two 90 % quantiles has 1 % / 99 % points -0.28 / +0.51: hence 4, not 3)
+K_F64 = 4.0
 
 
 def _close(a, ref, what, atol=1e-5, rtol=1e-5):
@@ -95,17 +102,21 @@ def run_case(c):
     M = drtk_amd.interpolation_normal_matrix(dvi, dindex, dbary, V)  # pattern built on the device
     assert th.equal(M.crow_indices().cpu(), ncrow_o) and th.equal(M.col_indices().cpu(), ncol_o), "A^T A pattern"
     nv_o = O.normal_matrix_values(pair_o, index, bary, nnz)
-    tol = dict(atol=1e-12, rtol=1e-10) if f64 else dict(atol=1e-5, rtol=1e-5)
-    if not f64:
-        # An entry of A^T A sums one product per pixel of the triangles around a vertex pair -- with a dozen vertices on a
-        # 64 x 127 canvas that is up to N*H*W ~ 24 000 float32 terms, and two float32 summations of that many terms in
-        # different orders (the oracle's loop, the kernel's atomics; the reference's CUDA kernel is a third) differ by
-        # ~ sqrt(terms) * eps of the sum: seed 202311 came out at 1.02e-5 of max|ref| against the flat 1e-5.  The bound
-        # follows the number of terms, and the comparison is against the same sums carried in double.
-        nv_o = O.normal_matrix_values(pair_o, index, bary.double(), nnz).to(dtype)
-        tol = dict(atol=1e-5, rtol=max(1e-5, 4 * 6e-8 * float(N * index.shape[-2] * index.shape[-1]) ** 0.5))
-    _close(M.values(), nv_o, "A^T A values (python api)", **tol)
-    _close(capi.interpolation_normal_matrix_values(d(pair_o), dindex, dbary, nnz), nv_o, "A^T A values", **tol)
+    if f64:
+        tol = dict(atol=1e-12, rtol=1e-10)
+        _close(M.values(), nv_o, "A^T A values (python api)", **tol)
+        _close(capi.interpolation_normal_matrix_values(d(pair_o), dindex, dbary, nnz), nv_o, "A^T A values", **tol)
+    else:
+        # An entry of A^T A sums one product per pixel of the triangles around a vertex pair -- up to N*H*W float32 terms,
+        # and two float32 summations of that many terms in different orders (the oracle's loop, the kernel's atomics; the
+        # reference's CUDA kernel is a third) differ by ~ sqrt(terms) * eps of the sum (seed 202311: 1.02e-5 of max|ref|).
+        # So: against the same sums carried in double, as near as the oracle's own float32 loop up to a factor
+        # (tests/f64_distance.py); every term is a product of non-negative barycentrics, so what was accumulated is the
+        # entry itself.
+        nv_64 = O.normal_matrix_values(pair_o, index, bary.double(), nnz)
+        acc = float(nv_64.abs().max()) if nv_64.numel() else 0.0
+        assert_within_f64_distance(M.values(), nv_o, nv_64, "A^T A values (python api)", acc_magnitude=acc)
+        assert_within_f64_distance(capi.interpolation_normal_matrix_values(d(pair_o), dindex, dbary, nnz), nv_o, nv_64, "A^T A values", acc_magnitude=acc)
     tol = dict(atol=1e-12, rtol=1e-10) if f64 else dict(atol=1e-5, rtol=1e-5)
     gnm = (th.rand(nnz, generator=g, dtype=th.float64) * 2 - 1).to(dtype)
     _close(capi.interpolation_normal_matrix_values_backward(d(gnm), d(pair_o), dindex, dbary), O.normal_matrix_values_backward(gnm, pair_o, index, bary),
@@ -150,7 +161,7 @@ def run_case(c):
         # pixels, kernel 1.11e-6, the previous kernel 1.13e-6 -- the median IS a face's rounding error, and the bar is the
         # composite's own median on the same pixels)
         med_g, med_r = float(rg.median()), float(rr.median())
-        assert med_g <= max(1e-6, 4 * med_r), f"screen_space_uv_derivative (f32): median relative error {med_g:.3e}, the composite's {med_r:.3e}"
+        assert med_g <= max(1e-6, K_F64 * med_r), f"screen_space_uv_derivative (f32): median relative error {med_g:.3e}, the composite's {med_r:.3e}"
         # The rounding error of the two inverses is a property of the FACE (its Jacobians are per-face constants), shared
         # by all of its pixels: the sample behind a quantile over pixels is the number of faces.  Seed 12589: 595 pixels
         # on 18 faces, one face with 13 % of them where the composite happened to land 15x closer -- the kernel's median
@@ -159,7 +170,7 @@ def run_case(c):
         # tests/diag_uv_derivative_accuracy.py).  So the quantile is compared only where enough faces stand behind it.
         if int(index[mask].unique().numel()) >= 40:
             q90g, q90r = float(th.quantile(rg, 0.9)), float(th.quantile(rr, 0.9))
-            assert q90g <= 4 * q90r + 1e-6, f"screen_space_uv_derivative (f32): 90 % quantile of the relative error {q90g:.3e}, the composite's {q90r:.3e}"
+            assert q90g <= K_F64 * q90r + 1e-6, f"screen_space_uv_derivative (f32): 90 % quantile of the relative error {q90g:.3e}, the composite's {q90r:.3e}"
 
 
 def describe(c):

@@ -4,9 +4,15 @@ and through the torch operators, against the committed reference fixtures and th
 Bars: index_img and rasterize depth bit-exact; every other float within
 |d| <= 1e-5 + 1e-5 * max|ref| per tensor (SURVEY.md §7 hard part 3), upstream gradients O(1).
 """
+import os
+import sys
+
 import pytest
 import torch as th
+from conftest import GOLDEN as GOLDEN_DIR
 from conftest import GOLDEN_SCENES, SPARSE_SCENES, load_golden, load_sparse
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -422,6 +428,38 @@ def test_full_size_index_img_and_the_committed_fast_math_owner_changes(mesh):
     assert float(rel.max()) <= 4 * 2.0 ** -23 and float(z["max_rel_depth_difference"]) <= 4e-7
 
 
+@pytest.mark.parametrize("mesh", ["100k", "250k"])
+def test_depth_fastmath_variant_reproduces_the_reference_as_built(mesh):
+    """The offered build variant (drtk_amd/libdrtk_amd_depth_fastmath.so, capi.use_depth_order("fastmath")): index_img of a
+    full benchmark view equals the image of the reference compiled with its own `-O3 --fast-math` at ZERO differing
+    pixels (SHA-256 of the committed fixture; the listed owner changes are reproduced one by one), where the default
+    library is the strict image.  Runs in a child process: a process binds one library."""
+    import subprocess
+
+    code = f"""
+import hashlib, sys
+import numpy as np, torch as th
+sys.path.insert(0, {ROOT!r})
+from drtk_amd import capi, synthetic as S
+capi.use_depth_order("fastmath")
+z = np.load({GOLDEN_DIR!r} + "/fastmath_owner_changes_{mesh}.npz")
+res = int(z["res"])
+nl, no = S.MESH_SIZES[{mesh!r}]
+_, vi = S.uv_sphere(nl, no, lobes=0.05)
+v = th.from_numpy(z["v"])[None].cuda()
+d, i = capi.rasterize(v, vi.cuda(), res, res)
+i, d = i.cpu(), d.cpu()
+sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+px = th.from_numpy(z["pixels"])
+diff = int((i.flatten()[px] != th.from_numpy(z["index_fast"])).sum())
+print("RESULT", sha(i) == str(z["sha256_index_fast"]), diff, bool(th.equal(d.flatten()[px], th.from_numpy(z["depth_fast"]))), int((i >= 0).sum()) == int(z["covered"]))
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+    assert line[1:] == ["True", "0", "True", "True"], f"index hash equal / differing listed pixels / depths at them equal / coverage equal: {line[1:]}"
+
+
 def rel_at(mask, a, b):
     if not bool(mask.any()):
         return th.zeros(())
@@ -750,6 +788,56 @@ def test_randomised_shapes(block):
             F.run_case(c)
         except AssertionError as e:
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_randomised_shapes_wide_channel_counts(block):
+    """24 seeded cases per block of the same fuzzer with the channel count drawn from 8 ... 64 (multiples of 4 -- the wide
+    interpolate-backward path with its 4 / 8 / 12-channel tails -- and their odd neighbours, which take the generic
+    kernel): all three gradient requests (both, attributes only, barycentrics only) against the oracle."""
+    import fuzz_all_ops as F
+
+    for seed in range(900 + 24 * block, 900 + 24 * block + 24):
+        c = F.make_case(seed, wide_channels=True)
+        try:
+            F.run_case(c)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
+
+
+@pytest.mark.parametrize("C", [8, 12, 16, 20, 24, 32, 64])
+@pytest.mark.parametrize("width", [320, 203])
+def test_interpolate_backward_channel_counts_and_gradient_requests(C, width):
+    """interpolate backward at every chunking of the wide path (16 / 16+4 / 16+8 / 2 x 16 / 4 x 16, a lone 8 or 12) for
+    the three gradient requests the reference instantiates (interpolate_kernel.cu:610-639: attributes and barycentrics,
+    attributes only, barycentrics only) against the oracle at the 1e-5 bar; the bary gradient's channel order is the
+    reference's, so with the attribute gradient left out it is compared at 1e-6 of its magnitude.  Width 320 takes the
+    vector paths, 203 the scalar ones."""
+    import oracle as O
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+
+    n, H = 2, 256
+    v, vi = S.sphere_views(n, 40, 44, H, width, second_sphere=True)
+    g = th.Generator().manual_seed(C)
+    attr = th.rand(n, v.shape[1], C, generator=g)
+    go = th.rand(n, C, H, width, generator=g) * 2 - 1
+    _, i_o = O.rasterize(v, vi, H, width, nthreads=0)
+    _, rb_o = O.render(v, vi, i_o, nthreads=0)
+    ag_o, bg_o = O.interpolate_backward(go, attr, vi, i_o, rb_o)
+    args = (dev(go), dev(attr), dev(vi), dev(i_o), dev(rb_o))
+    ag, bg = capi.interpolate_backward(*args, True, True)
+    close(ag, ag_o, f"attr grad C={C}")
+    close(bg, bg_o, f"bary grad C={C}")
+    ag1, none = capi.interpolate_backward(*args, True, False)
+    assert none is None
+    close(ag1, ag_o, f"attr grad (alone) C={C}")
+    none, bg1 = capi.interpolate_backward(*args, False, True)
+    assert none is None
+    close(bg1, bg_o, f"bary grad (alone) C={C}")
+    for got in (bg, bg1):  # per-pixel sums in the reference's order: far inside the bar
+        assert float((got.cpu() - bg_o).abs().max()) <= 1e-6 * float(bg_o.abs().max())
+    assert float(bg.cpu()[(i_o == -1)[:, None].expand_as(bg_o)].abs().sum()) == 0.0  # background written as exact zeros
 
 
 def test_rasterize_large_random_scenes_are_bit_exact():
