@@ -27,7 +27,7 @@ def _out(*shape, dtype, device):
     """Output / workspace allocation of this binding: uninitialised memory -- or, with DRTK_CAPI_POISON=1 in the
     environment (the fuzzers and the GPU suite set it), memory pre-filled with NaN / a large negative integer / 0xA5
     bytes, so that an element a kernel forgot to write cannot pass for a value (freshly allocated device memory reads as
-    zeros, which is a plausible image)."""
+    zeros, which is a plausible image; see profiles/NOTES.md 3.1, round 3)."""
     t = th.empty(*shape, dtype=dtype, device=device)
     if _POISON and t.numel():
         if t.dtype.is_floating_point:

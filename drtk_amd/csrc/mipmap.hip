@@ -214,7 +214,7 @@ __device__ __forceinline__ Taps<T> setup_taps(
   T dudx = uv.dudx, dvdx = uv.dvdx, dudy = uv.dudy, dvdy = uv.dvdy;
   // footprint lengths (:455-456, written with pow there): sqrt(a*a + b*b + 1e-12) with IEEE multiply and
   // sqrt -- the tap count below is a discontinuous function of them, so they are evaluated in the one
-  // form that is bit-reproducible everywhere
+  // form that is bit-reproducible everywhere (profiles/NOTES.md §3.7)
   const T ax = fabs(dudx * inp_W), bx = fabs(dvdx * inp_H);
   const T ay = fabs(dudy * inp_W), by = fabs(dvdy * inp_H);
   const T px = sqrt_rn(ax * ax + bx * bx + 1e-12f);
@@ -688,6 +688,15 @@ constexpr int kWinCells = win_cells_before(kWinLevels);
 // Measured dead end: the same LDS split 2048 / 768 / 256 cells over the levels with every window shaped like its tile's
 // bounding box -- 1-4 % (6.06 -> 6.02 ms at 1 texel/px, 11.5 -> 11.0 at 4), one outlier pixel stretches the box.
 
+// Round 4, where the time is WITHOUT the scatter (ablation flags 16 = no grid-gradient products, 32 = no tap loop at all, on
+// top of 1 / 2 / 4 / 8; textured benchmark, 1.96 ms with the 0.14 ms zero-fill of the pyramid): no accumulation, texel reads,
+// flush or rounds 1.02; also no grid-gradient products 0.95; no tap loop at all 0.75 -- of which 0.14 the fill and 0.3 the
+// 1.5 GB of upstream gradient, uv, Jacobian and grid gradient at stream speed.  Two structural variants were measured
+// against that and NOT kept: wave-private windows without any workgroup barrier (mipmap_backward_wave_kernel below; same
+// 3 waves per SIMD, same 1.0 ms floor, 2.52 vs 1.95 ms at C = 3: the floor is per-(tap, level) arithmetic and the stream,
+// not barriers), and persistent workgroups that request the next tile's upstream gradient before working on the current
+// one (2.20 vs 1.96 ms; the floor with no tap loop rose from 0.75 to 0.98: the hardware's own workgroup dispatch balances
+// the mix of background and silhouette tiles better than a static stride, and the job loop costs registers).
 // PAD / ALIGN: padding mode and align_corners as compile-time constants (the coordinate pipeline of every tap branches on
 // them: SQ counters of the runtime-parameter version showed 490 scalar and 950 vector instructions per wave).
 template <typename T, int PAD, bool ALIGN>

@@ -936,8 +936,8 @@ __device__ __forceinline__ void raster_rows(
 }
 
 // 8 waves per workgroup share one 32 KiB tile.  Registers: the lane's own triangle (19) + the row's triangle (19) + the
-// pixel loop; bounded to 80 VGPRs = 3 workgroups = 24 waves per CU (what spills at that bound is per-ITEM state: a few
-// scratch accesses per tile, none inside the step or pixel loops).
+// pixel loop; bounded to 80 VGPRs = 3 workgroups = 24 waves per CU, WITHOUT spills (the build fails on one: item-level
+// constants that the compiler hoists out of the item loop are rematerialised behind `asm volatile("" : "+v")`).
 #ifndef DRTK_RASTER_WAVES_PER_SIMD
 #define DRTK_RASTER_WAVES_PER_SIMD 6
 #endif
@@ -947,8 +947,8 @@ __device__ __forceinline__ void raster_rows(
 constexpr int kRasterBlock = DRTK_RASTER_BLOCK;
 constexpr int kRasterWaves = kRasterBlock / kWave;
 template <typename T>
-constexpr int raster_waves_per_simd() { // double: twice the registers per value -> 2 workgroups per CU, no spilling
-  return sizeof(T) == 4 ? DRTK_RASTER_WAVES_PER_SIMD : 2;
+constexpr int raster_waves_per_simd() { // double: twice the registers per value (134 VGPRs) -> ONE workgroup (2 waves per
+  return sizeof(T) == 4 ? DRTK_RASTER_WAVES_PER_SIMD : 2; // SIMD) per CU; bounded to 128 for two it spills
 }
 constexpr int kIdRing = 128; // accepted triangle ids waiting for set-up, per wave (power of two, >= 2 * kWave - 1)
 // Cooperative pass.  A 16-lane row walks its triangle's clipped bbox 16 pixels a pass, whatever the size: a triangle that

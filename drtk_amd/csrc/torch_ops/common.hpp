@@ -66,7 +66,7 @@ inline ViArg prep_vi(const Tensor& vi) {
 // Output allocation of the shim: uninitialised memory, or -- with DRTK_CAPI_POISON=1 in the environment, which the test
 // suite and the fuzzers set -- memory pre-filled with NaN / a large negative integer / 0xA5 bytes, so that an element a
 // kernel forgot to write cannot pass for a value (freshly allocated device memory reads as zeros, a plausible image:
-// DESIGN.md 3.1, round 3).  The product never pays for it: one getenv at load time.
+// profiles/NOTES.md 3.1, round 3).  The product never pays for it: one getenv at load time.
 inline const bool g_poison_outputs = [] {
   const char* e = std::getenv("DRTK_CAPI_POISON");
   return e && e[0] && !(e[0] == '0' && !e[1]);

@@ -50,8 +50,12 @@ __global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
     // one reciprocal per 2x2 inverse / per perspective divide instead of four (two) IEEE divisions: the reference's own
     // inverse is an LU solve, so neither form reproduces its roundings -- the bar of this operator is the f64 fixture
     // and the f32 error quantiles (tests/fuzz_next_ops.py), and a float division is a ten-instruction sequence
+    // (below ~1e-30 -- 1e-200 in double -- the reciprocal itself overflows where the quotients may still be finite: true
+    // divisions there; a wave takes that path only if one of its faces is that degenerate)
+    const T kTinyDet = sizeof(T) == 4 ? T(1e-30) : T(1e-200);
     const T rdet = T(1) / det;
-    const T i00 = d * rdet, i01 = -b * rdet, i10 = -c * rdet, i11 = a * rdet; // inverse(dtdb_t)
+    T i00 = d * rdet, i01 = -b * rdet, i10 = -c * rdet, i11 = a * rdet; // inverse(dtdb_t)
+    if (fabs(det) < kTinyDet) i00 = d / det, i01 = -b / det, i10 = -c / det, i11 = a / det;
     T dpdt[2][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
     o01 = -J[0][1] * rdj;
     o10 = -J[1][0] * rdj;
     o11 = J[0][0] * rdj;
+    if (fabs(dj) < kTinyDet) o00 = J[1][1] / dj, o01 = -J[0][1] / dj, o10 = -J[1][0] / dj, o11 = J[0][0] / dj;
   }
   T* o = out + (int64_t(n) * HW + pix) * 4;
   if constexpr (sizeof(T) == 4) {

@@ -1,7 +1,7 @@
 """`capture_step` -- one training step as a HIP graph.
 
 Every kernel of the library is capture-safe by construction (no synchronisation, no host read of device data, grids
-from static sizes, zero-fills done by kernels -- DESIGN.md "Graph capture"), so a whole step -- transform ->
+from static sizes, zero-fills done by kernels -- DESIGN.md section 1, profiles/NOTES.md "Graph capture"), so a whole step -- transform ->
 rasterize -> render -> interpolate -> shading -> edge_grad_estimator -> loss -> backward -- can be recorded once with
 torch's whole-network capture recipe and replayed.  That pays where the step is bound by launches rather than by the
 GPU: 4 views of a 10k-triangle mesh at 512 x 512 take 0.48 ms eagerly (25 launches, ~0.25 ms of kernels) and 0.27 ms

@@ -42,7 +42,7 @@
  *     build is -O3 --fast-math (setup.py:23-24), the CUDA build normalises with ::rnorm3df where the host divides by
  *     sqrt (cuda_math_helper.h:173-176).  Expect differences of 2 * max_dp_dr at a few such silhouette pixels when
  *     comparing against those (about 1 in 150 of the small two-object float32 test scenes has one); against the
- *     strict evaluation there are none.
+ *     strict evaluation there are none (profiles/NOTES.md section 3).
  *   - thread-safety: re-entrant; no global mutable state.
  */
 #ifndef DRTK_AMD_H
@@ -249,7 +249,7 @@ int drtk_amd_mipmap_grid_sampler_2d_backward(
  * drtk/utils/geometry.py:71-82, th.inverse) and raises for the whole call, visible face or not.  This kernel works
  * per pixel: pixels of such a face get the non-finite quotients of that zero determinant, every other pixel is
  * unaffected.  In float32 the two 2x2 inverses are ill-conditioned for triangles seen edge-on; accuracy there is
- * that of the reference's float32 composite, not 1e-5.
+ * that of the reference's float32 composite, not 1e-5 (profiles/NOTES.md section 4).
  * Forward only.  (The reference composite looks differentiable but is not: it masks the output of linalg.inv_ex in
  * place, drtk/screen_space_uv_derivative.py:79, and backward() through it raises -- recorded from the reference in
  * tests/golden/refpy_uv_derivative_autograd.npz; its consumer, mipmap_grid_sampler_2d, defines no gradient for this

@@ -1,4 +1,4 @@
-# Re-measures DESIGN.md section 5's table of the other BASELINE.json configurations (parity cases, not bench lines):
+# Re-measures the table of profiles/NOTES.md section 5 of the other BASELINE.json configurations (parity cases, not bench lines):
 # one bench.py run each, 10 timed steps, CPU-baseline leg skipped.  One JSON line per row in gpurun_out/configs/.
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT

@@ -1,7 +1,7 @@
 """Every op of tests/fuzz_all_ops.py (forward bits, gradients at the 1e-5 bar, both edge-grad routes at max_dp_dr = 1e4
 and 0.5) on LARGE two-object scenes: two intersecting lobed spheres at 512^2 - 1024^2 (and awkward aspect ratios),
 3e3 - 6e4 triangles, 1-2 views; thousands of intersection pixels with |dp/dr| > 100 per case.  A parity check at scale.
-It is NOT a test of the square-root correction: measured, the library with the old native root
+It is NOT a test of the square-root correction (profiles/NOTES.md section 3): measured, the library with the old native root
 passes these scenes too (60/60) -- a sign decided by rounding needs a pair of faces whose projected normals are parallel
 up to rounding, which more pixels do not produce; the small low-poly scenes of fuzz_all_ops do (11 cases in 9000), and
 test_edge_grad_sign_decisions_at_near_parallel_normals_follow_the_reference pins those.

@@ -458,7 +458,7 @@ def test_tap_count_at_near_isotropic_footprints_follows_the_reference():
     """The anisotropic tap count is a DISCONTINUOUS function of the two footprint lengths (sqrt of a sum of squares
     each): with a square root that is only 1 ulp accurate (`__fsqrt_rn` = the native root on this toolchain) two
     lengths that round to the same float can come out different, the ratio leaves 1 and the kernel takes 2 taps where
-    the reference takes 1.  sqrt, /, ceil are IEEE on both sides now; the level selection, by
+    the reference takes 1.  sqrt, /, ceil are IEEE on both sides now (profiles/NOTES.md section 3); the level selection, by
     contrast, is continuous across integer levels (floor + blend weight) and needs no such care."""
     import oracle as O
     from drtk_amd import capi

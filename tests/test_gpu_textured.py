@@ -10,7 +10,7 @@ Stage by stage, every stage fed with identical inputs on both sides (so that a d
 owner, a tap count -- cannot turn into an O(1) difference downstream and hide or fake an error):
   * index_img bit-exact; barycentrics and the uv image bit-identical (same operations, same order);
   * uv Jacobian: kernel (closed form) vs the reference's composite as restated by the oracle -- equal to rounding
-    except where a triangle is seen edge-on and the 2x2 inverse is ill-conditioned in f32: a robust bar
+    except where a triangle is seen edge-on and the 2x2 inverse is ill-conditioned in f32 (profiles/NOTES.md 4): a robust bar
     (median and 99 % quantile of the relative difference, share of pixels beyond 1e-3);
   * sampler forward on the kernel's Jacobian: 1e-5; whole-pipeline loss; gradients wrt the projected vertices, the uv
     attributes and EVERY mip level: 1e-5 + 1e-5 * max|ref|.
