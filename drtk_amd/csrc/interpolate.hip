@@ -74,16 +74,31 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
   T bgx[VEC];
   // "undefined region" sweep (interpolate_kernel.cu:104-108, CPU twin interpolate_kernel_cpu.cpp:99-104)
   const T bgy = (static_cast<T>(y) * T(2.0) + T(1.0)) / static_cast<T>(H) - T(1.0);
+  // corner ids of the lane's pixels: UNCONDITIONAL loads (a background pixel reads face 0 and discards it) so that the
+  // VEC x 3 of them form one batch -- under `if (covered)` every pixel's three loads sat in their own exec-masked region
+  // with an s_waitcnt behind them: four dependent round trips per lane before the first attribute row was requested
+  // (a lane with no covered pixel loads nothing -- with F = 0 there is no face to read --; in a lane that has one, its
+  // background pixels read that pixel's triangle)
+  int32_t t_any = tr[0];
+#pragma unroll
+  for (int j = 1; j < VEC; ++j) t_any = max(t_any, tr[j]);
+  const bool any_cov = t_any != -1;
+  int32_t fid[VEC][3];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) fid[j][0] = fid[j][1] = fid[j][2] = 0;
+  if (any_cov) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int32_t* face = vi_n + int64_t(tr[j] != -1 ? tr[j] : t_any) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fid[j][k] = face[k];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    if (tr[j] != -1) {
-      const int32_t* face = vi_n + int64_t(tr[j]) * 3;
-      a0[j] = attrs_n + int64_t(face[0]) * C;
-      a1[j] = attrs_n + int64_t(face[1]) * C;
-      a2[j] = attrs_n + int64_t(face[2]) * C;
-    } else {
-      a0[j] = a1[j] = a2[j] = attrs_n;
-    }
+    a0[j] = attrs_n + int64_t(fid[j][0]) * C;
+    a1[j] = attrs_n + int64_t(fid[j][1]) * C;
+    a2[j] = attrs_n + int64_t(fid[j][2]) * C;
     bgx[j] = (static_cast<T>(x0 + j) * T(2.0) + T(1.0)) / static_cast<T>(W) - T(1.0);
   }
 
@@ -140,22 +155,28 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
   }
   for (int c0 = 0; c0 < C; c0 += CV) {
     T r[CV][VEC];
+    // the block's attribute rows of all the lane's pixels first (unconditional: a background pixel reads vertex 0), the
+    // products after: one round trip per channel block instead of one per pixel
+    T u0[VEC][CV], u1[VEC][CV], u2[VEC][CV];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (!any_cov) break;
+      if constexpr (CV == 4) {
+        const V4 q0 = *reinterpret_cast<const V4*>(a0[j] + c0);
+        const V4 q1 = *reinterpret_cast<const V4*>(a1[j] + c0);
+        const V4 q2 = *reinterpret_cast<const V4*>(a2[j] + c0);
+        u0[j][0] = q0.x, u0[j][1] = q0.y, u0[j][2] = q0.z, u0[j][3] = q0.w;
+        u1[j][0] = q1.x, u1[j][1] = q1.y, u1[j][2] = q1.z, u1[j][3] = q1.w;
+        u2[j][0] = q2.x, u2[j][1] = q2.y, u2[j][2] = q2.z, u2[j][3] = q2.w;
+      } else {
+        u0[j][0] = a0[j][c0], u1[j][0] = a1[j][c0], u2[j][0] = a2[j][c0];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       if (tr[j] != -1) {
-        T u0[CV], u1[CV], u2[CV];
-        if constexpr (CV == 4) {
-          const V4 q0 = *reinterpret_cast<const V4*>(a0[j] + c0);
-          const V4 q1 = *reinterpret_cast<const V4*>(a1[j] + c0);
-          const V4 q2 = *reinterpret_cast<const V4*>(a2[j] + c0);
-          u0[0] = q0.x, u0[1] = q0.y, u0[2] = q0.z, u0[3] = q0.w;
-          u1[0] = q1.x, u1[1] = q1.y, u1[2] = q1.z, u1[3] = q1.w;
-          u2[0] = q2.x, u2[1] = q2.y, u2[2] = q2.z, u2[3] = q2.w;
-        } else {
-          u0[0] = a0[j][c0], u1[0] = a1[j][c0], u2[0] = a2[j][c0];
-        }
 #pragma unroll
-        for (int cc = 0; cc < CV; ++cc) r[cc][j] = u0[cc] * B0[j] + u1[cc] * B1[j] + u2[cc] * B2[j];
+        for (int cc = 0; cc < CV; ++cc) r[cc][j] = u0[j][cc] * B0[j] + u1[j][cc] * B1[j] + u2[j][cc] * B2[j];
       } else {
 #pragma unroll
         for (int cc = 0; cc < CV; ++cc) r[cc][j] = zero_background ? T(0) : (((c0 + cc) & 1) ? bgy : bgx[j]);

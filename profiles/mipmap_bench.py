@@ -17,6 +17,8 @@ ap.add_argument("--res", type=int, default=4096)
 ap.add_argument("--views", type=int, default=2)
 ap.add_argument("--tex", type=int, default=4096)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--channels", type=int, default=3, help="texture channels (3 = the textured configuration; 8 / 16: neural textures -- the wave-private backward kernel)")
+ap.add_argument("--bicubic", action="store_true")
 ap.add_argument("--flags", default="0")
 ap.add_argument("--lib", default="")
 ap.add_argument("--stats", action="store_true")
@@ -41,7 +43,7 @@ nl, no = S.MESH_SIZES[a.mesh]
 v_world, vi = S.uv_sphere(nl, no, lobes=0.05, device=dev)
 campos, camrot, focal, princpt = S.ring_cameras(a.views, W, H, device=dev)
 vt, vti = S.uv_sphere_atlas(nl, no, device=dev)
-tex = [t.expand(a.views, -1, -1, -1).contiguous() for t in S.texture_pyramid(1, 3, a.tex, device=dev)]
+tex = [t.expand(a.views, -1, -1, -1).contiguous() for t in S.texture_pyramid(1, a.channels, a.tex, device=dev)]
 v_pix = drtk_amd.transform(v_world[None], campos, camrot, focal, princpt)
 with th.no_grad():
     index = drtk_amd.rasterize(v_pix, vi, H, W)
@@ -54,7 +56,7 @@ with th.no_grad():
     jac = drtk_amd.screen_space_uv_derivative(v_world[None].expand(a.views, -1, -1), vtn, vi, vti, index, bary, mask, campos, camrot, focal)
     grid = ((uv.permute(0, 2, 3, 1) * 2 - 1) * mask[..., None]).contiguous()
 g = th.Generator(device=dev).manual_seed(0)
-go = (th.rand(a.views, 3, H, W, device=dev, generator=g) * 2 - 1) * mask[:, None]
+go = (th.rand(a.views, a.channels, H, W, device=dev, generator=g) * 2 - 1) * mask[:, None]
 print(f"coverage {mask.float().mean().item():.3f}")
 
 if a.stats:
@@ -105,9 +107,10 @@ def timeit(fn):
 
 for flags in [int(x) for x in a.flags.split(",")]:
     set_flags(flags)
-    f = timeit(lambda: capi.mipmap_grid_sampler_2d(tex, grid, jac, 8, 1, 0))
-    b = timeit(lambda: capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0))
-    print(f"flags={flags}: mipmap fwd {f:.3f} ms   bwd (incl. zero-fill of the pyramid) {b:.3f} ms")
+    MODE = 2 if a.bicubic else 0
+    f = timeit(lambda: capi.mipmap_grid_sampler_2d(tex, grid, jac, 8, 1, MODE))
+    b = timeit(lambda: capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, MODE))
+    print(f"flags={flags} C={a.channels}{' bicubic' if a.bicubic else ''}: mipmap fwd {f:.3f} ms   bwd (incl. zero-fill of the pyramid) {b:.3f} ms")
 set_flags(0)
 
 if a.dump:

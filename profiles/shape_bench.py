@@ -33,6 +33,7 @@ ap.add_argument("--mesh", default="100k")
 ap.add_argument("--channels", default="4,8,12,16,24,32,64")
 ap.add_argument("--lib", default="")
 ap.add_argument("--out", default="")
+ap.add_argument("--split-dir", default="", help="also write interp_bwd_by_C.json / raster_regimes.json / f64_and_odd_width.json there")
 ap.add_argument("--grads", default="both,attr_only,bary_only")
 ap.add_argument("--flags", type=int, default=0, help="ablation mask (needs profiles/libdrtk_amd_ablate.so: python drtk_amd/build.py --ablation)")
 a = ap.parse_args()
@@ -54,15 +55,19 @@ PEAK = 8000.0  # GB/s, MI355X_MICROARCH.md
 
 
 def timed(fn, reps):
+    """median over three rounds of `reps` calls (a round now and then catches an allocator or clock event: 9 ms once)"""
     fn()
     th.cuda.synchronize()
-    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    th.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    rounds = []
+    for _ in range(3):
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        th.cuda.synchronize()
+        rounds.append(e0.elapsed_time(e1) / reps)
+    return sorted(rounds)[1]
 
 
 def kernel_times(fn, reps):
@@ -164,7 +169,8 @@ if "raster" in a.what:
             bench_ns_per_px = ns_per_px
         rows.append({"regime": name, "views": N, "F": int(vi.shape[0]), "res": res, "ms": round(ms, 4),
                      "kernels_ms": {k: round(x, 4) for k, x in kt.items()}, "covered_px": covered,
-                     "big_triangles_all_views": big, "ns_per_covered_px": round(ns_per_px, 4),
+                     "big_triangles_all_views": big, "ns_per_triangle_view": round(1e6 * ms / max(N * int(vi.shape[0]), 1), 4),
+                     "ns_per_covered_px": round(ns_per_px, 4),
                      "vs_bench_per_covered_px": round(ns_per_px / bench_ns_per_px, 2)})
         print(rows[-1], file=sys.stderr)
         del v, vi, index, p
@@ -207,6 +213,12 @@ if "f64" in a.what:
 
 txt = json.dumps(result, indent=1)
 print(txt)
+if a.split_dir:  # one file per section, as committed under profiles/rNN/
+    os.makedirs(a.split_dir, exist_ok=True)
+    for key, name in (("interp_bwd_by_C", "interp_bwd_by_C.json"), ("raster_regimes", "raster_regimes.json"), ("f64_and_odd_width", "f64_and_odd_width.json")):
+        if key in result:
+            with open(os.path.join(a.split_dir, name), "w") as f:
+                f.write(json.dumps({"device": result["device"], "lib": result["lib"], key: result[key]}, indent=1) + "\n")
 if a.out:
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "w") as f:

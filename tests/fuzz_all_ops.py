@@ -14,6 +14,7 @@ import torch as th
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 DEV = "cuda:0"
 
@@ -32,6 +33,22 @@ def _close(a, ref, what, atol=1e-5, rtol=1e-5):
 # separate list so that the cases of the plain seeds -- among them the harvested regression seeds of
 # test_edge_grad_sign_decisions_at_near_parallel_normals_follow_the_reference -- stay what they were.
 WIDE_CHANNELS = [8, 12, 16, 20, 24, 28, 32, 36, 48, 64, 7, 13, 18, 30]
+
+
+def _close_or_f64(a, ref32, ref64_fn, what, **tol):
+    """The flat bar first; where a float32 gradient misses it, the ARBITER is the distance to the same computation in
+    double (tests/f64_distance.py: as near as the oracle's own float32 run, up to a factor) -- vertex gradients are float
+    sums of thousands of terms whose order differs between the oracle's loop and the kernel's atomics, and on a large
+    scene the two land a few per mille on either side of 1e-5 of the magnitude (fuzz_large_scenes seed 480020: render
+    backward 8.93e-4 against 8.89e-4).  Double cases keep the flat (1e-10) bar."""
+    try:
+        _close(a, ref32, what, **tol)
+    except AssertionError:
+        if ref32.dtype != th.float32:
+            raise
+        from f64_distance import assert_within_f64_distance
+
+        assert_within_f64_distance(a, ref32, ref64_fn(), what + " (against the oracle in double)")
 
 
 def make_case(seed, wide_channels=False):
@@ -108,15 +125,17 @@ def run_case(c, place=None):
     masked = capi.interpolate_masked(d(c["attr"]), d(vi), i_g, d(rb_o)).cpu()
     assert th.equal(masked, img_o * (i_o != -1)[:, None]), "interpolate_masked"
     tol = dict(atol=1e-12, rtol=1e-10) if tight else dict(atol=1e-5, rtol=1e-5)
-    _close(capi.render_backward(d(v), d(vi), i_g, d(c["gd"]), d(c["gb"])), O.render_backward(v, vi, i_o, c["gd"], c["gb"]),
-           "render backward", **tol)
+    D = lambda t: t.double()  # noqa: E731
+    _close_or_f64(capi.render_backward(d(v), d(vi), i_g, d(c["gd"]), d(c["gb"])), O.render_backward(v, vi, i_o, c["gd"], c["gb"]),
+                  lambda: O.render_backward(D(v), vi, i_o, D(c["gd"]), D(c["gb"])), "render backward", **tol)
     ag_o, bg_o = O.interpolate_backward(c["go"], c["attr"], vi, i_o, rb_o)
     ag_g, bg_g = capi.interpolate_backward(d(c["go"]), d(c["attr"]), d(vi), i_g, d(rb_o))
-    _close(ag_g, ag_o, "attr grad", **tol)
+    ag_64 = lambda: O.interpolate_backward(D(c["go"]), D(c["attr"]), vi, i_o, D(rb_o))[0]  # noqa: E731
+    _close_or_f64(ag_g, ag_o, ag_64, "attr grad", **tol)
     _close(bg_g, bg_o, "bary grad", **tol)
     ag_g1, none = capi.interpolate_backward(d(c["go"]), d(c["attr"]), d(vi), i_g, d(rb_o), True, False)
     assert none is None
-    _close(ag_g1, ag_o, "attr grad (vertex only)", **tol)
+    _close_or_f64(ag_g1, ag_o, ag_64, "attr grad (vertex only)", **tol)
     none, bg_g1 = capi.interpolate_backward(d(c["go"]), d(c["attr"]), d(vi), i_g, d(rb_o), False, True)
     assert none is None
     _close(bg_g1, bg_o, "bary grad (bary only)", **tol)
@@ -125,8 +144,9 @@ def run_case(c, place=None):
         eg_o = O.edge_grad_backward(v, img, i_o, vi, c["go"], M)
         _close(capi.edge_grad_backward(d(v), d(img), i_g, d(vi), d(c["go"]), M), eg_o, f"edge grad M={M}", **tol)
         vg_o, _ = O.interpolate_backward(eg_o, v, vi, i_o, rb_o, True, False)
-        _close(capi.edge_grad_backward_fused(d(v), d(img), i_g, d(vi), d(rb_o), d(c["go"]), M), vg_o, f"fused edge grad M={M}",
-               **tol)
+        vg_64 = lambda: O.interpolate_backward(O.edge_grad_backward(D(v), D(img), i_o, vi, D(c["go"]), M), D(v), vi, i_o, D(rb_o), True, False)[0]  # noqa: E731
+        _close_or_f64(capi.edge_grad_backward_fused(d(v), d(img), i_g, d(vi), d(rb_o), d(c["go"]), M), vg_o, vg_64,
+                      f"fused edge grad M={M}", **tol)
 
 
 def describe(c):
