@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r04j; O=gpurun_out/r04j
-python profiles/scripts/one_seed_next_ops.py 460768 product 2>&1 | grep -v amdgpu.ids
-python profiles/scripts/one_seed_next_ops.py 460768 profiles/variants/r03.so 2>&1 | grep -v amdgpu.ids
+python tests/diag_one_seed_next_ops.py 460768 product 2>&1 | grep -v amdgpu.ids
+python tests/diag_one_seed_next_ops.py 460768 profiles/variants/r03.so 2>&1 | grep -v amdgpu.ids
 timeout 200 python tests/fuzz_large_scenes.py --cases 3 --first 480019 2>&1 | tail -2
 cd tests; timeout 1500 python -m pytest test_gpu_parity.py test_gpu_textured.py test_gpu_f64_distance.py -x -q > ../$O/tests.log 2>&1; tail -3 ../$O/tests.log; cd ..
 timeout 600 python tests/fuzz_all_ops.py --cases 1500 --first 500000 > $O/fuzz_all.log 2>&1; tail -1 $O/fuzz_all.log

@@ -1,3 +1,6 @@
+"""Diagnostic (run from the repository root on a GPU box): one seed of tests/fuzz_next_ops.py against a given build of the
+library, and how ill-conditioned its screen_space_uv_derivative is (the oracle against itself on inputs one ulp apart).
+usage: python tests/diag_one_seed_next_ops.py SEED [product | path/to/variant.so]"""
 import sys, os
 sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
 from drtk_amd import capi
