@@ -700,7 +700,8 @@ constexpr int kWinCells = win_cells_before(kWinLevels);
 // PAD / ALIGN: padding mode and align_corners as compile-time constants (the coordinate pipeline of every tap branches on
 // them: SQ counters of the runtime-parameter version showed 490 scalar and 950 vector instructions per wave).
 template <typename T, int PAD, bool ALIGN>
-__global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
+// (3 workgroups per CU by registers as by LDS; reflection padding needs ~190: 2)
+__global__ __launch_bounds__(kMipBlock, PAD == 2 ? 2 : 3) void mipmap_backward_tiled_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
     const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
@@ -891,6 +892,20 @@ __global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
           if (DRTK_DBG(dbg, 1)) {
           } else if (cell >= 0) {
             double* wp = s_win + C * win_cells_before(l) + cell;
+#ifdef DRTK_MIP_LEAN
+            // the products in double: 7 conversions + 12 double multiplications instead of 12 float multiplications + 12
+            // conversions (the windows are double; the product is then exact)
+            const double wnw = q.nw, wne = q.ne, wsw = q.sw, wse = q.se;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (c >= C) break;
+              const double gd = g[c];
+              lds_add(wp + c * chan, wnw * gd);
+              lds_add(wp + c * chan + 1, wne * gd);
+              lds_add(wp + c * chan + stride, wsw * gd);
+              lds_add(wp + c * chan + stride + 1, wse * gd);
+            }
+#else
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               if (c >= C) break;
@@ -899,6 +914,7 @@ __global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
               lds_add(wp + c * chan + stride, static_cast<double>(q.sw * g[c]));
               lds_add(wp + c * chan + stride + 1, static_cast<double>(q.se * g[c]));
             }
+#endif
           } else if (i < 16) {
             miss[s] = true, pending |= 1u << (2 * i + s);
             miss_x[s] = min(miss_x[s], q.ix_nw), miss_y[s] = min(miss_y[s], q.iy_nw);
@@ -918,6 +934,16 @@ __global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
           for (int c = 0; c < 4; ++c) {
             if (c >= C || DRTK_DBG(dbg, 16)) break;
             const T gOut = g[c];
+#ifdef DRTK_MIP_LEAN
+            // the reference's eight products regrouped: d/dx = ((ne - nw) fy1 + (se - sw) fy0) g, d/dy = ((sw - nw) fx1 +
+            // (se - ne) fx0) g -- 10 operations per channel instead of 24 (fused multiply-adds written out: -ffp-contract=off)
+            if (gOut != T(0)) { // (with a zero upstream gradient every term is +-0 * finite)
+              const T gx = __builtin_fmaf(bot[c].y - bot[c].x, fy0, (top[c].y - top[c].x) * fy1);
+              const T gy = __builtin_fmaf(bot[c].y - top[c].y, fx0, (bot[c].x - top[c].x) * fx1);
+              gix = __builtin_fmaf(gx, gOut, gix);
+              giy = __builtin_fmaf(gy, gOut, giy);
+            }
+#else
             // with a zero upstream gradient every term is +-0 * finite: the texels count as 0
             const T v_nw = gOut != T(0) ? top[c].x : T(0), v_ne = gOut != T(0) ? top[c].y : T(0);
             const T v_sw = gOut != T(0) ? bot[c].x : T(0), v_se = gOut != T(0) ? bot[c].y : T(0);
@@ -929,6 +955,7 @@ __global__ __launch_bounds__(kMipBlock) void mipmap_backward_tiled_kernel(
             giy += v_sw * fx1 * gOut;
             gix += v_se * fy0 * gOut;
             giy += v_se * fx0 * gOut;
+#endif
           }
         } else {
         // General form.  One memory round trip per (tap, level): the texels of ALL channels are requested first

@@ -840,6 +840,60 @@ def test_interpolate_backward_channel_counts_and_gradient_requests(C, width):
     assert float(bg.cpu()[(i_o == -1)[:, None].expand_as(bg_o)].abs().sum()) == 0.0  # background written as exact zeros
 
 
+@pytest.mark.parametrize("dtype", [th.float32, th.float64])
+@pytest.mark.parametrize("scene", ["quads_2x2", "quads_16x16", "close_up", "low_poly_high_res", "huge_over_dense"])
+def test_rasterize_large_triangles_take_the_cooperative_pass_and_stay_bit_exact(scene, dtype):
+    """Scenes whose triangles cover hundreds to thousands of pixels of a tile -- screen-filling quads, a close-up, a
+    low-poly mesh at high resolution, one huge triangle over a dense mesh -- are shaded by the whole workgroup
+    (csrc/rasterize.hip: cooperative pass, thresholds 256 / 1024 clipped pixels) instead of one 16-lane row: index_img and
+    depth_img equal the oracle's bit for bit, over several views and with poisoned outputs."""
+    import oracle as O
+    from drtk_amd import capi
+    from drtk_amd import synthetic as S
+    from drtk_amd.transform import transform
+
+    def quads(n_side, res):
+        xs = th.linspace(-0.5, res - 0.5, n_side + 1, dtype=th.float64)
+        yy, xx = th.meshgrid(xs, xs, indexing="ij")
+        z = 2.0 + 0.5 * (xx / res) + 0.25 * (yy / res)
+        v = th.stack([xx, yy, z], -1).reshape(-1, 3)
+        ii, jj = th.meshgrid(th.arange(n_side), th.arange(n_side), indexing="ij")
+        s = n_side + 1
+        v00, v01, v10, v11 = ii * s + jj, ii * s + jj + 1, (ii + 1) * s + jj, (ii + 1) * s + jj + 1
+        vi = th.stack([th.stack([v00, v10, v11], -1), th.stack([v00, v11, v01], -1)], 2).reshape(-1, 3).to(th.int32)
+        return v[None].repeat(2, 1, 1), vi
+
+    def sphere(nl, no, res, distance, views=2):
+        v, vi = S.uv_sphere(nl, no, lobes=0.05, dtype=th.float64)
+        cams = S.ring_cameras(views, res, res, distance=distance, dtype=th.float64)
+        return transform(v[None].expand(views, -1, -1), *cams), vi
+
+    if scene == "quads_2x2":
+        v, vi = quads(2, 512)
+        res = 512
+    elif scene == "quads_16x16":
+        v, vi = quads(16, 1024)
+        res = 1024
+    elif scene == "close_up":
+        v, vi = sphere(40, 44, 768, 1.15)
+        res = 768
+    elif scene == "low_poly_high_res":
+        v, vi = sphere(10, 12, 1024, 3.0)
+        res = 1024
+    else:  # one triangle across the whole canvas in front of / behind parts of a dense mesh (long lists: the high threshold)
+        v, vi = sphere(120, 128, 512, 3.0)
+        big = th.tensor([[-40.0, -30.0, 2.9], [600.0, 10.0, 3.05], [100.0, 640.0, 2.95]], dtype=th.float64)
+        v = th.cat([v, big[None].expand(v.shape[0], -1, -1)], 1)
+        vi = th.cat([vi, th.tensor([[v.shape[1] - 3, v.shape[1] - 2, v.shape[1] - 1]], dtype=th.int32)], 0)
+        res = 512
+    v = v.to(dtype).contiguous()
+    d_o, i_o = O.rasterize(v, vi, res, res, nthreads=0)
+    d_g, i_g = capi.rasterize(dev(v), dev(vi), res, res)
+    assert th.equal(i_g.cpu(), i_o), f"{scene}: index_img differs at {int((i_g.cpu() != i_o).sum())} pixels"
+    assert th.equal(d_g.cpu(), d_o), f"{scene}: depth_img differs"
+    assert int((i_o >= 0).sum()) > 0.3 * i_o.numel()
+
+
 def test_rasterize_large_random_scenes_are_bit_exact():
     """16 seeded cases from tests/fuzz_raster_large.py: the binning passes at sizes the small-scene fuzzers never reach
     (up to 2048 x 1536 and 17 x 4096, 1e3 - 3e5 triangles per view, tiny / medium / screen-filling mix, clustered
