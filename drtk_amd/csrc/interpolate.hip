@@ -598,19 +598,29 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
   };
   // one call site, one offset register for grad_out and barycentrics (with an offset of its own the bary loads got a
   // freshly written register, and the compiler waited for the grad_out loads before writing it)
+  // (plane bases by repeated addition of H W: written as go_n + (c0 + c) H W every plane cost a 64-bit scalar multiply,
+  // eight scalar instructions -- the kernel issued more scalar than vector instructions, 152 M against 126 M per launch)
   auto load_row = [&](int ps, int c0, int cc, bool row_any, bool with_bary) {
     if (!row_any) return;
     const uint32_t bo = row_offset(ps);
+    const T* plane = go_n + int64_t(c0) * HW;
 #pragma unroll
     for (int q = 0; q < CH / 4; ++q) {
       if (4 * q < cc) {
 #pragma unroll
-        for (int c = 4 * q; c < 4 * q + 4; ++c) G[c] = plane_load(go_n + int64_t(c0 + c) * HW, bo);
+        for (int c = 4 * q; c < 4 * q + 4; ++c) {
+          G[c] = plane_load(plane, bo);
+          plane += HW;
+        }
       }
     }
     if (with_bary) {
+      const T* bplane = bary_n;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) B[k] = plane_load(bary_n + int64_t(k) * HW, bo);
+      for (int k = 0; k < 3; ++k) {
+        B[k] = plane_load(bplane, bo);
+        bplane += HW;
+      }
     }
   };
   // rotating state: row ps (tr, v*), row ps+1 (tr_n, vn*), row ps+2 (tr_nn)
@@ -717,13 +727,10 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
     if (cov != 0 && !DRTK_DBG(dbg, 1)) {
       const T* sg = s_g[wave];
       const T* sb = s_b[wave];
-      scatter_runs<T, TableAcc, DRTK_INTERP_WIDE_ONLY, TABLE, 16>(
-          heads, cov, TABLE ? s_slot[wave] : nullptr, s_vid[wave], 3 * cc, cc, t_vals, C, attr_grad_n, C, c0,
-          [sg, sb](int k, int c, int g4, T* xv) {
-            const V4 a = *reinterpret_cast<const V4*>(sg + c * kRunPad + 4 * g4);
-            const V4 b = *reinterpret_cast<const V4*>(sb + k * kRunPad + 4 * g4);
-            xv[0] = a.x * b.x, xv[1] = a.y * b.y, xv[2] = a.z * b.z, xv[3] = a.w * b.w;
-          }, dbg, 0, 1, TABLE ? c0 : 0);
+      // (the table + bary variant sits at its register bound: it keeps the unpipelined reads)
+      scatter_runs_rows<T, TableAcc, DRTK_INTERP_WIDE_ONLY, TABLE, 16, !(TABLE && HAS_BARY)>(
+          heads, cov, TABLE ? s_slot[wave] : nullptr, s_vid[wave], 3 * cc, cc, t_vals, C, attr_grad_n, C, c0, sg, sb, dbg,
+          TABLE ? c0 : 0);
     }
     // 6. bary gradient: interpolate_kernel.cu:238-246 accumulation order (channels ascending, over all chunks)
     if constexpr (HAS_BARY) {

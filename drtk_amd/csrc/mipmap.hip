@@ -473,17 +473,31 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
           T cx[4], cy[4];
           cubic_coeffs(cx, cb.tx);
           cubic_coeffs(cy, cb.ty);
+          // interior footprint (sixteen consecutive texels inside the level, nearly all): a row is ONE 16-byte load
+          // (element-aligned) instead of four predicated 4-byte ones; same products, same order
+          const int bx = cb.xi[0];
+          const bool interior = bx >= 0 && cb.xi[1] == bx + 1 && cb.xi[2] == bx + 2 && cb.xi[3] == bx + 3 &&
+              (cb.yi[0] | cb.yi[1] | cb.yi[2] | cb.yi[3]) >= 0;
 #pragma unroll
           for (int cc = 0; cc < kChBlock; ++cc) {
             if (c0 + cc < C) {
               const GlobalPtr<const T> p = base + cc * plane;
               T co[4];
+              if (interior) {
+                typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+                Quad4 row[4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                T xv[4];
+                for (int r = 0; r < 4; ++r) row[r] = *(GlobalPtr<const Quad4>)(p + cb.yi[r] * w + bx);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) xv[k] = (cb.yi[r] >= 0 && cb.xi[k] >= 0) ? p[cb.yi[r] * w + cb.xi[k]] : T(0);
-                co[r] = xv[0] * cx[0] + xv[1] * cx[1] + xv[2] * cx[2] + xv[3] * cx[3];
+                for (int r = 0; r < 4; ++r) co[r] = row[r].x * cx[0] + row[r].y * cx[1] + row[r].z * cx[2] + row[r].w * cx[3];
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  T xv[4];
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) xv[k] = (cb.yi[r] >= 0 && cb.xi[k] >= 0) ? p[cb.yi[r] * w + cb.xi[k]] : T(0);
+                  co[r] = xv[0] * cx[0] + xv[1] * cx[1] + xv[2] * cx[2] + xv[3] * cx[3];
+                }
               }
               acc[cc] += (co[0] * cy[0] + co[1] * cy[1] + co[2] * cy[2] + co[3] * cy[3]) * alpha;
             }
@@ -696,7 +710,9 @@ constexpr int kWinCells = win_cells_before(kWinLevels);
 // 3 waves per SIMD, same 1.0 ms floor, 2.52 vs 1.95 ms at C = 3: the floor is per-(tap, level) arithmetic and the stream,
 // not barriers), and persistent workgroups that request the next tile's upstream gradient before working on the current
 // one (2.20 vs 1.96 ms; the floor with no tap loop rose from 0.75 to 0.98: the hardware's own workgroup dispatch balances
-// the mix of background and silhouette tiles better than a static stride, and the job loop costs registers).
+// the mix of background and silhouette tiles better than a static stride, and the job loop costs registers).  Also
+// nothing: the window products in double (7 conversions + 12 double multiplications instead of 12 + 12) and the grid
+// gradient's eight products regrouped into 10 operations per channel with written-out fmas (1.967 vs 1.955 ms).
 // PAD / ALIGN: padding mode and align_corners as compile-time constants (the coordinate pipeline of every tap branches on
 // them: SQ counters of the runtime-parameter version showed 490 scalar and 950 vector instructions per wave).
 template <typename T, int PAD, bool ALIGN>
@@ -892,20 +908,6 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 2 : 3) void mipmap_backward_t
           if (DRTK_DBG(dbg, 1)) {
           } else if (cell >= 0) {
             double* wp = s_win + C * win_cells_before(l) + cell;
-#ifdef DRTK_MIP_LEAN
-            // the products in double: 7 conversions + 12 double multiplications instead of 12 float multiplications + 12
-            // conversions (the windows are double; the product is then exact)
-            const double wnw = q.nw, wne = q.ne, wsw = q.sw, wse = q.se;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              if (c >= C) break;
-              const double gd = g[c];
-              lds_add(wp + c * chan, wnw * gd);
-              lds_add(wp + c * chan + 1, wne * gd);
-              lds_add(wp + c * chan + stride, wsw * gd);
-              lds_add(wp + c * chan + stride + 1, wse * gd);
-            }
-#else
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               if (c >= C) break;
@@ -914,7 +916,6 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 2 : 3) void mipmap_backward_t
               lds_add(wp + c * chan + stride, static_cast<double>(q.sw * g[c]));
               lds_add(wp + c * chan + stride + 1, static_cast<double>(q.se * g[c]));
             }
-#endif
           } else if (i < 16) {
             miss[s] = true, pending |= 1u << (2 * i + s);
             miss_x[s] = min(miss_x[s], q.ix_nw), miss_y[s] = min(miss_y[s], q.iy_nw);
@@ -934,16 +935,6 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 2 : 3) void mipmap_backward_t
           for (int c = 0; c < 4; ++c) {
             if (c >= C || DRTK_DBG(dbg, 16)) break;
             const T gOut = g[c];
-#ifdef DRTK_MIP_LEAN
-            // the reference's eight products regrouped: d/dx = ((ne - nw) fy1 + (se - sw) fy0) g, d/dy = ((sw - nw) fx1 +
-            // (se - ne) fx0) g -- 10 operations per channel instead of 24 (fused multiply-adds written out: -ffp-contract=off)
-            if (gOut != T(0)) { // (with a zero upstream gradient every term is +-0 * finite)
-              const T gx = __builtin_fmaf(bot[c].y - bot[c].x, fy0, (top[c].y - top[c].x) * fy1);
-              const T gy = __builtin_fmaf(bot[c].y - top[c].y, fx0, (bot[c].x - top[c].x) * fx1);
-              gix = __builtin_fmaf(gx, gOut, gix);
-              giy = __builtin_fmaf(gy, gOut, giy);
-            }
-#else
             // with a zero upstream gradient every term is +-0 * finite: the texels count as 0
             const T v_nw = gOut != T(0) ? top[c].x : T(0), v_ne = gOut != T(0) ? top[c].y : T(0);
             const T v_sw = gOut != T(0) ? bot[c].x : T(0), v_se = gOut != T(0) ? bot[c].y : T(0);
@@ -955,7 +946,6 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 2 : 3) void mipmap_backward_t
             giy += v_sw * fx1 * gOut;
             gix += v_se * fy0 * gOut;
             giy += v_se * fx0 * gOut;
-#endif
           }
         } else {
         // General form.  One memory round trip per (tap, level): the texels of ALL channels are requested first
@@ -1200,13 +1190,16 @@ __device__ __forceinline__ void wave_minmax2(int x, int y, bool on, int& x0, int
   x1 = wave_max_i32(on ? x : INT32_MIN), y1 = wave_max_i32(on ? y : INT32_MIN);
 }
 
-template <typename T, int PAD, bool ALIGN>
-__global__ __launch_bounds__(kMipBlock, DRTK_MIP_WAVE_OCC) void mipmap_backward_wave_kernel(
+// MODE 0: bilinear (2 x 2 texels per tap); MODE 2: bicubic (4 x 4: mipmap_grid_sampler_kernel.cu:806-861) -- the same windows with
+// a span of four cells, interior taps (sixteen consecutive texels inside the level) windowed, the others corner by corner.
+template <typename T, int PAD, bool ALIGN, int MODE = 0>
+__global__ __launch_bounds__(kMipBlock, MODE == 2 ? 2 : DRTK_MIP_WAVE_OCC) void mipmap_backward_wave_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
     const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
   constexpr int padding = PAD;
   constexpr bool align_corners = ALIGN;
+  constexpr int kSpan = MODE == 2 ? 4 : 2; // cells per tap and axis
   static_assert(kTileW == 16 && kWave == 64, "a wave covers 16 x 4 pixels");
   __shared__ double s_f[kTapTab * kTapTab];
   __shared__ const void* s_ptr[kMaxLevels];
@@ -1245,7 +1238,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_WAVE_OCC) void mipmap_backward_
     T unused;
     const T c = unnormalize(coord, size, align_corners, &unused);
     const T lo = padding == 0 ? T(-1) : T(0);
-    return static_cast<int>(floor(fmin(fmax(c, lo), static_cast<T>(size - 1))));
+    return static_cast<int>(floor(fmin(fmax(c, lo), static_cast<T>(size - 1)))) - (MODE == 2 ? 1 : 0);
   };
 
   for (int c0 = 0; c0 < C; c0 += kChBlock) {
@@ -1300,8 +1293,8 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_WAVE_OCC) void mipmap_backward_
           ww[l] = wh[l] = 0;
           continue;
         }
-        // + 2: the east / south corners of the extreme taps; at least two columns, at most a flush row
-        const long long need_w = static_cast<long long>(x1[l]) - x0[l] + 2, need_h = static_cast<long long>(y1[l]) - y0[l] + 2;
+        // + kSpan: the east / south cells of the extreme taps; at most a flush row
+        const long long need_w = static_cast<long long>(x1[l]) - x0[l] + kSpan, need_h = static_cast<long long>(y1[l]) - y0[l] + kSpan;
         ww[l] = static_cast<int>(need_w < kWaveWinW ? need_w : kWaveWinW);
         const int rows = budget[l] / ww[l];
         wh[l] = static_cast<int>(need_h < rows ? need_h : rows);
@@ -1331,7 +1324,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_WAVE_OCC) void mipmap_backward_
       if (l < 0 || l > 1) return -1;
       const int wx = ix_nw - ox[l], wy = iy_nw - oy[l];
       stride = ww[l];
-      return (wx >= 0 && wx < ww[l] - 1 && wy >= 0 && wy < wh[l] - 1) ? base[l] + wy * ww[l] + wx : -1;
+      return (wx >= 0 && wx < ww[l] - (kSpan - 1) && wy >= 0 && wy < wh[l] - (kSpan - 1)) ? base[l] + wy * ww[l] + wx : -1;
     };
     // the wave's windows to global memory; every cell is left zero.  Two rows of <= 32 cells per step: lanes of a half
     // wave = consecutive texels of a row, so the atomics of a row form one or two requests.
@@ -1389,6 +1382,53 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_WAVE_OCC) void mipmap_backward_
           const int plane = h * w; // < 2^31, checked by fill_table()
           const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]) + int64_t(c0) * plane;
           const T alpha = s == 0 ? alpha_2 : alpha_1;
+          if constexpr (MODE == 2) {
+            const Cubic<T> cb = bicubic_footprint<T>(x, y, h, w, padding, align_corners);
+            T xc[4], yc[4], xg[4], yg[4];
+            cubic_coeffs(xc, cb.tx);
+            cubic_coeffs(yc, cb.ty);
+            cubic_coeffs_grad(xg, cb.tx);
+            cubic_coeffs_grad(yg, cb.ty);
+            const GlobalPtr<T> gp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C + c0) * plane);
+            T gix = T(0), giy = T(0);
+            const int bx = cb.xi[0], by = cb.yi[0];
+            const bool interior = bx >= 0 && by >= 0 && cb.xi[1] == bx + 1 && cb.xi[2] == bx + 2 && cb.xi[3] == bx + 3 &&
+                cb.yi[1] == by + 1 && cb.yi[2] == by + 2 && cb.yi[3] == by + 3;
+            int stride = 0;
+            const int cell = interior ? cell_of(d, bx, by, stride) : -1;
+            const bool defer = interior && cell < 0 && i < 16 && !DRTK_DBG(dbg, 1);
+            if (defer) {
+              pending |= 1u << (2 * i + s);
+              note_miss(s, bx, by);
+            }
+#pragma unroll 1
+            for (int c = 0; c < cc; ++c) {
+              const T gOut = go[c] * alpha;
+              if (gOut == T(0)) continue; // every term below would be +-0 * finite
+              const GlobalPtr<const T> pc = inp + c * plane;
+#pragma unroll
+              for (int i2 = 0; i2 < 4; ++i2) {
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                  const bool ok = cb.xi[i2] >= 0 && cb.yi[j2] >= 0;
+                  const int o = ok ? cb.yi[j2] * w + cb.xi[i2] : 0;
+                  const T wgt = gOut * xc[i2] * yc[j2];
+                  if (DRTK_DBG(dbg, 1)) {
+                  } else if (cell >= 0) {
+                    lds_add(win + cell + c * kWaveCells + j2 * stride + i2, static_cast<double>(wgt));
+                  } else if (ok && !defer) {
+                    atomic_add_g1(gp + c * plane + o, wgt);
+                  }
+                  const T val = (ok && !DRTK_DBG(dbg, 2)) ? pc[o] : T(0);
+                  gix -= gOut * val * (xg[i2] * yc[j2]);
+                  giy -= gOut * val * (yg[j2] * xc[i2]);
+                }
+              }
+            }
+            acc_x += cb.mx * gix;
+            acc_y += cb.my * giy;
+            continue;
+          }
           const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
           const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
           T g[kChBlock];
@@ -1517,6 +1557,39 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_WAVE_OCC) void mipmap_backward_
         const int h = s_h[d], w = s_w[d];
         const int plane = h * w;
         const T alpha = s2 == 0 ? alpha_2 : alpha_1;
+        if constexpr (MODE == 2) {
+          const Cubic<T> cb = bicubic_footprint<T>(x, y, h, w, padding, align_corners); // (interior: only those are deferred)
+          T xc[4], yc[4];
+          cubic_coeffs(xc, cb.tx);
+          cubic_coeffs(yc, cb.ty);
+          const int bx = cb.xi[0], by = cb.yi[0];
+          int stride;
+          const int cell = cell_of(d, bx, by, stride);
+          if (cell < 0 && !last) {
+            note_miss(s2, bx, by);
+            continue;
+          }
+          pending &= ~(1u << bit);
+          const GlobalPtr<T> gp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C + c0) * plane);
+#pragma unroll 1
+          for (int c = 0; c < cc; ++c) {
+            const T gOut = go[c] * alpha;
+            if (gOut == T(0)) continue;
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+#pragma unroll
+              for (int j2 = 0; j2 < 4; ++j2) {
+                const T wgt = gOut * xc[i2] * yc[j2];
+                if (cell >= 0) {
+                  lds_add(win + cell + c * kWaveCells + j2 * stride + i2, static_cast<double>(wgt));
+                } else {
+                  atomic_add_g1(gp + c * plane + (by + j2) * w + bx + i2, wgt);
+                }
+              }
+            }
+          }
+          continue;
+        }
         const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners); // (interior: only those are deferred)
         int stride;
         const int cell = cell_of(d, q.ix_nw, q.iy_nw, stride);
@@ -1665,10 +1738,20 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
 #else
   constexpr int64_t kWaveFromC = 5;
 #endif
-  if (interpolation_mode == 0 && C >= kWaveFromC && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
+  // bicubic f32 (any C >= 1): the same wave-private windows with 4 x 4 cells per tap (before round 4: the direct kernel,
+  // sixteen global float atomics per tap, level and channel -- 89 ms against 1.96 ms bilinear on the textured benchmark)
+  if (((interpolation_mode == 0 && C >= kWaveFromC) || (interpolation_mode == 2 && C >= 1)) && N <= 65535 && dtype == DRTK_F32 &&
+      !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
     const size_t lds = sizeof(double) * (C < kChBlock ? C : kChBlock) * kWaveCells * (kMipBlock / kWave);
 #define WAVEK(PAD, ALIGN)                                                                                               \
+  if (interpolation_mode == 2)                                                                                          \
+    DRTK_LAUNCH(                                                                                                        \
+        (mipmap_backward_wave_kernel<float, PAD, ALIGN, 2>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+        dim3(kMipBlock), lds, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid), gl, \
+        static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, force_max_aniso != 0,     \
+        clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags());                        \
+  else                                                                                                                  \
   DRTK_LAUNCH(                                                                                                          \
       (mipmap_backward_wave_kernel<float, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
       dim3(kMipBlock), lds, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid), gl,  \

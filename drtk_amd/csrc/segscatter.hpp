@@ -22,6 +22,8 @@
 //     a direct global atomic, so any input is handled.
 #pragma once
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace drtk_amd {
@@ -122,8 +124,45 @@ using TableAcc = double;
 // one-slice form (whose plain read-modify-write is only safe for a wave-private table); `tab_off` is added to the
 // component index of a table entry (a table whose rows hold all C_total components while the call scatters the chunk
 // that starts at c_base: tab_off = c_base).
-template <typename T, typename A = TableAcc, bool WIDE_ONLY = false, bool SHARED_TABLE = false, int SLICE_MAX_J = 32, typename Val4Fn>
-__device__ __forceinline__ void scatter_runs(
+// A val4 callable for scatter_runs: plain lambdas (k, c, g, out[4]) are wrapped in Val4Plain; Val4Rows is the pipelined
+// form for "pixel values = elementwise products of two staged LDS rows" (rows of kRunPad elements: a[c], b[k]).
+template <typename F>
+struct Val4Plain {
+  static constexpr bool pipelined = false;
+  struct Raw {};
+  F f;
+  template <typename T>
+  __device__ __forceinline__ void operator()(int k, int c, int g, T* x) const { f(k, c, g, x); }
+  template <typename R>
+  __device__ __forceinline__ void load(int, int, int, R&) const {}
+  template <typename R, typename T>
+  __device__ __forceinline__ void finish(const R&, T*) const {}
+};
+template <typename T, bool PIPELINED = true>
+struct Val4Rows {
+  static constexpr bool pipelined = PIPELINED;
+  using V4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
+  struct Raw {
+    V4 a, b;
+  };
+  const T* rows_a; // [c][kRunPad]
+  const T* rows_b; // [k][kRunPad]
+  __device__ __forceinline__ void load(int k, int c, int g, Raw& r) const {
+    r.a = *reinterpret_cast<const V4*>(rows_a + c * kRunPad + 4 * g);
+    r.b = *reinterpret_cast<const V4*>(rows_b + k * kRunPad + 4 * g);
+  }
+  __device__ __forceinline__ void finish(const Raw& r, T* x) const {
+    x[0] = r.a.x * r.b.x, x[1] = r.a.y * r.b.y, x[2] = r.a.z * r.b.z, x[3] = r.a.w * r.b.w;
+  }
+  __device__ __forceinline__ void operator()(int k, int c, int g, T* x) const { // (the sliced form)
+    Raw r;
+    load(k, c, g, r);
+    finish(r, x);
+  }
+};
+
+template <typename T, typename A, bool WIDE_ONLY, bool SHARED_TABLE, int SLICE_MAX_J, typename Val4Fn>
+__device__ __forceinline__ void scatter_runs_impl(
     unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
     int CC, A* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0,
     int c_off = 0, int c_step = 1, int tab_off = 0) {
@@ -163,10 +202,21 @@ __device__ __forceinline__ void scatter_runs(
       const int c = active ? j - k * CC : 0;
       T acc = T(0);
       int run_start = 0; // wave-uniform
+      // PIPELINED operands (val4 objects that offer load() / finish(): interpolate backward's products of two staged
+      // rows): group g + 1's two 16-byte LDS reads are issued before group g's run logic, whose branches otherwise keep
+      // every read next to its s_waitcnt lgkmcnt(0) -- sixteen exposed LDS round trips per row and chunk.
+      constexpr bool kPipelined = Val4Fn::pipelined;
+      typename Val4Fn::Raw raw;
+      if constexpr (kPipelined) val4.load(k, c, 0, raw);
 #pragma unroll 4
       for (int g = 0; g < kWave / 4; ++g) {
         T x[4];
-        val4(k, c, g, x);
+        if constexpr (kPipelined) {
+          val4.finish(raw, x);
+          if (g + 1 < kWave / 4) val4.load(k, c, g + 1, raw);
+        } else {
+          val4(k, c, g, x);
+        }
         // run heads among pixels 4g..4g+3 (pixel 0 never flushes)
         const uint32_t hb = __builtin_amdgcn_readfirstlane(
             static_cast<uint32_t>(heads >> (4 * g)) & (g == 0 ? 0xEu : 0xFu));
@@ -222,6 +272,24 @@ __device__ __forceinline__ void scatter_runs(
     }
   }
   if (active && ((cov >> run_start) & 1ull)) flush(k, c, run_start, acc, false);
+}
+
+template <typename T, typename A = TableAcc, bool WIDE_ONLY = false, bool SHARED_TABLE = false, int SLICE_MAX_J = 32, typename Val4Fn>
+__device__ __forceinline__ void scatter_runs(
+    unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
+    int CC, A* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, Val4Fn val4, int dbg = 0,
+    int c_off = 0, int c_step = 1, int tab_off = 0) {
+  scatter_runs_impl<T, A, WIDE_ONLY, SHARED_TABLE, SLICE_MAX_J>(
+      heads, cov, slot, vid, J, CC, vals, stride, dst_n, C_total, c_base, Val4Plain<Val4Fn>{val4}, dbg, c_off, c_step, tab_off);
+}
+// ... with the pipelined operand form
+template <typename T, typename A = TableAcc, bool WIDE_ONLY = false, bool SHARED_TABLE = false, int SLICE_MAX_J = 32, bool PIPELINED = true>
+__device__ __forceinline__ void scatter_runs_rows(
+    unsigned long long heads, unsigned long long cov, const int32_t* slot, const int32_t* vid, int J,
+    int CC, A* vals, int stride, T* __restrict__ dst_n, int C_total, int c_base, const T* rows_a, const T* rows_b,
+    int dbg = 0, int tab_off = 0) {
+  scatter_runs_impl<T, A, WIDE_ONLY, SHARED_TABLE, SLICE_MAX_J>(
+      heads, cov, slot, vid, J, CC, vals, stride, dst_n, C_total, c_base, Val4Rows<T, PIPELINED>{rows_a, rows_b}, dbg, 0, 1, tab_off);
 }
 
 // Wave-wide: add every occupied entry of the wave's table to dst_n[key * C_total + c_base + c], c < CC.
