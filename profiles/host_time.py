@@ -1,0 +1,122 @@
+"""Where the HOST time of a small step goes (BASELINE configs[1]: 10k triangles, 512x512, 4 views, C = 3).
+
+The kernels of that step take 0.21 ms, the eager step 0.45 ms: the rest is the host enqueueing ~30 launches.  This prints
+(a) the eager step's wall time with the queue kept full (what the host can enqueue per second) and with a synchronize
+    after every step (queue empty at each start),
+(b) torch.profiler's CPU-side table of one hundred steps (CPU activities only: no device tracing), sorted by self time,
+(c) the host time between entering and leaving each operator of the path (perf_counter, no synchronisation).
+
+    python profiles/host_time.py [--steps 200] [--out gpurun_out/host_time.txt]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--mesh", default="10k")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import drtk_amd
+    from drtk_amd import synthetic as S
+    from drtk_amd.transform import transform
+    import bench
+
+    dev = th.device("cuda", 0)
+    H = W = a.res
+    n = a.views
+    nl, no = S.MESH_SIZES[a.mesh]
+    v_world, vi = S.uv_sphere(nl, no, lobes=0.05, device=dev)
+    campos, camrot, focal, princpt = S.ring_cameras(n, W, H, device=dev)
+    v_world = v_world.clone().requires_grad_(True)
+    attr = S.random_attributes(1, v_world.shape[0], a.channels, seed=0, device=dev)[:1].contiguous().clone().requires_grad_(True)
+    lines = []
+
+    def say(s=""):
+        print(s, flush=True)
+        lines.append(s)
+
+    marks = {}
+
+    def step(clock=None):
+        t = time.perf_counter
+        v_world.grad = None
+        attr.grad = None
+        t0 = t()
+        v_pix = transform(v_world[None], campos, camrot, focal, princpt)
+        t1 = t()
+        index_img = drtk_amd.rasterize(v_pix, vi, H, W)
+        t2 = t()
+        depth_img, bary_img = drtk_amd.render(v_pix, vi, index_img)
+        t3 = t()
+        img = drtk_amd.interpolate(attr.expand(n, -1, -1), vi, index_img, bary_img)
+        t4 = t()
+        img = th.where((index_img != -1)[:, None], img, 0.0)
+        t5 = t()
+        img = drtk_amd.edge_grad_estimator(v_pix=v_pix, vi=vi, bary_img=bary_img, img=img, index_img=index_img)
+        t6 = t()
+        loss = bench._MeanSquare.apply(img) + depth_img.mean()
+        t7 = t()
+        loss.backward()
+        t8 = t()
+        if clock is not None:
+            for k, d in (("transform", t1 - t0), ("rasterize", t2 - t1), ("render", t3 - t2), ("interpolate", t4 - t3),
+                         ("mask (torch.where)", t5 - t4), ("edge_grad_estimator fwd", t6 - t5), ("loss (torch)", t7 - t6),
+                         ("backward (all)", t8 - t7)):
+                clock[k] = clock.get(k, 0.0) + d
+        return loss
+
+    for _ in range(20):
+        step()
+    th.cuda.synchronize()
+    # (a)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    t_enq = time.perf_counter() - t0
+    th.cuda.synchronize()
+    t_full = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        th.cuda.synchronize()
+    t_sync = time.perf_counter() - t1
+    say(f"(a) {a.steps} eager steps, queue kept full: host enqueue {t_enq / a.steps * 1e3:.4f} ms/step, "
+        f"to completion {t_full / a.steps * 1e3:.4f} ms/step; with a synchronize after each: {t_sync / a.steps * 1e3:.4f} ms/step")
+    # (c)
+    clock = {}
+    th.cuda.synchronize()
+    for _ in range(a.steps):
+        step(clock)
+        th.cuda.synchronize()
+    say("(c) host time inside each call, mean over the steps (queue empty at each start):")
+    for k, d in clock.items():
+        say(f"    {k:28s} {d / a.steps * 1e6:8.1f} us")
+    say(f"    {'sum':28s} {sum(clock.values()) / a.steps * 1e6:8.1f} us")
+    # (b)
+    from torch.profiler import profile, ProfilerActivity
+
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        for _ in range(100):
+            step()
+        th.cuda.synchronize()
+    say("(b) torch.profiler, CPU side, 100 steps:")
+    say(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
