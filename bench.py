@@ -396,10 +396,12 @@ def main():
     def step(fused_mask=False, reduce=True):
         for r in reducers:
             r.enabled = reduce  # off: this rank steps alone (no collective may be entered, not even from a gradient hook)
-        if reduce:
+        if reduce and grouped:
             for r in reducers:
-                r.zero_grad()
-        else:  # graph capture: gradients must be allocated by the captured backward pass itself (torch's capture recipe)
+                r.zero_grad()  # gradients accumulate straight into the reducer's flat buffer
+        else:
+            # one process, no group: what a single-GPU loop does (optimizer.zero_grad(set_to_none=True), PyTorch's default);
+            # also the graph-capture recipe: gradients must be allocated by the captured backward pass itself
             for p in leaves:
                 p.grad = None
         v_pix = transform(v_world[None], campos, camrot, focal, princpt)  # shared [1,V,3] -> [n_local,V,3]

@@ -23,12 +23,32 @@ _lib_path = None
 _POISON = os.environ.get("DRTK_CAPI_POISON", "") not in ("", "0")
 
 
+# DRTK_CAPI_GUARD=g (tests): every output / workspace of this binding is carved out of a larger flat allocation with g
+# sentinel elements on either side (16 g bytes for byte workspaces, which must stay 16-byte aligned) -- so outputs are
+# only element-aligned (g = 1, 2, 3), and `check_guards()` tells whether a kernel wrote outside what it was given.
+_GUARD = int(os.environ.get("DRTK_CAPI_GUARD", "0") or 0)
+_guards = []
+
+
+def _sentinel(dtype):
+    return 0x5A if dtype == th.uint8 else (-7.25 if dtype.is_floating_point else -(2 ** 29) - 3)
+
+
 def _out(*shape, dtype, device):
     """Output / workspace allocation of this binding: uninitialised memory -- or, with DRTK_CAPI_POISON=1 in the
     environment (the fuzzers and the GPU suite set it), memory pre-filled with NaN / a large negative integer / 0xA5
     bytes, so that an element a kernel forgot to write cannot pass for a value (freshly allocated device memory reads as
     zeros, which is a plausible image; see profiles/NOTES.md 3.1, round 3)."""
-    t = th.empty(*shape, dtype=dtype, device=device)
+    if _GUARD:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        g = _GUARD * (16 if dtype == th.uint8 else 1)
+        flat = th.full((n + 2 * g,), _sentinel(dtype), dtype=dtype, device=device)
+        _guards.append((flat, g, n))
+        t = flat[g:g + n].view(*shape)
+    else:
+        t = th.empty(*shape, dtype=dtype, device=device)
     if _POISON and t.numel():
         if t.dtype.is_floating_point:
             t.fill_(float("nan"))
@@ -37,6 +57,21 @@ def _out(*shape, dtype, device):
         else:
             t.fill_(-(2 ** 30) - 7)
     return t
+
+
+def check_guards() -> int:
+    """DRTK_CAPI_GUARD: assert that the sentinel elements around every output and workspace handed out since the last
+    call are intact (synchronises); returns how many allocations were checked.  Without the variable: 0."""
+    th.cuda.synchronize()
+    k = len(_guards)
+    for flat, g, n in _guards:
+        s = _sentinel(flat.dtype)
+        ok = bool((flat[:g] == s).all()) and bool((flat[g + n:] == s).all())
+        if not ok:
+            _guards.clear()
+            raise AssertionError(f"a kernel wrote outside a {flat.dtype} output / workspace of {n} elements")
+    _guards.clear()
+    return k
 
 
 

@@ -69,23 +69,13 @@ tensor_list rasterize_op(const Tensor& v, const Tensor& vi, int64_t height, int6
   return op.call(v, vi, height, width, wireframe);
 }
 
-class RasterizeFunction : public torch::autograd::Function<RasterizeFunction> {
- public:
-  static tensor_list forward(
-      AutogradContext* ctx, const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {
-    ctx->set_materialize_grads(false);
-    at::AutoDispatchBelowADInplaceOrView g;
-    auto outputs = rasterize_op(v, vi, height, width, wireframe);
-    ctx->mark_non_differentiable(outputs); // rasterize_module.cpp:43
-    return outputs;
-  }
-  static tensor_list backward(AutogradContext*, const tensor_list&) {
-    return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
-  }
-};
-
+// Autograd key: rasterize has no gradient (rasterize_module.cpp:43 marks both outputs non-differentiable).  The reference
+// says so through an autograd::Function whose backward returns nothing; here no node is built at all -- the outputs
+// come back with requires_grad == False and no grad_fn, which is what mark_non_differentiable leaves behind, without
+// the node's bookkeeping on every call (a few microseconds of a small scene's launch-bound step).
 tensor_list rasterize_autograd(const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {
-  return RasterizeFunction::apply(v, vi, height, width, wireframe);
+  at::AutoDispatchBelowADInplaceOrView g;
+  return rasterize_op(v, vi, height, width, wireframe);
 }
 
 tensor_list rasterize_autocast(const Tensor& v, const Tensor& vi, int64_t height, int64_t width, bool wireframe) {

@@ -8,8 +8,13 @@
 //   linalg.inv_ex + mask
 // which materialises ~40 floats per pixel in intermediate images.  Here it is ONE kernel: lane = pixel,
 // reads index (4 B) + bary (12 B), gathers the triangle's 3 positions and 3 uvs, writes 16 B.
-// The arithmetic follows the composite step by step (including the x*b0 + x*b1 + x*b2 form that
-// `interpolate` gives a per-face constant), the two 2x2 inverses are closed-form adjugates.
+// The arithmetic follows the composite's steps (including the x*b0 + x*b1 + x*b2 form that `interpolate` gives a
+// per-face constant) with ONE algebraic change: the composite inverts the UV edge matrix A, pushes A^-1 dpdb through
+// the (linear) interpolation and pinhole Jacobian to J = A^-1 G, and inverts again; J^-1 = G^-1 A is evaluated here
+// directly.  Same function, one 2x2 inverse (closed-form adjugate, compensated determinant) instead of two, and no
+// rounding error amplified by cond(A): on UV slivers the two-inverse form -- in f32, the composite's LU as well as a
+// closed form -- is 10-30x further from the f64 result than this one (tests/fuzz_next_ops.py, seeds 450324, 760460).
+// A face with zero UV area, for which the reference raises, gets the finite limit.
 // Pinhole cameras only, like project_points_grad itself (distortion raises NotImplementedError there).
 #include "common.hpp"
 
@@ -43,34 +48,13 @@ __global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
       const T* r = vt_n + int64_t(ft[k]) * 2;
       t[k][0] = r[0], t[k][1] = r[1];
     }
-    // face_dpdt: dtdb_t = [[t1-t0],[t2-t0]] (rows), dpdb_t = [[p1-p0],[p2-p0]]
+    // face_dpdt's two edge matrices: A = dtdb_t = [[t1-t0],[t2-t0]] (rows), dpdb_t = [[p1-p0],[p2-p0]]
     const T a = t[1][0] - t[0][0], b = t[1][1] - t[0][1];
     const T c = t[2][0] - t[0][0], d = t[2][1] - t[0][1];
-    const T det = a * d - b * c;
-    // one reciprocal per 2x2 inverse / per perspective divide instead of four (two) IEEE divisions: the reference's own
-    // inverse is an LU solve, so neither form reproduces its roundings -- the bar of this operator is the f64 fixture
-    // and the f32 error quantiles (tests/fuzz_next_ops.py), and a float division is a ten-instruction sequence
-    // (below ~1e-30 -- 1e-200 in double -- the reciprocal itself overflows where the quotients may still be finite: true
-    // divisions there; a wave takes that path only if one of its faces is that degenerate)
-    const T kTinyDet = sizeof(T) == 4 ? T(1e-30) : T(1e-200);
-    const T rdet = T(1) / det;
-    T i00 = d * rdet, i01 = -b * rdet, i10 = -c * rdet, i11 = a * rdet; // inverse(dtdb_t)
-    if (fabs(det) < kTinyDet) i00 = d / det, i01 = -b / det, i10 = -c / det, i11 = a / det;
-    T dpdt[2][3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const T e1 = p[1][j] - p[0][j], e2 = p[2][j] - p[0][j];
-      dpdt[0][j] = i00 * e1 + i01 * e2;
-      dpdt[1][j] = i10 * e1 + i11 * e2;
-    }
-    // the two interpolate() calls: per-face constant -> x*b0 + x*b1 + x*b2 ; positions -> sum b_k p_k
+    // the interpolate() of the positions: sum b_k p_k
     T P[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      dpdt[0][j] = dpdt[0][j] * b0 + dpdt[0][j] * b1 + dpdt[0][j] * b2;
-      dpdt[1][j] = dpdt[1][j] * b0 + dpdt[1][j] * b1 + dpdt[1][j] * b2;
-      P[j] = p[0][j] * b0 + p[1][j] * b1 + p[2][j] * b2;
-    }
+    for (int j = 0; j < 3; ++j) P[j] = p[0][j] * b0 + p[1][j] * b1 + p[2][j] * b2;
     // project_points_grad (pinhole)
     const T* R = camrot + int64_t(n) * 9;
     const T* cp = campos + int64_t(n) * 3;
@@ -82,25 +66,39 @@ __global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
     const T e = T(1e-8);
     z = z < T(0) ? (z < -e ? z : -e) : (z > e ? z : e);
     const T rzz = T(1) / (z * z);
-    T J[2][2]; // J[i][j] = d p_pix[j] / d t[i]
+    // G[k][j] = d p_pix[j] along the position edge k (p_{k+1} - p_0), carrying the interpolate() of a per-face constant
+    // (x*b0 + x*b1 + x*b2).  The composite's J = A^-1 G (every step after dp/dt = A^-1 dpdb_t is linear in its rows), so
+    // its result J^-1 = G^-1 A: the UV edge matrix is never inverted.
+    T G[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const T gx = R[0] * dpdt[i][0] + R[1] * dpdt[i][1] + R[2] * dpdt[i][2];
-      const T gy = R[3] * dpdt[i][0] + R[4] * dpdt[i][1] + R[5] * dpdt[i][2];
-      const T gz = R[6] * dpdt[i][0] + R[7] * dpdt[i][1] + R[8] * dpdt[i][2];
+    for (int k = 0; k < 2; ++k) {
+      T g[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const T ek = p[k + 1][j] - p[0][j];
+        g[j] = ek * b0 + ek * b1 + ek * b2;
+      }
+      const T gx = R[0] * g[0] + R[1] * g[1] + R[2] * g[2];
+      const T gy = R[3] * g[0] + R[4] * g[1] + R[5] * g[2];
+      const T gz = R[6] * g[0] + R[7] * g[1] + R[8] * g[2];
       const T px = (gx * z - cx * gz) * rzz;
       const T py = (gy * z - cy * gz) * rzz;
-      J[i][0] = K[0] * px + K[1] * py;
-      J[i][1] = K[2] * px + K[3] * py;
+      G[k][0] = K[0] * px + K[1] * py;
+      G[k][1] = K[2] * px + K[3] * py;
     }
-    // vt_dxdy = inverse(J): [i][j] = d t[j] / d p_pix[i]
-    const T dj = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    // det G by Kahan's difference of products (the rounding error of one product recovered with an fma): 1.5 ulp
+    const T w = G[0][1] * G[1][0];
+    const T dj = fma(G[0][0], G[1][1], -w) + fma(-G[0][1], G[1][0], w);
+    // one reciprocal instead of four IEEE divisions (a float division is a ten-instruction sequence); below ~1e-30
+    // (1e-200 in double) the reciprocal itself overflows where the quotients may still be finite: true divisions
+    // there -- a wave takes that path only if one of its faces is that degenerate
+    const T kTinyDet = sizeof(T) == 4 ? T(1e-30) : T(1e-200);
     const T rdj = T(1) / dj;
-    o00 = J[1][1] * rdj;
-    o01 = -J[0][1] * rdj;
-    o10 = -J[1][0] * rdj;
-    o11 = J[0][0] * rdj;
-    if (fabs(dj) < kTinyDet) o00 = J[1][1] / dj, o01 = -J[0][1] / dj, o10 = -J[1][0] / dj, o11 = J[0][0] / dj;
+    // vt_dxdy = G^-1 A: [i][j] = d t[j] / d p_pix[i]
+    const T n00 = fma(G[1][1], a, -(G[0][1] * c)), n01 = fma(G[1][1], b, -(G[0][1] * d));
+    const T n10 = fma(G[0][0], c, -(G[1][0] * a)), n11 = fma(G[0][0], d, -(G[1][0] * b));
+    o00 = n00 * rdj, o01 = n01 * rdj, o10 = n10 * rdj, o11 = n11 * rdj;
+    if (fabs(dj) < kTinyDet) o00 = n00 / dj, o01 = n01 / dj, o10 = n10 / dj, o11 = n11 / dj;
   }
   T* o = out + (int64_t(n) * HW + pix) * 4;
   if constexpr (sizeof(T) == 4) {

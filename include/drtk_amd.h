@@ -81,6 +81,10 @@ const char* drtk_amd_version(void);
  * Z-buffer rasterization of N views.  Writes index_img (triangle id, -1 where empty; lower id
  * wins depth ties) and depth_img (ALWAYS float32, 0 where empty, rasterize_kernel.cu:481) --
  * bit-exact with the reference's arithmetic (rasterize_kernel.cu:69-166).
+ * The depth's summation order is the one the reference's source spells, evaluated strictly.  A reference
+ * build compiled with -ffast-math may associate that sum differently; libdrtk_amd_depth_fastmath.so
+ * (same ABI, `python drtk_amd/build.py --depth-order fastmath`) evaluates it in the order such a build
+ * was observed to use, for deployments that must match one bit for bit.
  * `workspace` holds the tile bins; query its size first.
  * `wireframe != 0` selects the line mode (rasterize_kernel.cu:170-400: edges whose bit is set in the top
  * nibble of vi[...,0] are drawn by the diamond rule, the triangles themselves only occlude); it needs the
@@ -247,9 +251,11 @@ int drtk_amd_mipmap_grid_sampler_2d_backward(
  *   campos [N,3], camrot [N,3,3], focal [N,2,2].   Pixels with index -1 or mask 0 are written 0.
  * A face with ZERO UV AREA: the reference inverts every face's UV edge matrix up front (face_dpdt,
  * drtk/utils/geometry.py:71-82, th.inverse) and raises for the whole call, visible face or not.  This kernel works
- * per pixel: pixels of such a face get the non-finite quotients of that zero determinant, every other pixel is
- * unaffected.  In float32 the two 2x2 inverses are ill-conditioned for triangles seen edge-on; accuracy there is
- * that of the reference's float32 composite, not 1e-5 (profiles/NOTES.md section 4).
+ * per pixel and never inverts that matrix (J^-1 = (A^-1 G)^-1 is evaluated as G^-1 A, A the UV edge matrix, G the
+ * projected position edges): pixels of such a face get the finite limit, every other pixel is unaffected.  The one
+ * 2x2 inverse left is ill-conditioned for triangles seen edge-on ON SCREEN, where the derivative itself is large; in
+ * float32 the result is as near the float64 composite as the reference's float32 composite is, and 10-30x nearer on
+ * faces that are slivers in UV space (tests/fuzz_next_ops.py).
  * Forward only.  (The reference composite looks differentiable but is not: it masks the output of linalg.inv_ex in
  * place, drtk/screen_space_uv_derivative.py:79, and backward() through it raises -- recorded from the reference in
  * tests/golden/refpy_uv_derivative_autograd.npz; its consumer, mipmap_grid_sampler_2d, defines no gradient for this

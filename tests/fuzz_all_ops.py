@@ -147,6 +147,7 @@ def run_case(c, place=None):
         vg_64 = lambda: O.interpolate_backward(O.edge_grad_backward(D(v), D(img), i_o, vi, D(c["go"]), M), D(v), vi, i_o, D(rb_o), True, False)[0]  # noqa: E731
         _close_or_f64(capi.edge_grad_backward_fused(d(v), d(img), i_g, d(vi), d(rb_o), d(c["go"]), M), vg_o, vg_64,
                       f"fused edge grad M={M}", **tol)
+    capi.check_guards()  # DRTK_CAPI_GUARD=g: nothing was written outside an output or a workspace (no-op otherwise)
 
 
 def describe(c):

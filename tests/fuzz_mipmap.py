@@ -63,6 +63,15 @@ def make_case(seed):
 
 
 def run_case(c, place=None):
+    """One case; with DRTK_CAPI_GUARD=g in the environment also: nothing was written outside an output or a workspace."""
+    from drtk_amd import capi
+
+    out = _run_case(c, place)
+    capi.check_guards()
+    return out
+
+
+def _run_case(c, place=None):
     """`place(tensor)` puts an input on the device (default: a plain copy; fuzz_all_ops.misaligned for odd pointers)."""
     import oracle as O
     from drtk_amd import capi

@@ -62,6 +62,15 @@ def make_case(seed):
 
 
 def run_case(c):
+    """One case; with DRTK_CAPI_GUARD=g in the environment also: nothing was written outside an output or a workspace."""
+    from drtk_amd import capi
+
+    out = _run_case(c)
+    capi.check_guards()
+    return out
+
+
+def _run_case(c):
     import oracle as O
     import drtk_amd
     from drtk_amd import capi
@@ -137,15 +146,21 @@ def run_case(c):
         assert bool((got.cpu()[~mask] == 0).all()), "screen_space_uv_derivative: background / masked pixels must be 0"
         return "reference undefined: a face with zero UV area makes the reference composite raise"
     if f64:
-        # pins the formula -- per pixel, and aware of the conditioning: a face whose 2x2 Jacobian is singular up to rounding
-        # yields values of 1e13 (seed 460768: one pixel at 6.8e13, median 0.046) that move by 10 % when an input moves by
-        # one ulp; there two correct evaluations differ by as much as the oracle differs from itself on inputs one ulp apart
+        # pins the formula -- per pixel, and aware of the conditioning of the REFERENCE's evaluation: the composite inverts
+        # the UV edge matrix A and later the product A^-1 G again; on a face that is a sliver in UV space its own result
+        # moves when an input moves by one ulp (seed 460768: one pixel at 6.8e13, median 0.046, moving by 10 %).  The
+        # kernel evaluates G^-1 A and has no such error, so the distance between the two is the composite's: bounded by
+        # what the composite does on inputs one ulp apart, and not compared at all where that exceeds 1e-3 of the value
+        # (fewer than four digits left in the float64 reference).
         signs = 1.0 - 2.0 * (th.arange(c["vt"].numel(), dtype=th.float64) % 2).reshape(c["vt"].shape)  # +1, -1, +1, ...
         want_ulp = O.screen_space_uv_derivative(c["vN"], c["vt"] * (1 + 2.0 ** -52 * signs), vi, vi, index, bary, mask, campos, camrot, focal)
+        moved = (want_ulp - want).abs()
+        unstable = moved.amax((-1, -2)) > 1e-3 * want.abs().amax((-1, -2))
         err = (got.cpu() - want).abs()
-        bound = 1e-11 + 1e-10 * want.abs() + 8 * (want_ulp - want).abs()
-        worst = float((err - bound).max())
+        bound = 1e-11 + 1e-10 * want.abs() + 8 * moved
+        worst = float((err - bound)[~unstable].max()) if bool((~unstable).any()) else 0.0
         assert worst <= 0, f"screen_space_uv_derivative (f64): a pixel is {worst:.3e} beyond its conditioning-aware bound"
+        assert int(unstable.sum()) <= 0.05 * max(int(mask.sum()), 20), "screen_space_uv_derivative (f64): too many pixels set aside as unstable in the reference"
         return
     # f32: the op inverts a 2x2 Jacobian that is nearly singular for triangles seen edge-on; there two f32 evaluations
     # with different operation orders (the reference's PyTorch composite vs the kernel's closed form) scatter around
