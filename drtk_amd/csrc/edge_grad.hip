@@ -33,6 +33,12 @@ struct Vec4<double> {
   using type = double4;
 };
 
+// Four adjacent pixels of an image row as ONE 16 / 32-byte access that needs the alignment of its element only: rows
+// of an image whose width is not a multiple of four start at any element, and so do contiguous views into a flat buffer.
+// The hardware serves dword-aligned wide accesses (a wave's 64 such loads touch one cache line more than aligned ones).
+template <typename T>
+using Quad = T __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+
 // ---------------------------------------------------------------------------------------------
 // Pass A
 // ---------------------------------------------------------------------------------------------
@@ -48,9 +54,13 @@ __device__ __forceinline__ Row<T, VEC> load_row(
   Row<T, VEC> r;
   if (x_ok) {
     if constexpr (VEC == 4) {
-      using V4 = typename Vec4<T>::type;
-      const V4 q = *reinterpret_cast<const V4*>(plane + row_off + x);
-      r.v[0] = q.x, r.v[1] = q.y, r.v[2] = q.z, r.v[3] = q.w;
+      if (x + 4 <= W) {
+        const Quad<T> q = *reinterpret_cast<const Quad<T>*>(plane + row_off + x);
+        r.v[0] = q.x, r.v[1] = q.y, r.v[2] = q.z, r.v[3] = q.w;
+      } else { // the lane that holds the end of a row whose width is not a multiple of four
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.v[j] = x + j < W ? plane[row_off + x + j] : T(0);
+      }
     } else {
       r.v[0] = plane[row_off + x];
     }
@@ -71,7 +81,14 @@ __device__ __forceinline__ Row<T, VEC> load_row(
 template <typename T, int VEC, int R, int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
     const T* __restrict__ img, const T* __restrict__ grad_output, const int32_t* __restrict__ index_img, int C,
-    int H, int W, int strips_x, T* __restrict__ gdx, T* __restrict__ gdy, int strip) {
+    int H, int W, int strips_x, T* __restrict__ gdx, T* __restrict__ gdy, int strip, T* __restrict__ zero_out,
+    int64_t zero_count) {
+  // the accumulator of the pass that follows this one (grad_v_pix of the fused route) is cleared here, spread over the
+  // whole grid: one launch less per backward pass, which is what a small scene's step is made of
+  if (zero_out) {
+    const int64_t step = int64_t(gridDim.x) * gridDim.y * blockDim.x;
+    for (int64_t i = (int64_t(blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < zero_count; i += step) zero_out[i] = T(0);
+  }
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
   const int tile = tile_index(strip);
@@ -101,7 +118,13 @@ __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
         int32_t first = -1, last = -1;
         if (x < W) {
           if constexpr (VEC == 4) {
-            const int4 q = *reinterpret_cast<const int4*>(idx_n + int64_t(y) * W + x);
+            Quad<int32_t> q;
+            if (x + 4 <= W) {
+              q = *reinterpret_cast<const Quad<int32_t>*>(idx_n + int64_t(y) * W + x);
+            } else {
+              const int32_t* rp = idx_n + int64_t(y) * W + x;
+              q.x = rp[0], q.y = x + 1 < W ? rp[1] : -1, q.z = x + 2 < W ? rp[2] : -1, q.w = -1;
+            }
             fg = (q.x & q.y & q.z & q.w) != -1;
             first = q.x, last = q.w;
           } else {
@@ -155,9 +178,14 @@ __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
     if (y >= H) break;
     const int64_t o = int64_t(y) * W + x;
     if constexpr (VEC == 4) {
-      using V4 = typename Vec4<T>::type;
-      *reinterpret_cast<V4*>(ox + o) = V4{ax[r][0], ax[r][1], ax[r][2], ax[r][3]};
-      *reinterpret_cast<V4*>(oy + o) = V4{ay[r][0], ay[r][1], ay[r][2], ay[r][3]};
+      if (x + 4 <= W) {
+        *reinterpret_cast<Quad<T>*>(ox + o) = Quad<T>{ax[r][0], ax[r][1], ax[r][2], ax[r][3]};
+        *reinterpret_cast<Quad<T>*>(oy + o) = Quad<T>{ay[r][0], ay[r][1], ay[r][2], ay[r][3]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x + j < W) ox[o + j] = ax[r][j], oy[o + j] = ay[r][j];
+      }
     } else {
       ox[o] = ax[r][0];
       oy[o] = ay[r][0];
@@ -528,9 +556,9 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 // contributions (pixel A: -gA on the axis, -zA on z; pixel B: -gB, -zB; each times its own pixel's
 // barycentrics) through the run reduction of segscatter.hpp with six corner slots (A0..A2, B0..B2) and
 // two components each.
-// IDX_VEC: index_img is 16-byte aligned (its rows are fetched as int4); otherwise four scalar loads per row --
-// the only global vector access of this kernel, so that a contiguous but merely element-aligned index_img (a view
-// into a flat buffer) stays on the fused route.  W % 4 == 0 in both cases.
+// Any width, any element-aligned pointers: the index rows are the only wide global access of this kernel (Quad, above),
+// everything else is per pair.  (Rounds 2-3 took this route for W % 4 == 0 only and sent other widths through the
+// unfused one: 2.2x the time at 2048 x 2046.)
 #ifndef DRTK_PAIR_ROWS
 #define DRTK_PAIR_ROWS 2
 #endif
@@ -542,7 +570,7 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 // Narrower tiles instead (2 pixels per lane, 128 x 2 or 128 x 4): 0.80-0.84 ms against 0.72-0.76 -- the 8-byte index
 // loads and half-empty pair rounds cost more than the extra waves bring.
 constexpr int kPairRows = DRTK_PAIR_ROWS;
-template <typename T, bool IDX_VEC>
+template <typename T>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_pairs_kernel(
     const T* __restrict__ v_pix, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
     const T* __restrict__ bary_img, const T* __restrict__ gdx, const T* __restrict__ gdy, int64_t V, int64_t vi_sN,
@@ -584,13 +612,13 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_p
   for (int r = 0; r <= kRows; ++r) {
     const int y = y_base + r;
     if (in_x && y < H) {
-      const int32_t* rp = idx_n + int64_t(y) * W + x0; // x0 % 4 == 0 and W % 4 == 0: x0 + 3 < W
-      if constexpr (IDX_VEC) {
-        const int4 q = *reinterpret_cast<const int4*>(rp);
+      const int32_t* rp = idx_n + int64_t(y) * W + x0;
+      if (x0 + 4 <= W) {
+        const Quad<int32_t> q = *reinterpret_cast<const Quad<int32_t>*>(rp);
         row[r][0] = q.x, row[r][1] = q.y, row[r][2] = q.z, row[r][3] = q.w;
-      } else {
+      } else { // the end of a row whose width is not a multiple of four
 #pragma unroll
-        for (int j = 0; j < 4; ++j) row[r][j] = rp[j];
+        for (int j = 0; j < 4; ++j) row[r][j] = x0 + j < W ? rp[j] : -1;
       }
     } else {
 #pragma unroll
@@ -750,15 +778,12 @@ int edge_grad_backward_impl(
       (reinterpret_cast<uintptr_t>(grad_output) % (4 * sizeof(T)) == 0) &&
       (reinterpret_cast<uintptr_t>(workspace) % (4 * sizeof(T)) == 0) &&
       (reinterpret_cast<uintptr_t>(index_img) % 16 == 0);
-  const int px_per_wave = (kWave - 1) * (vec ? 4 : 1); // lane 63 = halo
+  // pass A takes any width and any element-aligned placement (Quad); `vec` only picks pass B's kernel
+  const int px_per_wave = (kWave - 1) * 4; // lane 63 = halo
   const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
-  if (vec) {
-    DRTK_LAUNCH((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
-  } else {
-    DRTK_LAUNCH((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
-  }
+  DRTK_LAUNCH((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))), static_cast<T*>(nullptr), int64_t(0));
   DRTK_RETURN_IF_LAUNCH_FAILED();
   const bool vec_out = vec && (reinterpret_cast<uintptr_t>(index_img) % 16 == 0) &&
       (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0);
@@ -775,16 +800,12 @@ int edge_grad_backward_impl(
 
 // pass A shared by both routes
 template <typename T>
-int launch_edge_dots(const T* img, const T* grad_output, const int32_t* index_img, int64_t N, int64_t C, int64_t H, int64_t W, T* gdx, T* gdy, bool vec, hipStream_t stream) {
-  const int px_per_wave = (kWave - 1) * (vec ? 4 : 1); // lane 63 = halo
+int launch_edge_dots(const T* img, const T* grad_output, const int32_t* index_img, int64_t N, int64_t C, int64_t H, int64_t W, T* gdx, T* gdy, hipStream_t stream, T* zero_out, int64_t zero_count) {
+  const int px_per_wave = (kWave - 1) * 4; // lane 63 = halo
   const int strips_x = static_cast<int>(ceil_div(W, px_per_wave));
   const int bands_y = static_cast<int>(ceil_div(H, kStripRows * kDotsWaves));
   const dim3 gridA(static_cast<unsigned>(int64_t(strips_x) * bands_y), static_cast<unsigned>(N));
-  if (vec) {
-    DRTK_LAUNCH((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
-  } else {
-    DRTK_LAUNCH((edge_dots_kernel<T, 1, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))));
-  }
+  DRTK_LAUNCH((edge_dots_kernel<T, 4, kStripRows, kDotsWaves>), gridA, dim3(kDotsWaves * kWave), 0, stream, img, grad_output, index_img, (int)C, (int)H, (int)W, strips_x, gdx, gdy, xcd_strip(int64_t(strips_x) * (16 / (kStripRows * kDotsWaves))), zero_out, zero_count);
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }
@@ -800,37 +821,24 @@ int edge_grad_backward_fused_impl(
     int64_t H, int64_t W, double max_dp_dr, T* grad_v_pix, void* workspace, size_t workspace_bytes,
     hipStream_t stream) {
   const int64_t HW = H * W;
-  if (N * V > 0 && fill_bytes_async(grad_v_pix, 0, sizeof(T) * N * V * 3, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
-  if (N * HW == 0) return DRTK_OK;
-  T* gdx = static_cast<T*>(workspace);
-  T* gdy = gdx + N * HW;
-  if (W % 4 == 0) {
-    // The ROUTE -- and with it the workspace, 2 planes here against 5 below -- is decided by the shape alone,
-    // exactly like drtk_amd_edge_grad_backward_fused_workspace_bytes(), which sees no pointers.  Pointer alignment
-    // only picks the load width inside the route: inputs that are contiguous but merely element-aligned (views
-    // into a flat buffer) used to fall through to the 5-plane route with the 2 planes the query had promised.
-    const bool vec_a = aligned_to(img, 4 * sizeof(T)) && aligned_to(grad_output, 4 * sizeof(T)) &&
-        aligned_to(workspace, 4 * sizeof(T)) && aligned_to(index_img, 16);
-    const int st = launch_edge_dots<T>(img, grad_output, index_img, N, C, H, W, gdx, gdy, vec_a, stream);
-    if (st != DRTK_OK) return st;
-    const int strips_x = static_cast<int>(ceil_div(W, kWave * 4));
-    const int64_t waves = int64_t(strips_x) * ceil_div(H, kPairRows);
-    const dim3 grid(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
-    const int strip = xcd_strip(ceil_div(int64_t(strips_x) * (16 / kPairRows), kBlock / kWave));
-    if (aligned_to(index_img, 16)) {
-      DRTK_LAUNCH((edge_scatter_pairs_kernel<T, true>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
-    } else {
-      DRTK_LAUNCH((edge_scatter_pairs_kernel<T, false>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
-    }
-    DRTK_RETURN_IF_LAUNCH_FAILED();
+  if (N * HW == 0) { // (otherwise grad_v_pix is cleared inside the first kernel)
+    if (N * V > 0 && fill_bytes_async(grad_v_pix, 0, sizeof(T) * N * V * 3, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
     return DRTK_OK;
   }
-  // generic sizes: the unfused route through a scratch grad_v_pix_img (needs 5 planes of workspace)
-  if (workspace_bytes < sizeof(T) * 5 * N * HW) return DRTK_ERR_WORKSPACE_TOO_SMALL;
-  T* tmp = gdy + N * HW;
-  int st = edge_grad_backward_impl<T>(v_pix, img, index_img, vi, grad_output, N, V, C, vi_sN, H, W, max_dp_dr, tmp, workspace, stream);
+  // One route for every shape and every element-aligned placement of the tensors (two planes of workspace): both kernels
+  // fetch four adjacent pixels per access with the alignment of the element and handle the end of a row whose width is
+  // not a multiple of four lane by lane.
+  T* gdx = static_cast<T*>(workspace);
+  T* gdy = gdx + N * HW;
+  const int st = launch_edge_dots<T>(img, grad_output, index_img, N, C, H, W, gdx, gdy, stream, grad_v_pix, N * V * 3);
   if (st != DRTK_OK) return st;
-  return drtk_amd_interpolate_backward(dtype, tmp, v_pix, vi, index_img, bary_img, N, V, 3, F, vi_sN, H, W, grad_v_pix, nullptr, stream);
+  const int strips_x = static_cast<int>(ceil_div(W, kWave * 4));
+  const int64_t waves = int64_t(strips_x) * ceil_div(H, kPairRows);
+  const dim3 grid(static_cast<unsigned>(ceil_div(waves, kBlock / kWave)), static_cast<unsigned>(N));
+  const int strip = xcd_strip(ceil_div(int64_t(strips_x) * (16 / kPairRows), kBlock / kWave));
+  DRTK_LAUNCH((edge_scatter_pairs_kernel<T>), grid, dim3(kBlock), 0, stream, v_pix, vi, index_img, bary_img, gdx, gdy, V, vi_sN, (int)H, (int)W, strips_x, static_cast<T>(max_dp_dr), grad_v_pix, strip);
+  DRTK_RETURN_IF_LAUNCH_FAILED();
+  return DRTK_OK;
 }
 
 } // namespace
@@ -879,8 +887,7 @@ extern "C" int drtk_amd_edge_grad_backward_fused_workspace_bytes(
     drtk_dtype_t dtype, int64_t N, int64_t H, int64_t W, size_t* bytes) {
   if (!bytes || N < 0 || H < 0 || W < 0 || (dtype != DRTK_F32 && dtype != DRTK_F64)) return DRTK_ERR_INVALID_ARGUMENT;
   const size_t es = dtype == DRTK_F32 ? 4 : 8;
-  const size_t planes = (W % 4 == 0) ? 2 : 5;
-  const size_t b = planes * N * H * W * es;
+  const size_t b = size_t(2) * N * H * W * es;
   *bytes = b > 0 ? b : 16;
   return DRTK_OK;
 }

@@ -93,6 +93,17 @@ def main():
     t_sync = time.perf_counter() - t1
     say(f"(a) {a.steps} eager steps, queue kept full: host enqueue {t_enq / a.steps * 1e3:.4f} ms/step, "
         f"to completion {t_full / a.steps * 1e3:.4f} ms/step; with a synchronize after each: {t_sync / a.steps * 1e3:.4f} ms/step")
+    # (a') the box's own host speed, to compare runs on different boxes: an ATen launch on a small tensor
+    x = th.zeros(1024, device=dev)
+    for _ in range(200):
+        x.add_(1.0)
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        x.add_(1.0)
+    t_add = (time.perf_counter() - t0) / 2000
+    th.cuda.synchronize()
+    say(f"(a') host calibration: one small aten::add_ enqueued in {t_add * 1e6:.2f} us on this box; the eager step's enqueue = {t_enq / a.steps / t_add:.1f} such launches")
     # (c)
     clock = {}
     th.cuda.synchronize()

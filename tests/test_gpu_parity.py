@@ -1366,6 +1366,24 @@ def test_contiguous_inputs_at_odd_element_offsets():
     assert float(grads[0].abs().max()) > 0
 
 
+@pytest.mark.parametrize("guard", [1, 3])
+def test_no_kernel_writes_outside_its_outputs_or_workspaces(guard):
+    """Every output and workspace of the C-ABI binding carved out of a larger allocation with `guard` sentinel elements on
+    either side (DRTK_CAPI_GUARD, drtk_amd/capi.py) -- which also makes every output merely element-aligned -- and the
+    fuzzers of all operators run on top: results against the oracle as usual, sentinels intact after every case.  The
+    shapes include widths of 1, 3, 5, 63, 66, 127, 258, 323: the rows whose end falls inside a lane's four pixels on the
+    render and edge-gradient routes (element-aligned 16-byte accesses, last lane pixel by pixel)."""
+    import subprocess
+
+    env = dict(os.environ, DRTK_CAPI_GUARD=str(guard), DRTK_CAPI_POISON="1")
+    for script, first, cases in (("fuzz_all_ops.py", 3000 + 100 * guard, 80), ("fuzz_mipmap.py", 3000 + 100 * guard, 80),
+                                 ("fuzz_next_ops.py", 3000 + 100 * guard, 40)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script), "--first", str(first), "--cases", str(cases)],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+        assert r.returncode == 0, f"{script} with {guard} guard element(s):\n{r.stdout[-2000:]}"
+        assert f"{cases}/{cases} cases passed" in r.stdout, r.stdout[-500:]
+
+
 def test_c_abi_output_and_workspace_pointers_at_odd_element_offsets():
     """A C caller sub-allocating from an arena: OUTPUT pointers that are only element-aligned (ptr % 16 = 4, 8, 12)
     give the bit-identical images and nothing is written outside them -- rasterize stores its tiles as 16-byte
