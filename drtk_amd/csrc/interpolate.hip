@@ -34,7 +34,11 @@ struct Vec4<double> {
 // SIMD instead of 5 -- and is still faster: 0.573 -> 0.548-0.560 ms on the bench shape, 2.46 -> 2.18 at 8 x 4096^2,
 // 1.46 -> 1.30 at C = 32.  With a single chunk (C = 4) there is nothing to prefetch and only the registers are paid
 // (0.216 -> 0.232 ms): that case keeps the plain loop.
-template <typename T, int VEC, int CV, bool PREFETCH = false>
+// ANYW (VEC = 4): any W >= 4 and any element-aligned placement of index / bary / out -- the lane's four consecutive
+// pixels may run over the end of a row (each gets its own coordinates for the background sweep), the accesses need the
+// element's alignment only, and the last lane of a view whose pixel count is not a multiple of four goes pixel by pixel
+// (round 4; before, such images took one pixel per lane: 1.2x the time at 2048 x 2046).
+template <typename T, int VEC, int CV, bool PREFETCH = false, bool ANYW = false>
 __global__ __launch_bounds__(kBlock) void interpolate_kernel(
     const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
@@ -50,9 +54,31 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
   const T* bary_p = bary_img + int64_t(n) * 3 * HW + pix0;
   T* out_p = out + int64_t(n) * C * HW + pix0;
 
+  typedef int32_t IQuad __attribute__((ext_vector_type(4), aligned(4)));
+  typedef T TQuad __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+  static_assert(!ANYW || VEC == 4, "ANYW is a variant of the four-pixel lane");
+  const bool whole = !ANYW || pix0 + 4 <= HW; // all four pixels belong to this view
   int32_t tr[VEC];
   T B0[VEC], B1[VEC], B2[VEC];
-  if constexpr (VEC == 4) {
+  if constexpr (ANYW) {
+    if (whole) {
+      const IQuad t4 = *reinterpret_cast<const IQuad*>(idx_p);
+      tr[0] = t4.x, tr[1] = t4.y, tr[2] = t4.z, tr[3] = t4.w;
+      const TQuad a = *reinterpret_cast<const TQuad*>(bary_p);
+      const TQuad b = *reinterpret_cast<const TQuad*>(bary_p + HW);
+      const TQuad c = *reinterpret_cast<const TQuad*>(bary_p + 2 * HW);
+      B0[0] = a.x, B0[1] = a.y, B0[2] = a.z, B0[3] = a.w;
+      B1[0] = b.x, B1[1] = b.y, B1[2] = b.z, B1[3] = b.w;
+      B2[0] = c.x, B2[1] = c.y, B2[2] = c.z, B2[3] = c.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const bool in = pix0 + j < HW;
+        tr[j] = in ? idx_p[j] : -1;
+        B0[j] = in ? bary_p[j] : T(0), B1[j] = in ? bary_p[HW + j] : T(0), B2[j] = in ? bary_p[2 * HW + j] : T(0);
+      }
+    }
+  } else if constexpr (VEC == 4) {
     const int4 t4 = *reinterpret_cast<const int4*>(idx_p);
     tr[0] = t4.x, tr[1] = t4.y, tr[2] = t4.z, tr[3] = t4.w;
     const V4 a = *reinterpret_cast<const V4*>(bary_p);
@@ -71,9 +97,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
   const T* a0[VEC];
   const T* a1[VEC];
   const T* a2[VEC];
-  T bgx[VEC];
-  // "undefined region" sweep (interpolate_kernel.cu:104-108, CPU twin interpolate_kernel_cpu.cpp:99-104)
-  const T bgy = (static_cast<T>(y) * T(2.0) + T(1.0)) / static_cast<T>(H) - T(1.0);
+  T bgx[VEC], bgy[VEC];
   // corner ids of the lane's pixels: UNCONDITIONAL loads (a background pixel reads face 0 and discards it) so that the
   // VEC x 3 of them form one batch -- under `if (covered)` every pixel's three loads sat in their own exec-masked region
   // with an s_waitcnt behind them: four dependent round trips per lane before the first attribute row was requested
@@ -99,8 +123,29 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
     a0[j] = attrs_n + int64_t(fid[j][0]) * C;
     a1[j] = attrs_n + int64_t(fid[j][1]) * C;
     a2[j] = attrs_n + int64_t(fid[j][2]) * C;
-    bgx[j] = (static_cast<T>(x0 + j) * T(2.0) + T(1.0)) / static_cast<T>(W) - T(1.0);
+    // "undefined region" sweep (interpolate_kernel.cu:104-108, CPU twin interpolate_kernel_cpu.cpp:99-104)
+    int xj = x0 + j, yj = y;
+    if constexpr (ANYW) {
+      if (xj >= W) xj -= W, yj += 1; // W >= 4: at most one row further
+    }
+    bgx[j] = (static_cast<T>(xj) * T(2.0) + T(1.0)) / static_cast<T>(W) - T(1.0);
+    bgy[j] = (static_cast<T>(yj) * T(2.0) + T(1.0)) / static_cast<T>(H) - T(1.0);
   }
+  // one row of four pixels' values to a channel plane
+  auto store4 = [&](T* o, T r0, T r1, T r2, T r3) {
+    if constexpr (ANYW) {
+      if (whole) {
+        *reinterpret_cast<TQuad*>(o) = TQuad{r0, r1, r2, r3};
+      } else {
+        const T r[4] = {r0, r1, r2, r3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (pix0 + j < HW) o[j] = r[j];
+      }
+    } else {
+      *reinterpret_cast<V4*>(o) = V4{r0, r1, r2, r3};
+    }
+  };
 
   if constexpr (PREFETCH) {
     static_assert(CV == 4 && VEC == 4, "the prefetching loop is written for 4 pixels x 4 channels");
@@ -137,13 +182,12 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
           for (int cc = 0; cc < CV; ++cc) r[cc][j] = u0[cc] * B0[j] + u1[cc] * B1[j] + u2[cc] * B2[j];
         } else {
 #pragma unroll
-          for (int cc = 0; cc < CV; ++cc) r[cc][j] = zero_background ? T(0) : (((c0 + cc) & 1) ? bgy : bgx[j]);
+          for (int cc = 0; cc < CV; ++cc) r[cc][j] = zero_background ? T(0) : (((c0 + cc) & 1) ? bgy[j] : bgx[j]);
         }
       }
 #pragma unroll
       for (int cc = 0; cc < CV; ++cc) {
-        T* o = out_p + int64_t(c0 + cc) * HW;
-        *reinterpret_cast<V4*>(o) = V4{r[cc][0], r[cc][1], r[cc][2], r[cc][3]};
+        store4(out_p + int64_t(c0 + cc) * HW, r[cc][0], r[cc][1], r[cc][2], r[cc][3]);
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -179,14 +223,14 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
         for (int cc = 0; cc < CV; ++cc) r[cc][j] = u0[j][cc] * B0[j] + u1[j][cc] * B1[j] + u2[j][cc] * B2[j];
       } else {
 #pragma unroll
-        for (int cc = 0; cc < CV; ++cc) r[cc][j] = zero_background ? T(0) : (((c0 + cc) & 1) ? bgy : bgx[j]);
+        for (int cc = 0; cc < CV; ++cc) r[cc][j] = zero_background ? T(0) : (((c0 + cc) & 1) ? bgy[j] : bgx[j]);
       }
     }
 #pragma unroll
     for (int cc = 0; cc < CV; ++cc) {
       T* o = out_p + int64_t(c0 + cc) * HW;
       if constexpr (VEC == 4) {
-        *reinterpret_cast<V4*>(o) = V4{r[cc][0], r[cc][1], r[cc][2], r[cc][3]};
+        store4(o, r[cc][0], r[cc][1], r[cc][2], r[cc][3]);
       } else {
         o[0] = r[cc][0];
       }
@@ -815,7 +859,7 @@ int interpolate_impl(
 #define LAUNCH(VEC, CV, ...)                                                                    \
   DRTK_LAUNCH(                                                                           \
       (interpolate_kernel<T, VEC, CV, ##__VA_ARGS__>),                                          \
-      dim3(static_cast<unsigned>(ceil_div(HW / VEC, kBlock)), static_cast<unsigned>(N)), block, \
+      dim3(static_cast<unsigned>(ceil_div(ceil_div(HW, VEC), kBlock)), static_cast<unsigned>(N)), block, \
       0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out, zero_background, \
       xcd_strip(ceil_div(16 * W, int64_t(kBlock) * VEC)))
   if (pvec && cvec && C > 4 && V * C < (int64_t(1) << 31)) // (32-bit row offsets in the prefetching loop)
@@ -824,6 +868,12 @@ int interpolate_impl(
     LAUNCH(4, 4);
   else if (pvec)
     LAUNCH(4, 1);
+  else if (W >= 4 && cvec && C > 4 && V * C < (int64_t(1) << 31)) // widths that are not a multiple of four, views into flat buffers
+    LAUNCH(4, 4, true, true);
+  else if (W >= 4 && cvec)
+    LAUNCH(4, 4, false, true);
+  else if (W >= 4)
+    LAUNCH(4, 1, false, true);
   else if (cvec)
     LAUNCH(1, 4);
   else

@@ -311,28 +311,29 @@ def test_batch_at_bench_shape_every_pixel_written_and_last_views_match_oracle(cf
     assert bool((rb.sum(1)[~cov] == 0).all()) and float((rb.sum(1)[cov] - 1).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("cfg", [("100k", 2048, 16), ("250k", 2048, 16), ("1M", 4096, 4)])
+@pytest.mark.parametrize("cfg", [("100k", 2048, 2048, 16), ("250k", 2048, 2048, 16), ("1M", 4096, 4096, 4), ("100k", 2048, 1334, 16), ("100k", 1023, 667, 3)])
 def test_full_size_view_matches_oracle(cfg):
     """One view of BASELINE.json configs[2], [3] and [4] at FULL resolution against the CPU oracle (all host
     threads; it finishes in seconds for one view): index_img and rasterize depth bit-exact, render /
-    interpolate forward and all four backward passes at the 1e-5 bar."""
+    interpolate forward and all four backward passes at the 1e-5 bar.  The last two shapes are the reference's usual
+    portrait images, 2048 x 1334 and 1023 x 667: widths with W % 4 = 2 and 3, whose rows end inside a lane's four pixels."""
     import oracle as O
     from drtk_amd import capi
     from drtk_amd import synthetic as S
 
-    mesh, res, C = cfg
+    mesh, H, W, C = cfg
     nl, no = S.MESH_SIZES[mesh]
-    v, vi = S.sphere_views(1, nl, no, res, res, lobes=0.05)
+    v, vi = S.sphere_views(1, nl, no, H, W, lobes=0.05)
     g = th.Generator().manual_seed(11)
     attr = th.rand(1, v.shape[1], C, generator=g)
-    go = th.rand(1, C, res, res, generator=g) * 2 - 1
-    gd = th.rand(1, res, res, generator=g) * 2 - 1
-    gbar = th.rand(1, 3, res, res, generator=g) * 2 - 1
+    go = th.rand(1, C, H, W, generator=g) * 2 - 1
+    gd = th.rand(1, H, W, generator=g) * 2 - 1
+    gbar = th.rand(1, 3, H, W, generator=g) * 2 - 1
 
-    d_o, i_o = O.rasterize(v, vi, res, res, nthreads=0)
-    d_g, i_g = capi.rasterize(dev(v), dev(vi), res, res)
+    d_o, i_o = O.rasterize(v, vi, H, W, nthreads=0)
+    d_g, i_g = capi.rasterize(dev(v), dev(vi), H, W)
     assert th.equal(i_g.cpu(), i_o) and th.equal(d_g.cpu(), d_o)
-    assert int((i_o >= 0).sum()) > 0.4 * res * res
+    assert int((i_o >= 0).sum()) > 0.25 * H * W
     rd_o, rb_o = O.render(v, vi, i_o, nthreads=0)
     rd_g, rb_g = capi.render(dev(v), dev(vi), i_g)
     assert th.equal(rd_g.cpu(), rd_o) and th.equal(rb_g.cpu(), rb_o), "render forward is not bit-identical"
