@@ -717,7 +717,7 @@ constexpr int kWinCells = win_cells_before(kWinLevels);
 // them: SQ counters of the runtime-parameter version showed 490 scalar and 950 vector instructions per wave).
 template <typename T, int PAD, bool ALIGN>
 // (3 workgroups per CU by registers as by LDS; reflection padding needs ~190: 2)
-__global__ __launch_bounds__(kMipBlock, PAD == 2 ? 2 : 3) void mipmap_backward_tiled_kernel(
+__global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : 3)) void mipmap_backward_tiled_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
     const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
@@ -1193,7 +1193,7 @@ __device__ __forceinline__ void wave_minmax2(int x, int y, bool on, int& x0, int
 // MODE 0: bilinear (2 x 2 texels per tap); MODE 2: bicubic (4 x 4: mipmap_grid_sampler_kernel.cu:806-861) -- the same windows with
 // a span of four cells, interior taps (sixteen consecutive texels inside the level) windowed, the others corner by corner.
 template <typename T, int PAD, bool ALIGN, int MODE = 0>
-__global__ __launch_bounds__(kMipBlock, MODE == 2 ? 2 : DRTK_MIP_WAVE_OCC) void mipmap_backward_wave_kernel(
+__global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (MODE == 2 ? 2 : DRTK_MIP_WAVE_OCC)) void mipmap_backward_wave_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
     const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
@@ -1729,7 +1729,11 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   GridLayout gl, ggl;
   if (make_grid_layout(gl, grid_layout, grid, H, W, es) != DRTK_OK || make_grid_layout(ggl, grad_grid_layout, grad_grid, H, W, es) != DRTK_OK)
     return DRTK_ERR_INVALID_ARGUMENT;
-  // bilinear f32: C <= 4 takes the workgroup-tiled kernel, wider textures (neural textures, 8-16 channels) the
+  // The windowed kernels (LDS accumulators in double whatever the element type) serve float and double alike: the
+  // reference dispatches both (kernel_utils.h:35-57).  Returns 1 when the shape is not theirs.
+  auto windowed = [&](auto tag) -> int {
+    using T = decltype(tag);
+  // bilinear: C <= 4 takes the workgroup-tiled kernel, wider textures (neural textures, 8-16 channels) the
   // wave-private one in blocks of four channels -- before round 4 they fell to the direct kernel, bound by the float-atomic
   // request rate.  (-DDRTK_MIP_BACKWARD_WAVE_ALL: the wave kernel for every C, for A/B; at C = 3 it is slower than the
   // tiled one -- 2.52 against 1.95 ms on the textured benchmark at the same 3 waves per SIMD.)
@@ -1738,25 +1742,25 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
 #else
   constexpr int64_t kWaveFromC = 5;
 #endif
-  // bicubic f32 (any C >= 1): the same wave-private windows with 4 x 4 cells per tap (before round 4: the direct kernel,
+  // bicubic (any C >= 1): the same wave-private windows with 4 x 4 cells per tap (before round 4: the direct kernel,
   // sixteen global float atomics per tap, level and channel -- 89 ms against 1.96 ms bilinear on the textured benchmark)
-  if (((interpolation_mode == 0 && C >= kWaveFromC) || (interpolation_mode == 2 && C >= 1)) && N <= 65535 && dtype == DRTK_F32 &&
+  if (((interpolation_mode == 0 && C >= kWaveFromC) || (interpolation_mode == 2 && C >= 1)) && N <= 65535 &&
       !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
     const size_t lds = sizeof(double) * (C < kChBlock ? C : kChBlock) * kWaveCells * (kMipBlock / kWave);
 #define WAVEK(PAD, ALIGN)                                                                                               \
   if (interpolation_mode == 2)                                                                                          \
     DRTK_LAUNCH(                                                                                                        \
-        (mipmap_backward_wave_kernel<float, PAD, ALIGN, 2>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
-        dim3(kMipBlock), lds, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid), gl, \
-        static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, force_max_aniso != 0,     \
-        clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags());                        \
+        (mipmap_backward_wave_kernel<T, PAD, ALIGN, 2>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+        dim3(kMipBlock), lds, s, lv, mipmaps, static_cast<const T*>(grad_out), static_cast<const T*>(grid), gl, \
+        static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, force_max_aniso != 0,     \
+        clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags());                        \
   else                                                                                                                  \
   DRTK_LAUNCH(                                                                                                          \
-      (mipmap_backward_wave_kernel<float, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
-      dim3(kMipBlock), lds, s, lv, mipmaps, static_cast<const float*>(grad_out), static_cast<const float*>(grid), gl,  \
-      static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, force_max_aniso != 0,        \
-      clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
+      (mipmap_backward_wave_kernel<T, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      dim3(kMipBlock), lds, s, lv, mipmaps, static_cast<const T*>(grad_out), static_cast<const T*>(grid), gl,  \
+      static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, force_max_aniso != 0,        \
+      clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
     if (align_corners) {
       if (padding_mode == 0) WAVEK(0, true); else if (padding_mode == 1) WAVEK(1, true); else WAVEK(2, true);
     } else {
@@ -1766,14 +1770,14 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;
   }
-  if (interpolation_mode == 0 && C <= 4 && N <= 65535 && dtype == DRTK_F32 && !DRTK_DBG(debug_flags(), 512)) {
+  if (interpolation_mode == 0 && C <= 4 && N <= 65535 && !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
 #define TILED(PAD, ALIGN)                                                                                                \
   DRTK_LAUNCH(                                                                                                           \
-      (mipmap_backward_tiled_kernel<float, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
-      dim3(kMipBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const float*>(grad_out),              \
-      static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
-      force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
+      (mipmap_backward_tiled_kernel<T, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      dim3(kMipBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const T*>(grad_out),              \
+      static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
+      force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
     if (align_corners) {
       if (padding_mode == 0) TILED(0, true); else if (padding_mode == 1) TILED(1, true); else TILED(2, true);
     } else {
@@ -1782,6 +1786,12 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
 #undef TILED
     DRTK_RETURN_IF_LAUNCH_FAILED();
     return DRTK_OK;
+  }
+    return 1;
+  };
+  {
+    const int w = dtype == DRTK_F32 ? windowed(float{}) : windowed(double{});
+    if (w != 1) return w;
   }
   const dim3 grid_dim(static_cast<unsigned>(ceil_div(count, kBlock)));
 #define LAUNCH(T, MODE)                                                                                       \

@@ -1049,6 +1049,9 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
       const int nbig = big_count[n];
       const int64_t img_base = int64_t(n) * H * W;
       const bool vec_ok = (W & 3) == 0;
+      // 16-byte stores that need the element's alignment only (rows of any width, output views at any element offset)
+      typedef int32_t IQuad __attribute__((ext_vector_type(4), aligned(4)));
+      typedef float FQuad __attribute__((ext_vector_type(4), aligned(4)));
       const int quads_per_row = ss >> 2;
       if ((item & kItemEmpty) && nbig == 0) {
         // nothing can touch this tile: background straight to the images, no LDS tile, no barrier
@@ -1061,9 +1064,9 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
           int none = -1;
           float zero = 0.0f;
           asm volatile("" : "+v"(none), "+v"(zero)); // constants made here (see `cleared` below)
-          if (vec_ok) {
-            *reinterpret_cast<int4*>(index_img + o) = make_int4(none, none, none, none);
-            *reinterpret_cast<float4*>(depth_img + o) = make_float4(zero, zero, zero, zero);
+          if (vec_ok || x + 3 <= x1) { // whole quad inside the row: one 16-byte store, element-aligned when W % 4 != 0
+            *reinterpret_cast<IQuad*>(index_img + o) = IQuad{none, none, none, none};
+            *reinterpret_cast<FQuad*>(depth_img + o) = FQuad{zero, zero, zero, zero};
           } else {
             for (int j = 0; j < 4 && x + j <= x1; ++j) {
               index_img[o + j] = none;
@@ -1329,9 +1332,9 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
           idx4[j] = static_cast<int32_t>(static_cast<uint32_t>(pv & 0xFFFFFFFFu));
         }
         const int64_t o = img_base + int64_t(y) * W + x;
-        if (vec_ok) { // x % 4 == 0 and W % 4 == 0 -> x+3 < W and 16-byte aligned
-          *reinterpret_cast<int4*>(index_img + o) = make_int4(idx4[0], idx4[1], idx4[2], idx4[3]);
-          *reinterpret_cast<float4*>(depth_img + o) = make_float4(dep4[0], dep4[1], dep4[2], dep4[3]);
+        if (vec_ok || x + 3 <= x1) { // W % 4 == 0 (x % 4 == 0 -> x + 3 < W), or a quad that ends inside the row
+          *reinterpret_cast<IQuad*>(index_img + o) = IQuad{idx4[0], idx4[1], idx4[2], idx4[3]};
+          *reinterpret_cast<FQuad*>(depth_img + o) = FQuad{dep4[0], dep4[1], dep4[2], dep4[3]};
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

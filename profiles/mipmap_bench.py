@@ -19,6 +19,7 @@ ap.add_argument("--tex", type=int, default=4096)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--channels", type=int, default=3, help="texture channels (3 = the textured configuration; 8 / 16: neural textures -- the wave-private backward kernel)")
 ap.add_argument("--bicubic", action="store_true")
+ap.add_argument("--f64", action="store_true", help="the sampler's inputs in double (the reference dispatches float and double alike)")
 ap.add_argument("--flags", default="0")
 ap.add_argument("--lib", default="")
 ap.add_argument("--stats", action="store_true")
@@ -105,12 +106,15 @@ def timeit(fn):
     return e0.elapsed_time(e1) / a.reps
 
 
+if a.f64:
+    tex = [t.double() for t in tex]
+    grid, jac, go = grid.double(), jac.double(), go.double()
 for flags in [int(x) for x in a.flags.split(",")]:
     set_flags(flags)
     MODE = 2 if a.bicubic else 0
     f = timeit(lambda: capi.mipmap_grid_sampler_2d(tex, grid, jac, 8, 1, MODE))
     b = timeit(lambda: capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, MODE))
-    print(f"flags={flags} C={a.channels}{' bicubic' if a.bicubic else ''}: mipmap fwd {f:.3f} ms   bwd (incl. zero-fill of the pyramid) {b:.3f} ms")
+    print(f"flags={flags} C={a.channels}{' bicubic' if a.bicubic else ''}{' f64' if a.f64 else ''}: mipmap fwd {f:.3f} ms   bwd (incl. zero-fill of the pyramid) {b:.3f} ms")
 set_flags(0)
 
 if a.dump:

@@ -1,11 +1,11 @@
 # Re-measures the table of profiles/NOTES.md section 5 of the other BASELINE.json configurations (parity cases, not bench lines):
-# one bench.py run each, 10 timed steps, CPU-baseline leg skipped.  One JSON line per row in gpurun_out/configs/.
+# one bench.py run each, 10 timed steps (200 for the launch-bound configs[1]), CPU-baseline leg skipped.  One JSON line per row in gpurun_out/configs/.
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/configs
 rm -rf $OUT; mkdir -p $OUT
-run() { name=$1; shift; timeout 400 python3 bench.py --steps 10 --warmup 3 --cpu-sample-views 0 "$@" 2> $OUT/$name.err | grep "^{" > $OUT/$name.json; }
-run config2_10k_512_v4_c3         --config 2
+run() { name=$1; shift; timeout 400 python3 bench.py --steps ${STEPS:-10} --warmup 3 --cpu-sample-views 0 "$@" 2> $OUT/$name.err | grep "^{" > $OUT/$name.json; }
+STEPS=200 run config2_10k_512_v4_c3 --config 2   # a 0.4 ms step: ten of them are shorter than one scheduler hiccup
 run config3_100k_2048_v8_c16      --config 3
 run config4_250k_2048_v8_c16      --config 4
 run config5_textured_1M_4096_v2   --config 5
