@@ -346,8 +346,11 @@ def test_committed_profile_artefacts_describe_one_collection():
         # bench workload, not the handful of launches of the CPU-baseline / set-up phase)
         step_kernels = [(n, a) for n, c, a in stats if c >= bench["steps"]]
         top = max(step_kernels, key=lambda t: t[1])
-        assert top[0] == k, f"{rdir}: roofline prices {k} but the largest kernel of the step is {top}"
-        assert abs(top[1] / 1e3 - roof["ms_per_launch"]) <= 0.05 * roof["ms_per_launch"], (top, roof["ms_per_launch"])
+        priced = [a for n, a in step_kernels if n == k]
+        # (round 4: interpolate backward and edge_dots are within 1 % of each other -- 579.8 and 583.7 us under rocprofv3,
+        # 594 and 579 under the bench's own events -- so "the largest" may be either side of a tie)
+        assert priced and priced[0] >= 0.97 * top[1], f"{rdir}: roofline prices {k} but the largest kernel of the step is {top}"
+        assert abs(priced[0] / 1e3 - roof["ms_per_launch"]) <= 0.05 * roof["ms_per_launch"], (priced, roof["ms_per_launch"])
         mine = [rec["hbm_bytes"] for name, rec in traffic.items() if name.split("<")[0] == k]
         assert mine and int(mine[0]) == roof["traffic"], f"{rdir}: bench_n1.json and traffic.json are from different collections"
         assert abs(roof["frac_traffic"] - roof["traffic"] / (roof["ms_per_launch"] * 1e-3) / 1e9 / roof["peak"]) < 1e-3
