@@ -56,7 +56,10 @@ def _check_common(d, n_gpus):
     # ONE HIP kernel is priced: the one with the largest per-launch time among the kernels that stream per-pixel tensors
     ks = d["path_roofline"]["kernels"]
     priced = {k: r for k, r in ks.items() if r["bytes_per_px"]}
-    assert rf["kernel"] == max(priced, key=lambda k: priced[k]["ms_per_launch"]) and rf["ms_per_launch"] == priced[rf["kernel"]]["ms_per_launch"]
+    # (within 3 % of the largest: a tie goes to the kernel furthest below the roofline, bench.py)
+    t_max = max(r["ms_per_launch"] for r in priced.values())
+    tied = [k for k, r in priced.items() if r["ms_per_launch"] >= 0.97 * t_max]
+    assert rf["kernel"] == min(tied, key=lambda k: priced[k]["GBps"]) and rf["ms_per_launch"] == priced[rf["kernel"]]["ms_per_launch"]
     P = d["config"]["views_per_gpu"] * d["config"]["height"] * d["config"]["width"]
     assert rf["algorithmic_bytes"] == rf["bytes_per_px"] * P
     assert abs(rf["achieved"] - rf["algorithmic_bytes"] / (rf["ms_per_launch"] * 1e-3) / 1e9) < 1.0
