@@ -862,13 +862,19 @@ int interpolate_impl(
       dim3(static_cast<unsigned>(ceil_div(ceil_div(HW, VEC), kBlock)), static_cast<unsigned>(N)), block, \
       0, stream, attrs, vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, out, zero_background, \
       xcd_strip(ceil_div(16 * W, int64_t(kBlock) * VEC)))
-  if (pvec && cvec && C > 4 && V * C < (int64_t(1) << 31)) // (32-bit row offsets in the prefetching loop)
+  // (double: the prefetching loop needs 254 VGPRs -- one wave per SIMD -- and loses to the plain one at two: 1.26 vs
+  // 1.15 ms at 8 x 2048^2, C = 16, same box)
+#ifndef DRTK_INTERP_F64_PREFETCH
+#define DRTK_INTERP_F64_PREFETCH 0
+#endif
+  const bool prefetch = sizeof(T) == 4 || DRTK_INTERP_F64_PREFETCH;
+  if (pvec && cvec && C > 4 && V * C < (int64_t(1) << 31) && prefetch) // (32-bit row offsets in the prefetching loop)
     LAUNCH(4, 4, true);
   else if (pvec && cvec)
     LAUNCH(4, 4);
   else if (pvec)
     LAUNCH(4, 1);
-  else if (W >= 4 && cvec && C > 4 && V * C < (int64_t(1) << 31)) // widths that are not a multiple of four, views into flat buffers
+  else if (W >= 4 && cvec && C > 4 && V * C < (int64_t(1) << 31) && prefetch) // widths that are not a multiple of four, views into flat buffers
     LAUNCH(4, 4, true, true);
   else if (W >= 4 && cvec)
     LAUNCH(4, 4, false, true);
