@@ -176,6 +176,21 @@ def _run_case(c):
     e_g = (got.cpu().double() - truth).abs().amax((-1, -2))
     e_r = (want.double() - truth).abs().amax((-1, -2))
     assert bool(th.isfinite(got).all())
+    # EVERY pixel of every case, in units of the problem's own sensitivity: how far the f64 result moves when each vertex
+    # and uv coordinate moves by half an f32 ulp (two sign patterns), plus one ulp of the value.  A forward-stable
+    # evaluation stays within a small multiple of that however ill-conditioned the pixel is.  Measured over 546 cases /
+    # 944 k pixels (tests/diag_uv_derivative_conditioning.py): kernel 50 / 90 / 99 / 99.9 / 100 % = 0.39 / 0.95 / 1.8 / 3.0 /
+    # 19 units -- the reference's float32 composite 0.52 / 1.8 / 16 / 108 / 2405.  The bar: 64.
+    sens = th.zeros_like(e_g)
+    for ph in (0, 1):
+        sg = lambda t: 1.0 - 2.0 * ((th.arange(t.numel(), dtype=th.float64) + ph) % 2).reshape(t.shape)  # noqa: E731
+        moved = O.screen_space_uv_derivative(c["vN"].double() * (1 + 2.0 ** -24 * sg(c["vN"])), c["vt"].double() * (1 + 2.0 ** -24 * sg(c["vt"])),
+                                             vi, vi, index, bary.double(), mask, campos.double(), camrot.double(), focal.double())
+        sens = th.maximum(sens, (moved - truth).abs().amax((-1, -2)))
+    unit = sens + 2.0 ** -23 * truth.abs().amax((-1, -2))
+    over = (e_g / unit.clamp_min(1e-300))[mask]
+    assert over.numel() == 0 or float(over.max()) <= 64.0, \
+        f"screen_space_uv_derivative (f32): a pixel is {float(over.max()):.1f} units of its own sensitivity off the f64 result (bar 64)"
     scale = float(truth.abs().max())
     assert float(e_g.max()) <= 100 * float(e_r.max()) + 1e-4 * scale + 1e-30, \
         f"screen_space_uv_derivative (f32): worst pixel {float(e_g.max()):.3e} vs f64, the reference composite's {float(e_r.max()):.3e}"
