@@ -21,6 +21,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _capi_guards_intact():
+    """With DRTK_CAPI_GUARD=g in the environment (a diagnostic run of the whole GPU suite: every output and workspace of the
+    ctypes binding sits between g sentinel elements and is merely element-aligned), check after each test that no kernel
+    wrote outside what it was given.  Without the variable: nothing."""
+    yield
+    if os.environ.get("DRTK_CAPI_GUARD", "0") not in ("", "0"):
+        capi = sys.modules.get("drtk_amd.capi")
+        if capi is not None and th.cuda.is_available():
+            capi.check_guards()
+
+
 def load_golden(name):
     """Returns (inputs, outputs) dicts of torch tensors / python ints from tests/golden/<name>.npz."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
