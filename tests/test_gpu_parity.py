@@ -1645,9 +1645,9 @@ def test_kernel_timing_brackets_every_launch_and_changes_nothing():
     close(got[2], ref[2], "v.grad under timing", atol=1e-7, rtol=1e-5)  # atomics order only
     close(got[3], ref[3], "attr.grad under timing", atol=1e-7, rtol=1e-5)
     names = {}
-    for k, v in rep.items():  # (instantiations of one kernel -- aligned / element-aligned outputs -- count together)
-        n0, t0 = names.get(k.split("<")[0], (0, 0.0))
-        names[k.split("<")[0]] = (n0 + v[0], t0 + v[1])
+    for kname, rec in rep.items():  # (instantiations of one kernel -- aligned / element-aligned outputs -- count together)
+        n0, t0 = names.get(kname.split("<")[0], (0, 0.0))
+        names[kname.split("<")[0]] = (n0 + rec[0], t0 + rec[1])
     for k, launches in (("bin_count_kernel", 3), ("bin_scan_kernel", 3), ("bin_fill_kernel", 3), ("tile_raster_kernel", 3), ("render_kernel", 4),
                         ("interpolate_kernel", 3), ("edge_dots_kernel", 3), ("edge_scatter_pairs_kernel", 3),
                         ("interpolate_backward_wide_kernel", 3), ("render_backward_kernel", 3)):
