@@ -21,6 +21,62 @@
 namespace drtk_amd {
 namespace {
 
+// The per-pixel arithmetic: p[k] / t[k] = positions / uvs of the pixel's triangle, b* its barycentrics, R / cp / K the view's
+// camera.  Shared by the two kernels below (same operations, same order).
+template <typename T>
+__device__ __forceinline__ void uv_jacobian(
+    const T (&p)[3][3], const T (&t)[3][2], T b0, T b1, T b2, const T* __restrict__ R, const T* __restrict__ cp,
+    const T* __restrict__ K, T& o00, T& o01, T& o10, T& o11) {
+  // face_dpdt's two edge matrices: A = dtdb_t = [[t1-t0],[t2-t0]] (rows), dpdb_t = [[p1-p0],[p2-p0]]
+  const T a = t[1][0] - t[0][0], b = t[1][1] - t[0][1];
+  const T c = t[2][0] - t[0][0], d = t[2][1] - t[0][1];
+  // the interpolate() of the positions: sum b_k p_k
+  T P[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) P[j] = p[0][j] * b0 + p[1][j] * b1 + p[2][j] * b2;
+  // project_points_grad (pinhole)
+  const T dx = P[0] - cp[0], dy = P[1] - cp[1], dz = P[2] - cp[2];
+  const T cx = R[0] * dx + R[1] * dy + R[2] * dz;
+  const T cy = R[3] * dx + R[4] * dy + R[5] * dz;
+  T z = R[6] * dx + R[7] * dy + R[8] * dz;
+  const T e = T(1e-8);
+  z = z < T(0) ? (z < -e ? z : -e) : (z > e ? z : e);
+  const T rzz = T(1) / (z * z);
+  // G[k][j] = d p_pix[j] along the position edge k (p_{k+1} - p_0), carrying the interpolate() of a per-face constant
+  // (x*b0 + x*b1 + x*b2).  The composite's J = A^-1 G (every step after dp/dt = A^-1 dpdb_t is linear in its rows), so
+  // its result J^-1 = G^-1 A: the UV edge matrix is never inverted.
+  T G[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    T g[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const T ek = p[k + 1][j] - p[0][j];
+      g[j] = ek * b0 + ek * b1 + ek * b2;
+    }
+    const T gx = R[0] * g[0] + R[1] * g[1] + R[2] * g[2];
+    const T gy = R[3] * g[0] + R[4] * g[1] + R[5] * g[2];
+    const T gz = R[6] * g[0] + R[7] * g[1] + R[8] * g[2];
+    const T px = (gx * z - cx * gz) * rzz;
+    const T py = (gy * z - cy * gz) * rzz;
+    G[k][0] = K[0] * px + K[1] * py;
+    G[k][1] = K[2] * px + K[3] * py;
+  }
+  // det G by Kahan's difference of products (the rounding error of one product recovered with an fma): 1.5 ulp
+  const T w = G[0][1] * G[1][0];
+  const T dj = fma(G[0][0], G[1][1], -w) + fma(-G[0][1], G[1][0], w);
+  // one reciprocal instead of four IEEE divisions (a float division is a ten-instruction sequence); below ~1e-30
+  // (1e-200 in double) the reciprocal itself overflows where the quotients may still be finite: true divisions
+  // there -- a wave takes that path only if one of its faces is that degenerate
+  const T kTinyDet = sizeof(T) == 4 ? T(1e-30) : T(1e-200);
+  const T rdj = T(1) / dj;
+  // vt_dxdy = G^-1 A: [i][j] = d t[j] / d p_pix[i]
+  const T n00 = fma(G[1][1], a, -(G[0][1] * c)), n01 = fma(G[1][1], b, -(G[0][1] * d));
+  const T n10 = fma(G[0][0], c, -(G[1][0] * a)), n11 = fma(G[0][0], d, -(G[1][0] * b));
+  o00 = n00 * rdj, o01 = n01 * rdj, o10 = n10 * rdj, o11 = n11 * rdj;
+  if (fabs(dj) < kTinyDet) o00 = n00 / dj, o01 = n01 / dj, o10 = n10 / dj, o11 = n11 / dj;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
     const T* __restrict__ v, int64_t v_sN, const T* __restrict__ vt, int64_t vt_sN,
@@ -48,57 +104,7 @@ __global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
       const T* r = vt_n + int64_t(ft[k]) * 2;
       t[k][0] = r[0], t[k][1] = r[1];
     }
-    // face_dpdt's two edge matrices: A = dtdb_t = [[t1-t0],[t2-t0]] (rows), dpdb_t = [[p1-p0],[p2-p0]]
-    const T a = t[1][0] - t[0][0], b = t[1][1] - t[0][1];
-    const T c = t[2][0] - t[0][0], d = t[2][1] - t[0][1];
-    // the interpolate() of the positions: sum b_k p_k
-    T P[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) P[j] = p[0][j] * b0 + p[1][j] * b1 + p[2][j] * b2;
-    // project_points_grad (pinhole)
-    const T* R = camrot + int64_t(n) * 9;
-    const T* cp = campos + int64_t(n) * 3;
-    const T* K = focal + int64_t(n) * 4;
-    const T dx = P[0] - cp[0], dy = P[1] - cp[1], dz = P[2] - cp[2];
-    const T cx = R[0] * dx + R[1] * dy + R[2] * dz;
-    const T cy = R[3] * dx + R[4] * dy + R[5] * dz;
-    T z = R[6] * dx + R[7] * dy + R[8] * dz;
-    const T e = T(1e-8);
-    z = z < T(0) ? (z < -e ? z : -e) : (z > e ? z : e);
-    const T rzz = T(1) / (z * z);
-    // G[k][j] = d p_pix[j] along the position edge k (p_{k+1} - p_0), carrying the interpolate() of a per-face constant
-    // (x*b0 + x*b1 + x*b2).  The composite's J = A^-1 G (every step after dp/dt = A^-1 dpdb_t is linear in its rows), so
-    // its result J^-1 = G^-1 A: the UV edge matrix is never inverted.
-    T G[2][2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      T g[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const T ek = p[k + 1][j] - p[0][j];
-        g[j] = ek * b0 + ek * b1 + ek * b2;
-      }
-      const T gx = R[0] * g[0] + R[1] * g[1] + R[2] * g[2];
-      const T gy = R[3] * g[0] + R[4] * g[1] + R[5] * g[2];
-      const T gz = R[6] * g[0] + R[7] * g[1] + R[8] * g[2];
-      const T px = (gx * z - cx * gz) * rzz;
-      const T py = (gy * z - cy * gz) * rzz;
-      G[k][0] = K[0] * px + K[1] * py;
-      G[k][1] = K[2] * px + K[3] * py;
-    }
-    // det G by Kahan's difference of products (the rounding error of one product recovered with an fma): 1.5 ulp
-    const T w = G[0][1] * G[1][0];
-    const T dj = fma(G[0][0], G[1][1], -w) + fma(-G[0][1], G[1][0], w);
-    // one reciprocal instead of four IEEE divisions (a float division is a ten-instruction sequence); below ~1e-30
-    // (1e-200 in double) the reciprocal itself overflows where the quotients may still be finite: true divisions
-    // there -- a wave takes that path only if one of its faces is that degenerate
-    const T kTinyDet = sizeof(T) == 4 ? T(1e-30) : T(1e-200);
-    const T rdj = T(1) / dj;
-    // vt_dxdy = G^-1 A: [i][j] = d t[j] / d p_pix[i]
-    const T n00 = fma(G[1][1], a, -(G[0][1] * c)), n01 = fma(G[1][1], b, -(G[0][1] * d));
-    const T n10 = fma(G[0][0], c, -(G[1][0] * a)), n11 = fma(G[0][0], d, -(G[1][0] * b));
-    o00 = n00 * rdj, o01 = n01 * rdj, o10 = n10 * rdj, o11 = n11 * rdj;
-    if (fabs(dj) < kTinyDet) o00 = n00 / dj, o01 = n01 / dj, o10 = n10 / dj, o11 = n11 / dj;
+    uv_jacobian<T>(p, t, b0, b1, b2, camrot + int64_t(n) * 9, campos + int64_t(n) * 3, focal + int64_t(n) * 4, o00, o01, o10, o11);
   }
   T* o = out + (int64_t(n) * HW + pix) * 4;
   if constexpr (sizeof(T) == 4) {
@@ -107,6 +113,13 @@ __global__ __launch_bounds__(kBlock) void uv_derivative_kernel(
     o[0] = o00, o[1] = o01, o[2] = o10, o[3] = o11;
   }
 }
+
+// (Round 4, measured and not kept: four consecutive pixels per lane for float -- index / barycentrics as element-aligned
+// 16-byte accesses, the face ids of all four pixels as one batch, then their 36 + 24 vertex / uv values as one batch, 64
+// contiguous bytes stored per lane.  The one-pixel kernel's waves wait 77 % of their cycles on that chain of three dependent
+// round trips, at 8 waves per SIMD; the batched one has 114 VGPRs, 4 waves per SIMD, and is SLOWER: 0.424 vs 0.343 ms
+// through the C ABI on the textured benchmark's 2 x 4096^2 pixels -- twice the loads per wave in flight do not make up for
+// half the waves.  Parity was green: fuzz_next_ops 3000.)
 
 } // namespace
 } // namespace drtk_amd

@@ -19,6 +19,7 @@ ap.add_argument("--tex", type=int, default=4096)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--channels", type=int, default=3, help="texture channels (3 = the textured configuration; 8 / 16: neural textures -- the wave-private backward kernel)")
 ap.add_argument("--bicubic", action="store_true")
+ap.add_argument("--uv", action="store_true", help="also time screen_space_uv_derivative on the same scene (through the C ABI: --lib applies)")
 ap.add_argument("--f64", action="store_true", help="the sampler's inputs in double (the reference dispatches float and double alike)")
 ap.add_argument("--flags", default="0")
 ap.add_argument("--lib", default="")
@@ -106,6 +107,10 @@ def timeit(fn):
     return e0.elapsed_time(e1) / a.reps
 
 
+if a.uv:
+    vw = v_world[None].expand(a.views, -1, -1).contiguous()
+    args_uv = (vw, vtn, vi, vti, index, bary, mask, campos, camrot, focal)
+    print(f"screen_space_uv_derivative: {timeit(lambda: capi.screen_space_uv_derivative(*args_uv)):.4f} ms")
 if a.f64:
     tex = [t.double() for t in tex]
     grid, jac, go = grid.double(), jac.double(), go.double()
