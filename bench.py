@@ -34,6 +34,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this platform needs dmabuf IPC (the image exports it already; kept here so that a bare launcher
+# environment works too) -- must be in place before the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch as th
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

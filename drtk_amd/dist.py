@@ -15,6 +15,10 @@ One process per GPU; launch with `python -m torch.distributed.run --nproc-per-no
 import os
 from typing import Iterable, List, Optional, Tuple
 
+# RCCL between processes needs dmabuf IPC on this platform (hipIpcGetMemHandle fails otherwise); only effective if nothing has
+# initialised the HIP runtime yet, which is the case when a launcher script imports this module first
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch as th
 import torch.distributed as dist
 
