@@ -28,12 +28,20 @@ KERNEL_SRCS = ["rasterize.hip", "rasterize_lines.hip", "render.hip", "interpolat
 HEADERS = ["common.hpp", "segscatter.hpp"]
 LIB = os.path.join(PKG, "libdrtk_amd.so")
 OPS = os.path.join(PKG, "drtk_amd_torch_ops.so")
+EXPORTS_MAP = os.path.join(CSRC, "exports.map")
+# the C ABI and nothing else in the dynamic symbol table: -fvisibility=hidden (include/drtk_amd.h pushes `default` around
+# its declarations) + a version script that also localises what the toolchain adds (__hip_cuid_*)
+LINK_FLAGS = [f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS_MAP}"]
 
 # No fast-math, no FMA contraction: coverage/depth/classification are exact float decisions.
 HIP_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-    "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", f"-I{INC}", f"-I{CSRC}",
+    "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", f"-I{INC}", f"-I{CSRC}",
 ]
+
+
+def _kernel_deps():
+    return [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [EXPORTS_MAP, os.path.join(INC, "drtk_amd.h"), __file__]
 
 
 def _run(cmd):
@@ -91,7 +99,7 @@ def check_no_vgpr_spills(compiler_output, what):
 
 
 def build_kernels(force=False, verbose=True):
-    deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
+    deps = _kernel_deps()
     if not force and _newer(LIB, deps, " ".join(HIP_FLAGS)):
         return LIB
     objs, cmds = [], []
@@ -104,7 +112,7 @@ def build_kernels(force=False, verbose=True):
     for s, out in zip(KERNEL_SRCS, outs):
         check_no_vgpr_spills(out, s)
     outs = ["\n".join(l for l in out.splitlines() if "remark:" not in l and "[-Rpass-analysis" not in l and l.strip() not in ("^",) and not l.lstrip().startswith(("|", "^")) and not l.strip().split(" | ")[0].strip().isdigit()) for out in outs]
-    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
+    _run([HIPCC, *LINK_FLAGS, "-o", LIB, *objs])
     for o in objs:
         os.remove(o)
     _stamp(LIB, deps, " ".join(HIP_FLAGS))
@@ -121,7 +129,7 @@ def build_ablation(force=False, verbose=True):
     """profiles/libdrtk_amd_ablate.so: the same sources with -DDRTK_AMD_ABLATION, i.e. WITH the phase switches
     and `drtk_amd_debug_set_flags` (csrc/common.hpp).  A profiling tool's library (profiles/kernel_bench.py
     --flags ...); it lives outside the package, the product never loads it and build_all() does not build it."""
-    deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
+    deps = _kernel_deps()
     if not force and _newer(ABLATE_LIB, deps, "ablation"):
         return ABLATE_LIB
     objs, cmds = [], []
@@ -131,7 +139,7 @@ def build_ablation(force=False, verbose=True):
         cmds.append([HIPCC, *HIP_FLAGS, "-DDRTK_AMD_ABLATION", "-c", os.path.join(CSRC, s), "-o", o])
     with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
         list(ex.map(_run, cmds))
-    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", ABLATE_LIB, *objs])
+    _run([HIPCC, *LINK_FLAGS, "-o", ABLATE_LIB, *objs])
     for o in objs:
         os.remove(o)
     _stamp(ABLATE_LIB, deps, "ablation")
@@ -150,7 +158,7 @@ def build_variant(out, defines, verbose=True):
         cmds.append([HIPCC, *HIP_FLAGS, *[d if d.startswith("-") else f"-D{d}" for d in defines], "-c", os.path.join(CSRC, s), "-o", o])
     with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
         list(ex.map(_run, cmds))
-    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs])
+    _run([HIPCC, *LINK_FLAGS, "-o", out, *objs])
     for o in objs:
         os.remove(o)
     if verbose:
@@ -169,7 +177,7 @@ def build_depth_fastmath(force=False, verbose=True):
     default, and nothing loads this one unless asked (drtk_amd.capi.use_depth_order("fastmath") before the first call,
     or DRTK_AMD_DEPTH_ORDER=fastmath in the environment).  Pinned by tests/test_gpu_parity.py::
     test_depth_fastmath_variant_reproduces_the_reference_as_built."""
-    deps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
+    deps = _kernel_deps()
     extra = " ".join(HIP_FLAGS) + " -DDRTK_DEPTH_FASTMATH_ORDER"
     if not force and _newer(FASTMATH_DEPTH_LIB, deps, extra):
         return FASTMATH_DEPTH_LIB
@@ -184,7 +192,7 @@ def build_depth_fastmath(force=False, verbose=True):
         outs = list(ex.map(_run, cmds))
     for s, out in zip(KERNEL_SRCS, outs):
         check_no_vgpr_spills(out, s + " (depth-order variant)")
-    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", FASTMATH_DEPTH_LIB, *objs])
+    _run([HIPCC, *LINK_FLAGS, "-o", FASTMATH_DEPTH_LIB, *objs])
     for o in objs:
         os.remove(o)
     _stamp(FASTMATH_DEPTH_LIB, deps, extra)
@@ -261,9 +269,18 @@ def build_ext_modules(force=False, verbose=True):
     return outs
 
 
-def build_all(force=False, verbose=True):
+def build_all(force=False, verbose=True, depth_fastmath=None):
+    """The product: kernels + C ABI, torch-operator shim, `import drtk` modules.  The depth-order variant is an OFFERED
+    extra nothing loads by default: it is built when asked for (`--with-depth-fastmath`, DRTK_AMD_BUILD_DEPTH_FASTMATH=1,
+    __graft_entry__.build() asks: a GPU test pins it), and a failure there never fails the product build."""
     build_kernels(force=force, verbose=verbose)
-    build_depth_fastmath(force=force, verbose=verbose)
+    if depth_fastmath is None:
+        depth_fastmath = os.environ.get("DRTK_AMD_BUILD_DEPTH_FASTMATH", "0") == "1"
+    if depth_fastmath:
+        try:
+            build_depth_fastmath(force=force, verbose=verbose)
+        except RuntimeError as e:  # optional variant: report, keep going
+            print(f"[drtk_amd] WARNING: the optional depth-order variant did not build:\n{e}", file=sys.stderr)
     build_torch_ops(force=force, verbose=verbose)
     build_ext_modules(force=force, verbose=verbose)
     return LIB, OPS
@@ -277,7 +294,7 @@ def _state(target, deps, extra=""):
 
 def dry_run():
     """What build_all() would do, without compiling anything."""
-    kdeps = [os.path.join(CSRC, f) for f in KERNEL_SRCS + HEADERS] + [os.path.join(INC, "drtk_amd.h"), __file__]
+    kdeps = _kernel_deps()
     odeps = _ops_deps()
     for target, deps, extra in ((LIB, kdeps, " ".join(HIP_FLAGS)), (OPS, odeps, "")):
         print(f"[drtk_amd] {target}: {_state(target, deps, extra)}")
@@ -295,4 +312,4 @@ if __name__ == "__main__":
     elif "--ablation" in sys.argv:
         build_ablation(force="--force" in sys.argv)
     else:
-        build_all(force="--force" in sys.argv)
+        build_all(force="--force" in sys.argv, depth_fastmath=True if "--with-depth-fastmath" in sys.argv else None)

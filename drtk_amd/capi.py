@@ -102,7 +102,9 @@ def lib() -> ctypes.CDLL:
             use_depth_order("fastmath")
         path = _lib_path or native_library_paths()[0]
         if not os.path.isfile(path):
-            raise ImportError(f"{path} is missing: run `python {os.path.join(os.path.dirname(path), 'build.py')}`")
+            build_py = os.path.join(os.path.dirname(os.path.abspath(__file__)), "build.py")
+            how = f"python {build_py} --depth-order fastmath" if path.endswith("libdrtk_amd_depth_fastmath.so") else f"python {build_py}"
+            raise ImportError(f"{path} is missing: run `{how}`")
         L = ctypes.CDLL(path)
         L.drtk_amd_status_string.restype = ctypes.c_char_p
         L.drtk_amd_status_string.argtypes = [ctypes.c_int]

@@ -997,6 +997,14 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
   constexpr int kTriWords = sizeof(TriRow<T>) / 4;
   static_assert(sizeof(TriRow<T>) % 4 == 0, "TriRow is parked in LDS word by word");
   __shared__ uint32_t s_tri[kCoopMin > 0 ? kCoopBatch * kTriWords : 1];
+  // the batch's set-up deals kCoopBatch / kRasterWaves entries to the first lanes of every wave (any other
+  // DRTK_RASTER_BLOCK would leave entries of s_tri unset), and the launcher's resident-workgroup count assumes
+  // raster_waves_per_simd / 2 workgroups per CU also fit by LDS (160 KiB per CU)
+  static_assert(kCoopBatch % kRasterWaves == 0 && kCoopBatch / kRasterWaves <= kWave, "cooperative batch set-up needs kRasterWaves | kCoopBatch");
+  static_assert(
+      (sizeof(unsigned long long) * NPIX + sizeof(uint32_t) * (TILE / 8) * (TILE / 8) + 2 * sizeof(int32_t) * kRasterWaves * kIdRing +
+       sizeof(int32_t) * kCoopMax + sizeof(uint32_t) * kCoopBatch * kTriWords + 64) * (raster_waves_per_simd<T>() * 4 / kRasterWaves > 0 ? raster_waves_per_simd<T>() * 4 / kRasterWaves : 1) <= 160 * 1024,
+      "tile_raster's static LDS no longer fits the workgroups per CU its launch bounds ask for");
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid & (kWave - 1);

@@ -55,6 +55,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden and a linker version script (drtk_amd/csrc/exports.map): the functions
+ * declared between this push and its pop are its ENTIRE dynamic symbol table (tests/test_host_logic.py checks nm -D). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define DRTK_AMD_VERSION_MAJOR 0
 #define DRTK_AMD_VERSION_MINOR 3
 
@@ -301,6 +307,10 @@ int drtk_amd_selftest_exact_div(
  * returns DRTK_ERR_WORKSPACE_TOO_SMALL.  Process-global, serialised by a mutex. */
 int drtk_amd_kernel_timing_begin(void);
 int drtk_amd_kernel_timing_report(char* buf, size_t capacity, size_t* needed);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,9 @@ def test_c_abi_exports_every_declared_symbol():
     syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "drtk_amd", "libdrtk_amd.so")], capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r" T (drtk_amd_\w+)", syms)))
     assert exported == declared, set(exported) ^ set(declared)
+    # NO other defined dynamic symbol of any kind (C++ internals, toolchain ids): -fvisibility=hidden + csrc/exports.map
+    others = [l for l in syms.splitlines() if l.strip() and not re.search(r" T drtk_amd_\w+$", l)]
+    assert not others, others
     assert "debug" not in syms
     csrc = os.path.join(ROOT, "drtk_amd", "csrc")
     for path in [os.path.join(d, f) for d, _, files in os.walk(csrc) for f in files]:
