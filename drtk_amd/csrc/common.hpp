@@ -135,6 +135,31 @@ inline int64_t ceil_div(int64_t a, int64_t b) {
   return (a + b - 1) / b;
 }
 
+// The view is blockIdx.y of every image kernel (65 535 at most per launch): an entry point that is handed more views --
+// the reference's grid-stride kernels take any N (render_kernel.cu:349-377) -- calls itself on consecutive slices of
+// at most kMaxViewsPerLaunch views (views are independent: same results, a few more launches).
+constexpr int64_t kMaxViewsPerLaunch = 65535;
+inline size_t dtype_size(drtk_dtype_t d) { return d == DRTK_F32 ? 4 : 8; }
+inline const void* advance(const void* p, int64_t elements, size_t elem_size) {
+  return p ? static_cast<const char*>(p) + elements * int64_t(elem_size) : nullptr;
+}
+inline void* advance(void* p, int64_t elements, size_t elem_size) {
+  return p ? static_cast<char*>(p) + elements * int64_t(elem_size) : nullptr;
+}
+template <typename P>
+inline P* advance_typed(P* p, int64_t elements) {
+  return p ? p + elements : nullptr;
+}
+#define DRTK_FOR_VIEW_SLICES(N, n0, n, CALL)                                        \
+  if ((N) > kMaxViewsPerLaunch) {                                                    \
+    for (int64_t n0 = 0; n0 < (N); n0 += kMaxViewsPerLaunch) {                       \
+      const int64_t n = (N) - n0 < kMaxViewsPerLaunch ? (N) - n0 : kMaxViewsPerLaunch; \
+      const int rc_slice_ = (CALL);                                                  \
+      if (rc_slice_ != DRTK_OK) return rc_slice_;                                    \
+    }                                                                                \
+    return DRTK_OK;                                                                  \
+  }
+
 // Per-kernel timing for benchmarks (include/drtk_amd.h: drtk_amd_kernel_timing_begin / _report).  Every launch of
 // the library goes through DRTK_LAUNCH; while a collection is open the launch is bracketed by two HIP events on its
 // own stream (what is computed is unaffected), otherwise the scope object costs one relaxed atomic load.

@@ -860,8 +860,8 @@ extern "C" int drtk_amd_edge_grad_backward(
     const int32_t* vi, const void* grad_output, int64_t N, int64_t V, int64_t C, int64_t F,
     int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix_img, void* workspace,
     size_t workspace_bytes, drtk_stream_t stream) {
-  if (N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || N > 65535 ||
-      (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31))
+  if (N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 ||
+      (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31) || (dtype != DRTK_F32 && dtype != DRTK_F64))
     return DRTK_ERR_INVALID_ARGUMENT;
   if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return DRTK_ERR_INVALID_ARGUMENT; // include/drtk_amd.h, alignment
   size_t need = 0;
@@ -871,6 +871,13 @@ extern "C" int drtk_amd_edge_grad_backward(
     if ((N * V > 0 && !v_pix) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
     if (C > 0 && (!img || !grad_output)) return DRTK_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < need) return DRTK_ERR_WORKSPACE_TOO_SMALL;
+  }
+  {
+    const size_t es = dtype_size(dtype); // (every slice reuses the front of the workspace: stream order)
+    DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_edge_grad_backward(
+        dtype, advance(v_pix, n0 * V * 3, es), advance(img, n0 * C * H * W, es), advance_typed(index_img, n0 * H * W),
+        advance_typed(vi, n0 * vi_sN), advance(grad_output, n0 * C * H * W, es), n, V, C, F, vi_sN, H, W, max_dp_dr,
+        advance(grad_v_pix_img, n0 * 3 * H * W, es), workspace, workspace_bytes, stream))
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
@@ -897,8 +904,8 @@ extern "C" int drtk_amd_edge_grad_backward_fused(
     const int32_t* vi, const void* bary_img, const void* grad_output, int64_t N, int64_t V, int64_t C,
     int64_t F, int64_t vi_sN, int64_t H, int64_t W, double max_dp_dr, void* grad_v_pix,
     void* workspace, size_t workspace_bytes, drtk_stream_t stream) {
-  if (N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || N > 65535 ||
-      (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31))
+  if (N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 ||
+      (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31) || (dtype != DRTK_F32 && dtype != DRTK_F64))
     return DRTK_ERR_INVALID_ARGUMENT;
   if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return DRTK_ERR_INVALID_ARGUMENT; // include/drtk_amd.h, alignment
   size_t need = 0;
@@ -909,6 +916,13 @@ extern "C" int drtk_amd_edge_grad_backward_fused(
     if ((N * V > 0 && !v_pix) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
     if (C > 0 && (!img || !grad_output)) return DRTK_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < need) return DRTK_ERR_WORKSPACE_TOO_SMALL;
+  }
+  {
+    const size_t es = dtype_size(dtype);
+    DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_edge_grad_backward_fused(
+        dtype, advance(v_pix, n0 * V * 3, es), advance(img, n0 * C * H * W, es), advance_typed(index_img, n0 * H * W),
+        advance_typed(vi, n0 * vi_sN), advance(bary_img, n0 * 3 * H * W, es), advance(grad_output, n0 * C * H * W, es), n, V, C, F,
+        vi_sN, H, W, max_dp_dr, advance(grad_v_pix, n0 * V * 3, es), workspace, workspace_bytes, stream))
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {

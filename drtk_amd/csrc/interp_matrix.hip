@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void normal_matrix_values_backward_kernel(
 }
 
 bool bad(int64_t N, int64_t F, int64_t H, int64_t W) {
-  return N < 0 || F < 0 || H < 0 || W < 0 || N > 65535 || H * W >= (int64_t(1) << 31);
+  return N < 0 || F < 0 || H < 0 || W < 0 || H * W >= (int64_t(1) << 31);
 }
 
 } // namespace
@@ -210,7 +210,8 @@ extern "C" int drtk_amd_interpolation_normal_matrix_values(
     drtk_dtype_t dtype, const int32_t* pair_indices, const int32_t* index_img, const void* bary_img,
     int64_t N, int64_t F, int64_t pair_sN, int64_t H, int64_t W, int64_t nnz, void* values,
     drtk_stream_t stream) {
-  if (bad(N, F, H, W) || nnz < 0 || (pair_sN != 0 && pair_sN != F * 9)) return DRTK_ERR_INVALID_ARGUMENT;
+  // (the two normal-matrix kernels take the view from blockIdx.y and accumulate into ONE values array: no slicing here)
+  if (bad(N, F, H, W) || N > kMaxViewsPerLaunch || nnz < 0 || (pair_sN != 0 && pair_sN != F * 9)) return DRTK_ERR_INVALID_ARGUMENT;
   if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t es = dtype == DRTK_F32 ? 4 : 8;
@@ -232,7 +233,7 @@ extern "C" int drtk_amd_interpolation_normal_matrix_values_backward(
     drtk_dtype_t dtype, const void* grad_values, const int32_t* pair_indices, const int32_t* index_img,
     const void* bary_img, int64_t N, int64_t F, int64_t pair_sN, int64_t H, int64_t W, void* bary_grad,
     drtk_stream_t stream) {
-  if (bad(N, F, H, W) || (pair_sN != 0 && pair_sN != F * 9)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (bad(N, F, H, W) || N > kMaxViewsPerLaunch || (pair_sN != 0 && pair_sN != F * 9)) return DRTK_ERR_INVALID_ARGUMENT;
   if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W == 0) return DRTK_OK;
   if (!bary_grad) return DRTK_ERR_INVALID_ARGUMENT;

@@ -540,14 +540,31 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
 #ifndef DRTK_INTERP_WIDE_ONLY
 #define DRTK_INTERP_WIDE_ONLY false
 #endif
-template <typename T, bool HAS_BARY, bool TABLE>
-__global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
+#ifndef DRTK_INTERP_ANYC_QA
+#define DRTK_INTERP_ANYC_QA 1
+#endif
+#ifndef DRTK_INTERP_ANYC_WAVES
+#define DRTK_INTERP_ANYC_WAVES 3
+#endif
+#ifndef DRTK_INTERP_F64_WAVES
+#define DRTK_INTERP_F64_WAVES 3 // waves per SIMD the double instantiations are compiled for (144-152 VGPRs; 32-50 spilled at 4)
+#endif
+//   * ANYC (round 5): channel counts that are not a multiple of four (C >= 5: position + normal = 6, RGB + k features) and
+//     attribute tensors that are only element-aligned.  The last chunk is then 1 ... 15 channels: its grad_out planes are
+//     still fetched in groups of four, the planes beyond C through a descriptor of ZERO records (they read 0.0 without
+//     touching memory); the attribute rows' last, partial group of four is read as the four channels that END the row
+//     (window shifted back by 4 - r: never a byte beyond the row, element alignment only) and its dot products skip the
+//     channels the previous group already took; phase 2 is channel-count agnostic (J = 3 cc lanes).  Rows of such a C
+//     are never whole 64-byte segments, so the run sums go through the workgroup's vertex table.
+//   * double (round 5): the same pipeline in chunks of CH = 8 channels (the registers of 16 floats), 8-byte buffer loads.
+template <typename T, bool HAS_BARY, bool TABLE, int CH, bool ANYC>
+__global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : ANYC && HAS_BARY ? DRTK_INTERP_ANYC_WAVES : 4)) void interpolate_backward_wide_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
     int dbg, int strip, int log2_slots) {
   using V4 = typename Vec4<T>::type;
-  constexpr int CH = 16;
+  static_assert(CH % 4 == 0 && CH >= 8 && CH <= 16, "chunks of 8 or 16 channels");
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPasses = kTileRows / kWaves;
   static_assert(kPasses == 4, "row pipeline below is written for 4 rows per wave");
@@ -633,9 +650,13 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
   // register bound, recycled registers that were still load destinations as address temporaries -- an s_waitcnt
   // vmcnt(0) in the middle of the batch.
   const uint32_t plane_bytes = static_cast<uint32_t>(HW * int64_t(sizeof(T)));
-  auto plane_load = [&](const T* plane, uint32_t byte_offset) -> T {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(plane), 0, static_cast<int>(plane_bytes), 0x00020000);
-    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, byte_offset, 0, 0));
+  auto plane_load = [&](const T* plane, uint32_t byte_offset, bool exists) -> T { // `exists`: wave-uniform (ANYC: a plane < C)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(plane), 0, exists ? static_cast<int>(plane_bytes) : 0, 0x00020000);
+    if constexpr (sizeof(T) == 4) {
+      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, byte_offset, 0, 0));
+    } else {
+      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, byte_offset, 0, 0));
+    }
   };
   auto row_offset = [&](int ps) -> uint32_t { // beyond the plane for a lane off the canvas
     return (x < W && y0 + ps < H) ? static_cast<uint32_t>((y0 + ps) * W + x) * static_cast<uint32_t>(sizeof(T)) : plane_bytes;
@@ -653,7 +674,7 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
       if (4 * q < cc) {
 #pragma unroll
         for (int c = 4 * q; c < 4 * q + 4; ++c) {
-          G[c] = plane_load(plane, bo);
+          G[c] = plane_load(plane, bo, !ANYC || c < cc);
           plane += HW;
         }
       }
@@ -662,7 +683,7 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
       const T* bplane = bary_n;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        B[k] = plane_load(bplane, bo);
+        B[k] = plane_load(bplane, bo, true);
         bplane += HW;
       }
     }
@@ -713,7 +734,7 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
         s_slot[wave][2 * kRunPad + lane] = s2;
       }
     }
-    const int cc = min(CH, C - c0); // 4, 8, 12 or 16
+    const int cc = min(CH, C - c0); // 4, 8, 12 or 16 (ANYC: anything from 1)
     const bool last_chunk = c0 + CH >= C;
     // 2. stage this chunk's grad_out
 #pragma unroll
@@ -730,16 +751,29 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
 #ifndef DRTK_INTERP_QA
 #define DRTK_INTERP_QA 1
 #endif
-    constexpr int QA = DRTK_INTERP_QA, QD = CH / 4 - QA; // float4 per corner requested before / after phase 2
-    V4 A0[QA], A1[QA], A2[QA];
+    // float4 per corner requested before / after phase 2 (ANYC + bary gradient: compiled for 3 waves per SIMD -- the window arithmetic
+    // of the partial group spills 4-10 registers at 4, and 2-4 with every request moved behind phase 2)
+    constexpr int QA = ANYC ? DRTK_INTERP_ANYC_QA : DRTK_INTERP_QA, QD = CH / 4 - QA;
+    // group q of a row's chunk: channels 4q .. 4q+3, or (ANYC, the chunk's partial last group) the four that end the row
+    typedef T TQuadU __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+    auto attr4 = [&](const T* row, int q) -> V4 {
+      if constexpr (ANYC) {
+        const int ws = 4 * q + 4 <= cc ? 4 * q : cc - 4; // wave-uniform; c0 + cc - 4 >= 1 (C >= 5)
+        const TQuadU u = *reinterpret_cast<const TQuadU*>(row + ws);
+        return V4{u.x, u.y, u.z, u.w};
+      } else {
+        return *reinterpret_cast<const V4*>(row + 4 * q);
+      }
+    };
+    V4 A0[QA > 0 ? QA : 1], A1[QA > 0 ? QA : 1], A2[QA > 0 ? QA : 1];
     if constexpr (HAS_BARY) {
       if (covered) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
           if (4 * q < cc) {
-            A0[q] = *reinterpret_cast<const V4*>(a0 + 4 * q);
-            A1[q] = *reinterpret_cast<const V4*>(a1 + 4 * q);
-            A2[q] = *reinterpret_cast<const V4*>(a2 + 4 * q);
+            A0[q] = attr4(a0, q);
+            A1[q] = attr4(a1, q);
+            A2[q] = attr4(a2, q);
           }
         }
       }
@@ -789,12 +823,29 @@ __global__ __launch_bounds__(kBlock, 4) void interpolate_backward_wide_kernel(
 #pragma unroll
         for (int q = 0; q < QD; ++q) {
           if (4 * (QA + q) < cc) {
-            D0[q] = *reinterpret_cast<const V4*>(d0 + 4 * (QA + q));
-            D1[q] = *reinterpret_cast<const V4*>(d1 + 4 * (QA + q));
-            D2[q] = *reinterpret_cast<const V4*>(d2 + 4 * (QA + q));
+            D0[q] = attr4(d0, QA + q);
+            D1[q] = attr4(d1, QA + q);
+            D2[q] = attr4(d2, QA + q);
           }
         }
         auto dot4 = [&](int q4, const V4& u0, const V4& u1, const V4& u2) {
+          if constexpr (ANYC) {
+            if (4 * q4 + 4 > cc) { // the partial group: the window holds channels cc-4 .. cc-1, the first `skip` are done
+              const int base = cc - 4, skip = 4 * q4 - base;
+              const T* sgp = &s_g[wave][lane] + base * kRunPad;
+              if (skip <= 1) {
+                const T g1 = sgp[1 * kRunPad];
+                bg0 += g1 * u0.y, bg1 += g1 * u1.y, bg2 += g1 * u2.y;
+              }
+              if (skip <= 2) {
+                const T g2 = sgp[2 * kRunPad];
+                bg0 += g2 * u0.z, bg1 += g2 * u1.z, bg2 += g2 * u2.z;
+              }
+              const T g3 = sgp[3 * kRunPad];
+              bg0 += g3 * u0.w, bg1 += g3 * u1.w, bg2 += g3 * u2.w;
+              return;
+            }
+          }
           const T g0 = s_g[wave][(4 * q4 + 0) * kRunPad + lane], g1 = s_g[wave][(4 * q4 + 1) * kRunPad + lane];
           const T g2 = s_g[wave][(4 * q4 + 2) * kRunPad + lane], g3 = s_g[wave][(4 * q4 + 3) * kRunPad + lane];
           bg0 += g0 * u0.x, bg1 += g0 * u1.x, bg2 += g0 * u2.x;
@@ -914,44 +965,46 @@ int interpolate_backward_impl(
       vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad,  \
       debug_flags(), strip)
   const bool small_c = C <= 4;
-  // wide path: the vertex gradient (+ bary gradient) for any C % 4 == 0, C >= 8.  float only: the double instantiation
-  // would need > 256 VGPRs for the same pipeline
-  const bool wide = sizeof(T) == 4 && attr_grad && cvec && C >= 8 && HW < (int64_t(1) << 30) && !DRTK_DBG(debug_flags(), 128);
+  // wide path: the vertex gradient (+ bary gradient) for any C >= 5, float and double (round 5; round 4: C % 4 == 0,
+  // C >= 8, float only -- every other shape took the generic kernel, a chain of dependent waits per row)
+  const bool wide = attr_grad && C >= 5 && HW * int64_t(sizeof(T)) < (int64_t(1) << 32) && !DRTK_DBG(debug_flags(), 128);
   // (the bary gradient alone stays with the generic kernel: no scatter, covered pixels only -- 0.95 of the HBM peak on
   // SURVEY 8d's bytes at the bench coverage; a forward-shaped streaming kernel with four pixels per lane, which cannot
   // skip the background of a partly covered quad, was measured slower: 0.55 vs 0.40 ms at C = 16)
   if (wide) {
-    if constexpr (sizeof(T) == 4) {
-      // the workgroup's vertex table: as many slots as fit DRTK_INTERP_TABLE_BYTES of LDS (the staging rows take 27 KB; 4
-      // workgroups per CU leave 40 KB each), at most 128, at least 16 -- else per-run atomics as before
+    // the workgroup's vertex table: as many slots as fit DRTK_INTERP_TABLE_BYTES of LDS (the staging rows take 27 KB; 4
+    // workgroups per CU leave 40 KB each), at most 128, at least 16 -- else per-run atomics as before
 #ifndef DRTK_INTERP_TABLE_BYTES
 #define DRTK_INTERP_TABLE_BYTES 12800
 #endif
-      // -- and only where the rows of attr_grad are not made of whole 64-byte segments (C = 12, 20, 24, 28, ...): there the
-      // per-run atomics are several times slower (8 x 2048^2, both gradients: C = 12 0.92 -> 0.65 ms, C = 24 1.30 -> 1.04
-      // with the table), while on aligned rows (C = 8, 16, 32, 64) the table's lookups and barriers cost more than the
-      // fire-and-forget atomics they replace (C = 16: 0.63 -> 0.70 ms)
-      int log2_slots = 7;
-      while (log2_slots > 0 && (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) > DRTK_INTERP_TABLE_BYTES) --log2_slots;
-      const size_t row_bytes = sizeof(T) * C;
-      const bool rows_aligned = row_bytes % 64 == 0 || 64 % row_bytes == 0;
+    // -- and only where the rows of attr_grad are not made of whole 64-byte segments (C = 12, 20, 24, 28, ..., every C that
+    // is not a multiple of four): there the per-run atomics are several times slower (8 x 2048^2, both gradients: C = 12
+    // 0.92 -> 0.65 ms, C = 24 1.30 -> 1.04 with the table), while on aligned rows (C = 8, 16, 32, 64) the table's lookups
+    // and barriers cost more than the fire-and-forget atomics they replace (C = 16: 0.63 -> 0.70 ms)
+    int log2_slots = 7;
+    while (log2_slots > 0 && (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) > DRTK_INTERP_TABLE_BYTES) --log2_slots;
+    const size_t row_bytes = sizeof(T) * C;
+    const bool rows_aligned = row_bytes % 64 == 0 || 64 % row_bytes == 0;
 #ifdef DRTK_INTERP_NO_TABLE
-      const bool table = false;
+    const bool table = false;
 #else
-      const bool table = log2_slots >= 4 && !rows_aligned && !DRTK_DBG(debug_flags(), 4096);
+    const bool table = log2_slots >= 4 && !rows_aligned && !DRTK_DBG(debug_flags(), 4096);
 #endif
-      const size_t lds = table ? (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) : 0;
-#define WIDE(HB, TB)                                                                                                      \
-  DRTK_LAUNCH(                                                                                                            \
-      (interpolate_backward_wide_kernel<T, HB, TB>), grid, block, lds, stream, grad_out, attrs, vi, index_img, bary_img, \
-      V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots)
-      if (bary_grad) {
-        if (table) WIDE(true, true); else WIDE(true, false);
-      } else {
-        if (table) WIDE(false, true); else WIDE(false, false);
-      }
-#undef WIDE
+    const size_t lds = table ? (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) : 0;
+    constexpr int CH = sizeof(T) == 4 ? 16 : 8;
+#define WIDE(HB, TB, AC)                                                                                                   \
+  DRTK_LAUNCH(                                                                                                             \
+      (interpolate_backward_wide_kernel<T, HB, TB, CH, AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img,    \
+      bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots)
+#define WIDE_T(HB, AC) \
+  if (table) WIDE(HB, true, AC); else WIDE(HB, false, AC)
+    if (bary_grad) {
+      if (cvec) { WIDE_T(true, false); } else { WIDE_T(true, true); }
+    } else {
+      if (cvec) { WIDE_T(false, false); } else { WIDE_T(false, true); }
     }
+#undef WIDE_T
+#undef WIDE
   } else if (small_c && !DRTK_DBG(debug_flags(), 128)) {
 #define SMALL(HV, HB, CN)                                                                                                   \
   DRTK_LAUNCH(                                                                                                              \
@@ -990,7 +1043,7 @@ int interpolate_backward_impl(
 }
 
 bool bad_common(int64_t N, int64_t V, int64_t C, int64_t F, int64_t vi_sN, int64_t H, int64_t W) {
-  return N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || N > 65535 || C >= (1 << 20) ||
+  return N < 0 || V < 0 || C < 0 || F < 0 || H < 0 || W < 0 || C >= (1 << 20) ||
       (vi_sN != 0 && vi_sN != F * 3) || H * W >= (int64_t(1) << 31);
 }
 
@@ -1006,6 +1059,11 @@ static int interpolate_entry(
   if (bad_common(N, V, C, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W * C > 0 && (!index_img || !bary_img || !out)) return DRTK_ERR_INVALID_ARGUMENT;
   if ((N * V * C > 0 && !attrs) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype_size(dtype);
+  DRTK_FOR_VIEW_SLICES(N, n0, n, interpolate_entry(
+      dtype, advance(attrs, n0 * V * C, es), advance_typed(vi, n0 * vi_sN), advance_typed(index_img, n0 * H * W),
+      advance(bary_img, n0 * 3 * H * W, es), n, V, C, F, vi_sN, H, W, advance(out, n0 * C * H * W, es), zero_background, stream))
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:
@@ -1044,6 +1102,12 @@ extern "C" int drtk_amd_interpolate_backward(
   }
   if (N * H * W * C > 0 && (!grad_out || !index_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
   if ((N * V * C > 0 && !attrs) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype_size(dtype);
+  DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_interpolate_backward(
+      dtype, advance(grad_out, n0 * C * H * W, es), advance(attrs, n0 * V * C, es), advance_typed(vi, n0 * vi_sN),
+      advance_typed(index_img, n0 * H * W), advance(bary_img, n0 * 3 * H * W, es), n, V, C, F, vi_sN, H, W,
+      advance(attr_grad, n0 * V * C, es), advance(bary_grad, n0 * 3 * H * W, es), stream))
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:

@@ -1496,8 +1496,14 @@ extern "C" int drtk_amd_rasterize(
   // 64-bit counters / packed pixels updated with 64-bit atomics live in the workspace (include/drtk_amd.h, alignment)
   if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return DRTK_ERR_INVALID_ARGUMENT;
   if (V >= 0x10000000LL) return DRTK_ERR_TOO_MANY_VERTICES;                           // :459-462
+  if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
+  if (vi_sN != 0 && vi_sN != F * 3) return DRTK_ERR_INVALID_ARGUMENT;
+  // more views than one launch takes: slices, each reusing the workspace (sized for all N: enough for any slice)
+  DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_rasterize(
+      dtype, advance(v, n0 * V * 3, dtype_size(dtype)), advance_typed(vi, n0 * vi_sN), n, V, F, vi_sN, H, W, wireframe,
+      advance_typed(depth_img, n0 * H * W), advance_typed(index_img, n0 * H * W), workspace, workspace_bytes, stream))
   if (wireframe) {
-    if (N > 65535 || N * H * W >= (int64_t(1) << 40) || (dtype != DRTK_F32 && dtype != DRTK_F64)) return DRTK_ERR_INVALID_ARGUMENT;
+    if (N * H * W >= (int64_t(1) << 40)) return DRTK_ERR_INVALID_ARGUMENT;
     if (N * H * W > 0 && (!depth_img || !index_img)) return DRTK_ERR_INVALID_ARGUMENT;
     // Triangles need vertices: with F > 0 an empty `v` (V == 0, no storage) is rejected here on purpose -- every
   // non-degenerate index would be read off a null base (like the reference, the kernels do not bounds-check vi).
@@ -1505,7 +1511,7 @@ extern "C" int drtk_amd_rasterize(
     if (vi_sN != 0 && vi_sN != F * 3) return DRTK_ERR_INVALID_ARGUMENT;
     return rasterize_lines_dispatch(dtype, v, vi, N, V, F, vi_sN, H, W, depth_img, index_img, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   }
-  if (N > 65535 || H > 65535LL * 32 || W > 65535LL * 32 || N * F >= (int64_t(1) << 31) / kMaxSmallTiles ||
+  if (H > 65535LL * 32 || W > 65535LL * 32 || N * F >= (int64_t(1) << 31) / kMaxSmallTiles ||
       N * H * W >= (int64_t(1) << 40))
     return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W > 0 && (!depth_img || !index_img || !workspace)) return DRTK_ERR_INVALID_ARGUMENT;

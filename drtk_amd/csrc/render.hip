@@ -388,7 +388,7 @@ int render_backward_impl(
 }
 
 bool bad_common(int64_t N, int64_t V, int64_t F, int64_t vi_sN, int64_t H, int64_t W) {
-  return N < 0 || V < 0 || F < 0 || H < 0 || W < 0 || N > 65535 || (vi_sN != 0 && vi_sN != F * 3) ||
+  return N < 0 || V < 0 || F < 0 || H < 0 || W < 0 || (vi_sN != 0 && vi_sN != F * 3) ||
       H * W >= (int64_t(1) << 31);
 }
 
@@ -404,6 +404,11 @@ extern "C" int drtk_amd_render(
   if (bad_common(N, V, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W > 0 && (!index_img || !depth_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
   if ((N * V > 0 && !v) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype_size(dtype);
+  DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_render(
+      dtype, advance(v, n0 * V * 3, es), advance_typed(vi, n0 * vi_sN), advance_typed(index_img, n0 * H * W), n, V, F, vi_sN, H, W,
+      advance(depth_img, n0 * H * W, es), advance(bary_img, n0 * 3 * H * W, es), stream))
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:
@@ -423,6 +428,12 @@ extern "C" int drtk_amd_render_backward(
   if (N * V > 0 && !grad_v) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W > 0 && (!index_img || !grad_depth_img || !grad_bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
   if ((N * V > 0 && !v) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype_size(dtype);
+  DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_render_backward(
+      dtype, advance(v, n0 * V * 3, es), advance_typed(vi, n0 * vi_sN), advance_typed(index_img, n0 * H * W),
+      advance(grad_depth_img, n0 * H * W, es), advance(grad_bary_img, n0 * 3 * H * W, es), n, V, F, vi_sN, H, W,
+      advance(grad_v, n0 * V * 3, es), stream))
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:

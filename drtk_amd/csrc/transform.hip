@@ -138,8 +138,13 @@ extern "C" int drtk_amd_transform_pinhole(
     drtk_dtype_t dtype, const void* v, int64_t v_sN, const void* campos, const void* camrot,
     const void* focal, const void* princpt, int64_t N, int64_t V, void* v_pix, void* v_cam,
     drtk_stream_t stream) {
-  if (N < 0 || V < 0 || N > 65535 || V >= (int64_t(1) << 31) || (v_sN != 0 && v_sN != V * 3)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N < 0 || V < 0 || V >= (int64_t(1) << 31) || (v_sN != 0 && v_sN != V * 3)) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * V > 0 && (!v || !campos || !camrot || !focal || !princpt || !v_pix)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype_size(dtype);
+  DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_transform_pinhole(
+      dtype, advance(v, n0 * v_sN, es), v_sN, advance(campos, n0 * 3, es), advance(camrot, n0 * 9, es), advance(focal, n0 * 4, es),
+      advance(princpt, n0 * 2, es), n, V, advance(v_pix, n0 * V * 3, es), advance(v_cam, n0 * V * 3, es), stream))
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:
@@ -155,8 +160,15 @@ extern "C" int drtk_amd_transform_pinhole_backward(
     drtk_dtype_t dtype, const void* v, int64_t v_sN, const void* campos, const void* camrot,
     const void* focal, const void* princpt, const void* grad_v_pix, int64_t N, int64_t V,
     void* grad_v, drtk_stream_t stream) {
-  if (N < 0 || V < 0 || N > 65535 || V >= (int64_t(1) << 31) || (v_sN != 0 && v_sN != V * 3)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (N < 0 || V < 0 || V >= (int64_t(1) << 31) || (v_sN != 0 && v_sN != V * 3)) return DRTK_ERR_INVALID_ARGUMENT;
   if (N * V > 0 && (!v || !campos || !camrot || !focal || !princpt || !grad_v_pix || !grad_v)) return DRTK_ERR_INVALID_ARGUMENT;
+  if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
+  if (v_sN != 0) { // per-view vertices: views are independent (shared vertices: ONE launch sums the views in-kernel, any N)
+    const size_t es = dtype_size(dtype);
+    DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_transform_pinhole_backward(
+        dtype, advance(v, n0 * v_sN, es), v_sN, advance(campos, n0 * 3, es), advance(camrot, n0 * 9, es), advance(focal, n0 * 4, es),
+        advance(princpt, n0 * 2, es), advance(grad_v_pix, n0 * V * 3, es), n, V, advance(grad_v, n0 * V * 3, es), stream))
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:

@@ -131,12 +131,19 @@ extern "C" int drtk_amd_screen_space_uv_derivative(
     const int32_t* vti, const int32_t* index_img, const void* bary_img, const uint8_t* mask, const void* campos,
     const void* camrot, const void* focal, int64_t N, int64_t V, int64_t T_, int64_t F, int64_t H, int64_t W,
     void* out, drtk_stream_t stream) {
-  if (N < 0 || V < 0 || T_ < 0 || F < 0 || H < 0 || W < 0 || N > 65535 || H * W >= (int64_t(1) << 31) ||
+  if (N < 0 || V < 0 || T_ < 0 || F < 0 || H < 0 || W < 0 || H * W >= (int64_t(1) << 31) ||
       (v_sN != 0 && v_sN != V * 3) || (vt_sN != 0 && vt_sN != T_ * 2) || (dtype != DRTK_F32 && dtype != DRTK_F64))
     return DRTK_ERR_INVALID_ARGUMENT;
   if (N * H * W == 0) return DRTK_OK;
   if (!index_img || !bary_img || !out || !campos || !camrot || !focal || (F > 0 && (!vi || !vti || !v || !vt)))
     return DRTK_ERR_INVALID_ARGUMENT;
+  {
+    const size_t es = dtype_size(dtype);
+    DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_screen_space_uv_derivative(
+        dtype, advance(v, n0 * v_sN, es), v_sN, advance(vt, n0 * vt_sN, es), vt_sN, vi, vti, advance_typed(index_img, n0 * H * W),
+        advance(bary_img, n0 * 3 * H * W, es), advance_typed(mask, n0 * H * W), advance(campos, n0 * 3, es), advance(camrot, n0 * 9, es),
+        advance(focal, n0 * 4, es), n, V, T_, F, H, W, advance(out, n0 * 4 * H * W, es), stream))
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N));
   if (dtype == DRTK_F32) {

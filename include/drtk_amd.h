@@ -24,6 +24,10 @@
  *     DRTK_ERR_INVALID_ARGUMENT otherwise.
  *   - `dtype` selects float or double for every floating tensor of the call (the reference
  *     dispatches float/double only: src/include/kernel_utils.h:35-57); indices are int32.
+ *   - N (views) is unbounded on the path's operators: a launch takes 65 535 views (the view is blockIdx.y), a larger
+ *     batch is executed as consecutive slices by the entry point itself -- views are independent, results identical
+ *     (the reference's grid-stride kernels take any N: render_kernel.cu:349-377).  H * W < 2^31 per view (in-plane
+ *     offsets are 32-bit); the two normal-matrix operators, which accumulate all views into one array, keep N <= 65 535.
  *   - `stream` is a hipStream_t (NULL = the null stream).  No call synchronises the device or
  *     allocates memory; all work is enqueued on `stream`.
  *   - return value: DRTK_OK or a negative drtk_status_t; drtk_amd_status_string() explains it.

@@ -35,6 +35,7 @@ ap.add_argument("--lib", default="")
 ap.add_argument("--out", default="")
 ap.add_argument("--split-dir", default="", help="also write interp_bwd_by_C.json / raster_regimes.json / f64_and_odd_width.json there")
 ap.add_argument("--grads", default="both,attr_only,bary_only")
+ap.add_argument("--dtypes", default="f32", help="interp_c: f32, f64 or f32,f64")
 ap.add_argument("--flags", type=int, default=0, help="ablation mask (needs profiles/libdrtk_amd_ablate.so: python drtk_amd/build.py --ablation)")
 a = ap.parse_args()
 if a.lib:
@@ -103,25 +104,31 @@ if "interp_c" in a.what:
     _, bary = capi.render(v, vi, index)
     cov = (index != -1).float().mean().item()
     rows = []
-    for C in [int(c) for c in a.channels.split(",")]:
-        attr = S.random_attributes(a.views, v.shape[1], C, shared=False, device=dev)
+    for dname in a.dtypes.split(","):
+      dt = th.float64 if dname == "f64" else th.float32
+      es = 8 if dname == "f64" else 4
+      v_d, bary_d = (v.double(), None) if dname == "f64" else (v, bary)
+      if dname == "f64":
+          _, bary_d = capi.render(v_d, vi, index)
+      for C in [int(c) for c in a.channels.split(",")]:
+        attr = S.random_attributes(a.views, v.shape[1], C, shared=False, device=dev).to(dt)
         g = th.Generator(device=dev).manual_seed(C)
-        go = th.rand(a.views, C, H, W, device=dev, generator=g) * 2 - 1
+        go = (th.rand(a.views, C, H, W, device=dev, generator=g) * 2 - 1).to(dt)
         px = a.views * H * W
         for name, hv, hb in (("both", True, True), ("attr_only", True, False), ("bary_only", False, True)):
             if name not in a.grads.split(","):
                 continue
             set_flags(a.flags)
-            ms = timed(lambda: capi.interpolate_backward(go, attr, vi, index, bary, hv, hb), a.reps)
+            ms = timed(lambda: capi.interpolate_backward(go, attr, vi, index, bary_d, hv, hb), a.reps)
             set_flags(0)
-            bpp = 4 * C + 16 + (12 if hb else 0)
+            bpp = es * C + 3 * es + 4 + (3 * es if hb else 0)
             gbps = bpp * px / ms / 1e6
-            rows.append({"C": C, "grads": name, "ms": round(ms, 4), "bytes_per_px": bpp, "GBps": round(gbps, 1),
+            rows.append({"dtype": dname, "C": C, "grads": name, "ms": round(ms, 4), "bytes_per_px": bpp, "GBps": round(gbps, 1),
                          "frac": round(gbps / PEAK, 3), "us_per_channel": round(1e3 * ms / C, 2)})
             print(rows[-1], file=sys.stderr)
         del attr, go
     result["interp_bwd_by_C"] = {"views": a.views, "res": a.res, "mesh": a.mesh, "coverage": round(cov, 3), "peak_GBps": PEAK,
-                                 "bytes": "SURVEY 8d: 4C + 16 read (+12 bary_grad written), every pixel counted", "rows": rows}
+                                 "bytes": "SURVEY 8d: grad_out C + bary 3 elements + index 4 B read (+ bary_grad 3 elements written) per pixel, every pixel counted: f32 4C + 16 (+12), f64 8C + 28 (+24)", "rows": rows}
 
 if "raster" in a.what:
     def quads(views, res, n_side, dtype=th.float32):

@@ -1296,11 +1296,13 @@ def test_tensors_beyond_two_to_the_31_elements(which):
         rel(gv[n:n + 1], gv1, "vertex gradient of the last view")
 
 
-@pytest.mark.parametrize("shape", [(3000, 24, 20, 3), (65535, 4, 4, 1), (700, 65, 33, 16)])
+@pytest.mark.parametrize("shape", [(3000, 24, 20, 3), (65535, 4, 4, 1), (70000, 4, 4, 1), (131075, 4, 4, 2), (700, 65, 33, 16)])
 def test_many_small_views(shape):
-    """Thousands of tiny views, up to the batch limit of 65535: the view is blockIdx.y in every kernel, the
-    blockIdx.x -> tile mapping runs with one or two blocks per image, the rasterizer picks 64-pixel tiles for
-    images smaller than a tile.  Against the oracle: forward bit-identical, gradients at the usual bar."""
+    """Thousands of tiny views, up to and BEYOND one launch's 65535 (the view is blockIdx.y in every kernel; the reference's
+    grid-stride kernels take any N, render_kernel.cu:349-377: the entry points slice such a batch into launches of at
+    most 65535 views -- 70000 = one full slice + a rest, 131075 = two + 5), the blockIdx.x -> tile mapping runs with one
+    or two blocks per image, the rasterizer picks 64-pixel tiles for images smaller than a tile.  Against the oracle:
+    forward bit-identical, gradients at the usual bar."""
     import oracle as O
     from drtk_amd import capi
     from drtk_amd import synthetic as S
