@@ -546,6 +546,15 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
 #ifndef DRTK_INTERP_ANYC_WAVES
 #define DRTK_INTERP_ANYC_WAVES 3
 #endif
+#ifndef DRTK_INTERP_CH8
+#define DRTK_INTERP_CH8 1
+#endif
+#ifndef DRTK_INTERP_CH8_ANYC
+#define DRTK_INTERP_CH8_ANYC 0 // 9 <= C <= 15, C % 4 != 0: chunks of 8 + a tail (4 waves per SIMD) instead of one chunk (3)
+#endif
+#ifndef DRTK_INTERP_CH8_WAVES
+#define DRTK_INTERP_CH8_WAVES 4 // (with the bary gradient 104 VGPRs; 4-12 spilled at 5)
+#endif
 #ifndef DRTK_INTERP_F64_WAVES
 #define DRTK_INTERP_F64_WAVES 3 // waves per SIMD the double instantiations are compiled for (144-152 VGPRs; 32-50 spilled at 4)
 #endif
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
 //     are never whole 64-byte segments, so the run sums go through the workgroup's vertex table.
 //   * double (round 5): the same pipeline in chunks of CH = 8 channels (the registers of 16 floats), 8-byte buffer loads.
 template <typename T, bool HAS_BARY, bool TABLE, int CH, bool ANYC>
-__global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : ANYC && HAS_BARY ? DRTK_INTERP_ANYC_WAVES : 4)) void interpolate_backward_wide_kernel(
+__global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : CH == 8 ? DRTK_INTERP_CH8_WAVES : ANYC && HAS_BARY ? DRTK_INTERP_ANYC_WAVES : 4)) void interpolate_backward_wide_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
@@ -991,11 +1000,21 @@ int interpolate_backward_impl(
     const bool table = log2_slots >= 4 && !rows_aligned && !DRTK_DBG(debug_flags(), 4096);
 #endif
     const size_t lds = table ? (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) : 0;
+    // chunks of 16 channels (float), 8 where that is all there is (C <= 8: the registers of the other eight planes and of
+    // their attribute rows buy occupancy) and for double
     constexpr int CH = sizeof(T) == 4 ? 16 : 8;
+    const bool ch8 = sizeof(T) == 4 && DRTK_INTERP_CH8 && (C <= 8 || (DRTK_INTERP_CH8_ANYC && !cvec && C < 16));
 #define WIDE(HB, TB, AC)                                                                                                   \
-  DRTK_LAUNCH(                                                                                                             \
-      (interpolate_backward_wide_kernel<T, HB, TB, CH, AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img,    \
-      bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots)
+  do {                                                                                                                     \
+    if (ch8)                                                                                                               \
+      DRTK_LAUNCH(                                                                                                         \
+          (interpolate_backward_wide_kernel<T, HB, TB, 8, AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img, \
+          bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots);   \
+    else                                                                                                                   \
+      DRTK_LAUNCH(                                                                                                         \
+          (interpolate_backward_wide_kernel<T, HB, TB, CH, AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img, \
+          bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots);   \
+  } while (0)
 #define WIDE_T(HB, AC) \
   if (table) WIDE(HB, true, AC); else WIDE(HB, false, AC)
     if (bary_grad) {

@@ -9,6 +9,7 @@ clip_grad=False (and high_quality=False on the model side).  Each fixture holds 
 model's output and its autograd gradients wrt every mip level and the grid.
 
     python oracle/gen_golden_mipmap.py      # rewrites tests/golden/mipmap_*.npz
+    python oracle/gen_golden_mipmap.py --adaptive  # rewrites tests/golden/mipmap_adaptive_*.npz (force_max_aniso=False)
     python oracle/gen_golden_mipmap.py --uv # rewrites tests/golden/uv_derivative_*.npz (own process: it binds
                                             # interpolate_ext::interpolate to the reference's CPU kernel)
 """
@@ -89,7 +90,93 @@ def main():
         print(f"  {path}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
-if __name__ == "__main__" and "--uv" not in sys.argv:
+# ---- the ADAPTIVE tap count (force_max_aniso=False), pinned with data the reference's own model produced ------------
+# mipmap_grid_sample_ref always takes `max_aniso` taps per pixel, but it selects the mip level from
+# N = min(ceil(p_max / p_min), max_aniso) (drtk/mipmap_grid_sample.py:252-258) -- exactly the N the CUDA kernel also uses as
+# its tap COUNT when force_max_aniso is false (mipmap_grid_sampler_kernel.cu:459-462, :496-499).  So on a pixel whose
+# N is k, the kernel's adaptive result with max_aniso = M equals the model called with max_aniso = k: same N, same
+# lambda, the same k taps at (j + 1) / (k + 1) * 2 - 1.  The fixture is assembled pixel class by pixel class from M runs
+# of the model (k = 1 .. M), its gradients by linearity from the upstream gradient masked to each class.
+# PREDICATE (stated here, enforced below): no pixel's ratio p_max / p_min lies within ADAPTIVE_MARGIN of an integer below
+# M, so that ceil() is the same whatever the rounding of the footprint lengths (the kernel adds 1e-12 under the root and
+# evaluates in its own order); ratios at or beyond M need no margin (N = M on either side).  Pixels are re-drawn until the
+# predicate holds.  clip_grad stays False (the model has no such mode).
+ADAPTIVE_MARGIN = 0.05
+ADAPTIVE_CASES = {
+    # name: (N, C, tex size, levels, H, W, max_aniso, mode, padding, dtype, jacobian scale)
+    "adaptive_bilinear_border_a4": (2, 3, 64, 4, 24, 20, 4, "bilinear", "border", th.float32, 0.05),
+    "adaptive_bilinear_zeros_a8": (1, 2, 64, 5, 20, 24, 8, "bilinear", "zeros", th.float32, 0.04),
+    "adaptive_bicubic_border_a3": (1, 2, 32, 3, 12, 16, 3, "bicubic", "border", th.float32, 0.05),
+    "adaptive_bilinear_reflection_a6_f64": (1, 3, 32, 3, 16, 12, 6, "bilinear", "reflection", th.float64, 0.08),
+    "adaptive_bicubic_zeros_a5_f64": (1, 2, 32, 4, 10, 14, 5, "bicubic", "zeros", th.float64, 0.06),
+}
+
+
+def tap_class(jac, size, max_aniso):
+    """N = min(ceil(p_max / p_min), max_aniso) per pixel and the distance of the ratio from the nearest integer where
+    that matters (ratios below max_aniso), in double from the fixture's (dtype-rounded) Jacobian."""
+    j = jac.double() * th.tensor([size, size], dtype=th.float64)
+    px, py = j[..., 0, :].norm(dim=-1), j[..., 1, :].norm(dim=-1)
+    r = th.maximum(px, py) / th.minimum(px, py)
+    n = th.clamp(th.ceil(r), max=max_aniso)
+    margin = th.where(r < max_aniso, (r - th.round(r)).abs(), th.full_like(r, 1.0))
+    return n.long(), margin
+
+
+def main_adaptive():
+    if not os.path.isdir(REF):
+        raise SystemExit("needs /root/reference (build container only)")
+    model = import_reference_model()
+    th.set_num_threads(1)
+    for name, (N, C, size, levels, H, W, M, mode, padding, dtype, jscale) in ADAPTIVE_CASES.items():
+        gen = th.Generator().manual_seed(sum(map(ord, name)))
+        tex = [t.requires_grad_(True) for t in pyramid(gen, N, C, size, levels, dtype)]
+        grid = ((th.rand(N, H, W, 2, generator=gen, dtype=th.float64) * 2.4 - 1.2)).to(dtype).requires_grad_(True)
+
+        def draw():
+            j = th.randn(N, H, W, 2, 2, generator=gen, dtype=th.float64) * jscale
+            j[..., 0, :] *= th.rand(N, H, W, 1, generator=gen, dtype=th.float64) * (M + 1) + 0.05
+            swap = th.rand(N, H, W, generator=gen) < 0.5  # either axis may be the major one
+            j = th.where(swap[..., None, None], j.flip(-2), j)
+            return j.to(dtype)
+
+        jac = draw()
+        for _ in range(200):
+            _, margin = tap_class(jac, size, M)
+            bad = margin < ADAPTIVE_MARGIN
+            if not bad.any():
+                break
+            jac = th.where(bad[..., None, None], draw(), jac)
+        cls, margin = tap_class(jac, size, M)
+        assert float(margin.min()) >= ADAPTIVE_MARGIN, name
+        gout = (th.rand(N, C, H, W, generator=gen, dtype=th.float64) * 2 - 1).to(dtype)
+        out = th.zeros(N, C, H, W, dtype=dtype)
+        grads = [th.zeros_like(t) for t in tex] + [th.zeros_like(grid)]
+        for k in range(1, M + 1):
+            m = (cls == k)
+            if not m.any():
+                continue
+            o_k = model(tex, grid, jac, k, mode=mode, padding_mode=padding, align_corners=False)
+            out = th.where(m[:, None], o_k.detach(), out)
+            g_k = th.autograd.grad(o_k, tex + [grid], gout * m[:, None].to(dtype))
+            grads = [a + b for a, b in zip(grads, g_k)]
+        hist = th.bincount(cls.reshape(-1), minlength=M + 1)[1:].tolist()
+        arrs = {"in_grid": grid.detach().numpy(), "in_vt_dxdy_img": jac.numpy(), "in_grad_out": gout.numpy(),
+                "in_max_aniso": np.asarray(M), "in_mode": np.asarray(0 if mode == "bilinear" else 2),
+                "in_padding": np.asarray({"zeros": 0, "border": 1, "reflection": 2}[padding]),
+                "in_levels": np.asarray(levels), "out_out": out.numpy(), "out_grad_grid": grads[-1].numpy(),
+                "info_tap_class": cls.numpy().astype(np.int8), "info_min_margin": np.asarray(float(margin.min()))}
+        for i, t in enumerate(tex):
+            arrs[f"in_tex{i}"] = t.detach().numpy()
+            arrs[f"out_grad_tex{i}"] = grads[i].numpy()
+        path = os.path.join(OUT, f"mipmap_{name}.npz")
+        np.savez_compressed(path, **arrs)
+        print(f"  {path}: {os.path.getsize(path) / 1024:.1f} KiB, pixels per tap count 1..{M}: {hist}, min margin {float(margin.min()):.3f}")
+
+
+if __name__ == "__main__" and "--adaptive" in sys.argv:
+    main_adaptive()
+elif __name__ == "__main__" and "--uv" not in sys.argv:
     main()
 
 

@@ -67,6 +67,11 @@ MIPMAP_CASES = [
     "bilinear_border_a4", "bilinear_zeros_a1", "bilinear_reflection_a2", "bicubic_border_a3", "bicubic_zeros_a2_f64",
     "bilinear_border_a8_f64", "single_level_a2",
 ]
+# force_max_aniso=False: the reference model's outputs assembled per tap-count class (oracle/gen_golden_mipmap.py --adaptive)
+MIPMAP_ADAPTIVE_CASES = [
+    "adaptive_bilinear_border_a4", "adaptive_bilinear_zeros_a8", "adaptive_bicubic_border_a3",
+    "adaptive_bilinear_reflection_a6_f64", "adaptive_bicubic_zeros_a5_f64",
+]
 
 
 def load_mipmap(name):

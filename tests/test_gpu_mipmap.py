@@ -5,7 +5,7 @@
 Tolerance: |d| <= 1e-5 + 1e-5 * max|ref| per tensor (f32); f64 1e-10."""
 import pytest
 import torch as th
-from conftest import MIPMAP_CASES, load_mipmap, mipmap_inputs
+from conftest import MIPMAP_ADAPTIVE_CASES, MIPMAP_CASES, load_mipmap, mipmap_inputs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -38,6 +38,35 @@ def test_capi_matches_reference_model_fixture(name):
     close(gg, c["grad_grid"], "grad grid")
     for i, (g, ref) in enumerate(zip(glv, c["grad_tex"])):
         close(g, ref, f"grad level {i}")
+
+
+@pytest.mark.parametrize("name", MIPMAP_ADAPTIVE_CASES)
+def test_adaptive_tap_count_matches_reference_model_fixture(name):
+    """force_max_aniso=False (the default of drtk.mipmap_grid_sample): kernel through the C ABI and through the Python
+    API with autograd, against the reference model's outputs assembled per tap-count class
+    (tests/test_mipmap_oracle.py::test_oracle_adaptive_tap_count_matches_reference_model_fixture explains the fixture)."""
+    import drtk_amd
+    from drtk_amd import capi
+
+    c = load_mipmap(name)
+    tex, grid, vt = dev(c["tex"]), dev(c["grid"]), dev(c["vt"])
+    out = capi.mipmap_grid_sampler_2d(tex, grid, vt, c["max_aniso"], c["padding"], c["mode"], False, False, False)
+    close(out, c["out"], "forward")
+    glv, gg = capi.mipmap_grid_sampler_2d_backward(
+        dev(c["grad_out"]), tex, grid, vt, c["max_aniso"], c["padding"], c["mode"], False, False, False)
+    close(gg, c["grad_grid"], "grad grid")
+    for i, (g, ref) in enumerate(zip(glv, c["grad_tex"])):
+        close(g, ref, f"grad level {i}")
+    texr = [t.to(DEV).requires_grad_(True) for t in c["tex"]]
+    gridr = c["grid"].to(DEV).requires_grad_(True)
+    mode = "bilinear" if c["mode"] == 0 else "bicubic"
+    padding = ["zeros", "border", "reflection"][c["padding"]]
+    o2 = drtk_amd.mipmap_grid_sample(texr, gridr, vt, c["max_aniso"], mode=mode, padding_mode=padding)
+    close(o2, c["out"], "forward (python api, default force_max_aniso)")
+    o2.backward(dev(c["grad_out"]))
+    close(gridr.grad, c["grad_grid"], "grad grid (autograd)")
+    for i, (t, ref) in enumerate(zip(texr, c["grad_tex"])):
+        close(t.grad, ref, f"grad level {i} (autograd)")
 
 
 @pytest.mark.parametrize("name", MIPMAP_CASES)

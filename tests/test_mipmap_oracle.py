@@ -5,7 +5,7 @@ CUDA kernel), forward and gradients; plus self-consistency of the modes no execu
 covers here (adaptive tap count, clip_grad)."""
 import pytest
 import torch as th
-from conftest import MIPMAP_CASES, load_mipmap, mipmap_inputs
+from conftest import MIPMAP_ADAPTIVE_CASES, MIPMAP_CASES, load_mipmap, mipmap_inputs
 
 import oracle as O
 
@@ -26,6 +26,28 @@ def test_oracle_matches_reference_model_fixture(name):
     assert (gg - c["grad_grid"]).abs().max() <= _tol(c["grad_grid"], dt)
     for g, ref in zip(glv, c["grad_tex"]):
         assert (g - ref).abs().max() <= _tol(ref, dt)
+
+
+@pytest.mark.parametrize("name", MIPMAP_ADAPTIVE_CASES)
+def test_oracle_adaptive_tap_count_matches_reference_model_fixture(name):
+    """force_max_aniso=False -- the tap COUNT follows N = min(ceil(p_max / p_min), max_aniso) per pixel
+    (mipmap_grid_sampler_kernel.cu:459-462, :496-499) -- against outputs of the reference's own model: on a pixel whose N
+    is k the kernel's result equals drtk.mipmap_grid_sample_ref called with max_aniso = k (same N, same lambda, the same k
+    taps), so the fixture is that model's output assembled class by class, its gradients by linearity
+    (oracle/gen_golden_mipmap.py --adaptive; no ratio within 0.05 of an integer below max_aniso, so ceil() does not
+    depend on rounding).  Before round 5 this branch was held by hand-derived answers only."""
+    c = load_mipmap(name)
+    dt = c["grid"].dtype
+    out = O.mipmap_grid_sampler_2d(c["tex"], c["grid"], c["vt"], c["max_aniso"], c["padding"], c["mode"], False, False, False)
+    assert (out - c["out"]).abs().max() <= _tol(c["out"], dt)
+    glv, gg = O.mipmap_grid_sampler_2d_backward(
+        c["grad_out"], c["tex"], c["grid"], c["vt"], c["max_aniso"], c["padding"], c["mode"], False, False, False)
+    assert (gg - c["grad_grid"]).abs().max() <= _tol(c["grad_grid"], dt)
+    for g, ref in zip(glv, c["grad_tex"]):
+        assert (g - ref).abs().max() <= _tol(ref, dt)
+    # ... and the fixture is not the fixed-count result in disguise: with force_max_aniso=True the output differs
+    fixed = O.mipmap_grid_sampler_2d(c["tex"], c["grid"], c["vt"], c["max_aniso"], c["padding"], c["mode"], False, True, False)
+    assert (fixed - c["out"]).abs().max() > 100 * _tol(c["out"], dt)
 
 
 def test_forward_ignores_align_corners_backward_does_not():
