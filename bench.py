@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="skip the captured-graph timing of the same step")
     ap.add_argument("--reduce-after-backward", action="store_true",
                     help="N > 1: ONE all-reduce of all shared gradients after the backward pass instead of one per shared tensor launched from inside it (A/B of the overlap)")
+    ap.add_argument("--grad-reset", default="auto", choices=["auto", "set_to_none", "flat_zero"],
+                    help="how a step clears the shared gradients: set_to_none (a one-GPU loop's optimizer.zero_grad(); the default without a "
+                         "process group) or flat_zero (zero the reducer's flat buffer and accumulate into it; what every rank of a group does). "
+                         "Recorded in config.grad_reset; at N = 1 the line also carries the other mode's time (extensions.grad_reset_flat_zero)")
     ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)  # internal: this process only captures + replays the step
     a = ap.parse_args()
     if a.workload == "textured" and a.config == 3:
@@ -142,9 +146,29 @@ def measured_traffic_table():
     if not files:
         return {}, None
     out = {}
-    for name, rec in json.load(open(files[-1]))["kernels"].items():
+    doc = json.load(open(files[-1]))
+    for name, rec in doc["kernels"].items():
         out[name.split("(")[0].split("<")[0].split()[-1]] = int(rec["hbm_bytes"])
+    measured_traffic_table.sources = doc.get("sources")  # {csrc file: sha256} at collection time (profiles/make_traffic.py)
     return out, os.path.relpath(files[-1], ROOT)
+
+
+def traffic_staleness(kernel):
+    """Has the source of `kernel` changed since the committed PMC collection was taken?  (stale, [files that differ]):
+    the collection records the SHA-256 of every file under drtk_amd/csrc; compared are the file that defines the kernel
+    and the shared headers.  A collection without that record (rounds 1-4) counts as stale: provenance unknown."""
+    import hashlib
+
+    sources = getattr(measured_traffic_table, "sources", None)
+    if not sources:
+        return True, ["(the collection records no source hashes)"]
+    csrc = os.path.join(ROOT, "drtk_amd", "csrc")
+    mine = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hpp")]
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip") and (" " + kernel + "(") in open(os.path.join(csrc, f)).read():
+            mine.append(f)
+    changed = [f for f in mine if sources.get(f) != hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()]
+    return bool(changed), changed
 
 
 def measured_traffic(kernel):
@@ -397,10 +421,14 @@ def main():
         r.run_single_rank = single_rank_group
     leaves = [p for r in reducers for p in r.params]
 
-    def step(fused_mask=False, reduce=True):
+    grad_reset = args.grad_reset if args.grad_reset != "auto" else ("flat_zero" if grouped else "set_to_none")
+
+    def step(fused_mask=False, reduce=True, flat_zero=None):
         for r in reducers:
             r.enabled = reduce  # off: this rank steps alone (no collective may be entered, not even from a gradient hook)
-        if reduce and grouped:
+        if flat_zero is None:
+            flat_zero = (reduce and grouped) or (grad_reset == "flat_zero" and reduce)
+        if flat_zero:
             for r in reducers:
                 r.zero_grad()  # gradients accumulate straight into the reducer's flat buffer
         else:
@@ -456,6 +484,18 @@ def main():
         if all(t is not None for t in per):
             comm = (sum(t[0] for t in per), sum(t[1] for t in per))
     loss_value = float(loss.detach())
+
+    # N = 1 without a group clears gradients the one-GPU way (set to None); the ranks of a group zero the reducer's flat
+    # buffer and accumulate into it.  So that a scaling curve can be read like for like, the one-GPU line also carries the
+    # SAME step timed the group's way (no collective: there is no group)
+    flat_zero_alt = None
+    if not grouped and grad_reset == "set_to_none":
+        step(flat_zero=True)
+        el_fz, _ = timed_loop(lambda: step(flat_zero=True), args.steps, dev, world)
+        flat_zero_alt = {"note": "the same step with the shared gradients zeroed in the reducer's flat buffer and accumulated into it -- what "
+                                 "every rank of an N > 1 run does (config.grad_reset there) -- for a like-for-like N = 1 point of the scaling curve",
+                         "value": round(n_total * H * W * args.steps / el_fz / 1e6, 2), "ms_per_step": round(el_fz / args.steps * 1e3, 4)}
+        step()  # leave the leaves in the headline's mode
 
     # the same step with the drtk_amd.interpolate_masked extension (reported beside, never as `value`)
     ext = None
@@ -593,10 +633,14 @@ def main():
         alg = d["bytes_per_px"] * P
         ach = alg / (d["ms_per_launch"] * 1e-3) / 1e9
         traffic = traffic_table.get(dom)
+        stale, stale_files = traffic_staleness(dom) if traffic else (None, [])
         roofline = {
             "bound": "hbm", "kernel": dom, "op": d["op"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
             "frac_traffic": round(traffic / (d["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            # the kernel's source (or a shared header) differs from what the PMC collection was taken on: `traffic` describes
+            # an older kernel -- re-collect (profiles/scripts/collect_r05.sh) before reading it
+            "traffic_stale": stale, "traffic_sources_changed": stale_files,
             "achieved_moved": d["GBps_moved"], "frac_moved": round(d["GBps_moved"] / HBM_PEAK_GBS, 4),
             "algorithmic_bytes": alg, "bytes_per_px": d["bytes_per_px"], "bytes_per_px_moved": d["bytes_per_px_moved"],
             "ms_per_launch": d["ms_per_launch"], "launches_per_step": d["launches_per_step"],
@@ -678,7 +722,7 @@ def main():
             "config": {
                 "workload": what, "baseline_config": f"BASELINE.json configs[{args.config - 1}]",
                 "views_per_gpu": n_local, "triangles": int(vi.shape[0]), "vertices": int(v_world.shape[0]),
-                "height": H, "width": W, "channels": C,
+                "height": H, "width": W, "channels": C, "grad_reset": grad_reset,
                 "parallelism": (f"views sharded {world}-way, no data-path collective; {nbytes} B of shared gradients all-reduced over RCCL "
                                 "per step, each shared tensor on a side stream as soon as its gradient is final") if world > 1 else "single GPU",
             },
@@ -690,7 +734,7 @@ def main():
                 "note": "one extra step after the timed region, rank 0: side-stream time from each collective's launch to its "
                         "completion (sum), and how long the main stream then waited for them"},
             "graph_step": graph,
-            "extensions": ext,
+            "extensions": dict(ext or {}, **({"grad_reset_flat_zero": flat_zero_alt} if flat_zero_alt else {})) or None,
             "roofline": roofline,
             "path_roofline": path,
             "cpu_baseline": cpu,

@@ -512,6 +512,174 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
   }
 }
 
+// Wave-wide min / max of an int, every lane active: four DPP steps leave each 16-lane row's result in all of its lanes,
+// four v_readlane + scalar min / max join the rows (a __shfl_xor ladder is six dependent ds_bpermute round trips).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, dpp_i32<0xB1>(v));  // quad_perm [1,0,3,2]
+  v = min(v, dpp_i32<0x4E>(v));  // quad_perm [2,3,0,1]
+  v = min(v, dpp_i32<0x141>(v)); // row_half_mirror
+  v = min(v, dpp_i32<0x140>(v)); // row_mirror
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = max(v, dpp_i32<0xB1>(v));
+  v = max(v, dpp_i32<0x4E>(v));
+  v = max(v, dpp_i32<0x141>(v));
+  v = max(v, dpp_i32<0x140>(v));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// ---- Forward, bilinear, float, zeros / border padding: the LEAN kernel (round 5) -------------------------------------
+// What the counters of rounds 3-4 meant, read with the right cost model (profiles/r05/micro_valu_issue.txt: a wave64 VALU
+// instruction occupies its SIMD for ~2.3 cycles, f64 / conversions / 64-bit adds / DPP 4.2, transcendentals 8, and scalar
+// instructions take issue slots too): SQ_ACTIVE_INST_ANY of mipmap_forward_kernel is 420 M quad-cycles per launch = 1.64 M
+// cycles per SIMD = 0.73 of its 0.76 ms -- the kernel is INSTRUCTION-bound, not latency-bound (which is why keeping K items in
+// flight, mipmap_forward_batched_kernel below, bought nothing: 0.79 vs 0.77 ms).  Per (tap, level) it issues ~170 vector and
+// ~60 scalar instructions: per-corner validity logic in 87 exec-mask regions, 64-bit address arithmetic per texel load, three
+// dependent operations per product, the backward pass's gradient multipliers.  Here the common case -- every corner of the
+// tap inside its level -- is ONE straight line for the whole wave:
+//   * cell decisions are the reference's operations in the reference's order (tap position through the double product,
+//     unnormalise, clip, floor: a tap must land in the same texel cell as in the oracle, the grid gradient's terms are
+//     discontinuous there); what is CONTINUOUS is computed the cheap way: corner weights times the level's weight once per
+//     tap, then one fma per texel and channel (12 instead of 36 operations for RGB; differs from the reference's
+//     (texel * weight) * alpha by an ulp of each term);
+//   * lanes whose tap is not interior (or that have no tap i) get offset 0 and weight 0 and run the same loads and fmas -- no
+//     exec-mask regions in the loop; the border taps themselves (rare) are added by a branch the wave only takes if it has one;
+//   * 32-bit texel offsets from per-pixel level bases.
+// Reflection padding, double and bicubic stay with the kernels above.
+template <int PAD, int CB>
+__global__ __launch_bounds__(kBlock) void mipmap_forward_lean_kernel(
+    LevelTable lv, int mipmaps, const float* __restrict__ grid, GridLayout gl, const float* __restrict__ vt, int C,
+    int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, float* __restrict__ out, int strip) {
+  using T = float;
+  static_assert(PAD == 0 || PAD == 1, "zeros or border padding");
+  static_assert(CB >= 1 && CB <= 4, "channels per sweep over the taps (C is a multiple of CB)");
+  constexpr int padding = PAD;
+  constexpr bool align_corners = false; // mipmap_grid_sampler_kernel.cu:423
+  __shared__ const void* s_ptr[kMaxLevels];
+  __shared__ void* s_grad[kMaxLevels];
+  __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  __shared__ long long s_sn[kMaxLevels];
+  __shared__ double s_f[kTapTab * kTapTab];
+  stage_tap_table(s_f);
+  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w, s_sn);
+  // (view = blockIdx.y: `index / HW` on a flat grid is a 64-bit division per pixel, ~80 instructions)
+  const int64_t n = blockIdx.y;
+  const int64_t pix_raw = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
+  const bool valid = pix_raw < HW;
+  const int64_t pix = valid ? pix_raw : 0;
+  const int64_t index = n * HW + pix;
+  Taps<T> t = {};
+  if (valid) t = setup_taps<T>(load_pixel_uv<T>(grid, gl, vt, n, pix, index), s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+  const int n_lv = mipmaps > 1 ? 2 : 1;
+  // the levels' weights a / n and (1 - a) / n: continuous quantities, computed in float from one reciprocal (the reference
+  // divides the second one in double, :486: a 16-instruction sequence at a quarter of the float rate, for the last ulp)
+  const T rn = T(1) / static_cast<T>(max(t.n, 1));
+  const T alpha_1 = valid ? t.a * rn : T(0);
+  const T alpha_2 = valid ? (T(1) - t.a) * rn : T(0);
+  // level slot s = 0: level d1 with weight alpha_2; s = 1: level d1 + 1 with alpha_1.  A slot whose weight is exactly
+  // zero -- the coarser level of every magnified pixel -- is dead (as in the kernels above).
+  const bool live[2] = {bool(valid & (alpha_2 != T(0))), bool(valid & (n_lv == 2) & (alpha_1 != T(0)))};
+  int lw[2], lh[2];
+  T lwf[2], lhf[2];
+  GlobalPtr<const T> lbase[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int d = live[s] ? t.d1 + s : 0;
+    lw[s] = s_w[d], lh[s] = s_h[d];
+    lwf[s] = static_cast<T>(lw[s]), lhf[s] = static_cast<T>(lh[s]);
+    lbase[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * s_sn[d]);
+  }
+  const double du_d = t.du, dv_d = t.dv;
+  const int n_max = wave_max_i32(valid ? t.n : 0);
+  const bool table = max_aniso <= kTapTab; // kernel-uniform: the taps' positions come from the LDS table
+  const int tab_row = (max(t.n, 1) - 1) * kTapTab;
+  T* out_px = out + n * C * HW + pix;
+
+  for (int c0 = 0; c0 < C; c0 += CB) {
+    T acc[CB];
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) acc[cc] = T(0);
+    for (int i = 0; i < n_max; ++i) {
+      const bool has_tap = i < t.n;
+      // tap i of t.n: f = (i + 1.0) / (n + 1.0) * 2.0 - 1.0 (:497-499); a lane that has no tap i reads its last one
+      // (its weights are zeroed below)
+      const int ic = min(i, max(t.n, 1) - 1);
+      const double f = table ? s_f[tab_row + ic] : (ic + 1.0) / (t.n + 1.0) * 2.0 - 1.0;
+      const T x = t.u + static_cast<T>(du_d * f), y = t.v + static_cast<T>(dv_d * f);
+      const bool ordered = (x == x) & (y == y); // a NaN coordinate samples nothing (safe_downgrade_to_int_range: -100)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bool on = has_tap & live[s];
+        if (__ballot(on) == 0) continue; // wave-uniform
+        // the reference's coordinate pipeline for an INTERIOR tap: unnormalize, clip (border padding), floor.  Values are
+        // made finite first (a clamp that cannot move a tap whose cell lies inside the level), so that the weights of the
+        // lanes that do not count -- no tap, a tap on or beyond the border, a NaN -- are finite and their products with
+        // alpha = 0 vanish; those lanes' real contribution, if any, comes from the branch below.
+        T ix = ((x + 1.f) * lwf[s] - 1) / 2, iy = ((y + 1.f) * lhf[s] - 1) / 2;
+        if (padding == 1) {
+          ix = fminf(fmaxf(ix, T(0)), lwf[s] - T(1)), iy = fminf(fmaxf(iy, T(0)), lhf[s] - T(1)); // == clip_coord but NaN -> 0
+        } else {
+          ix = fminf(fmaxf(ix, T(-4)), T(2e9f)), iy = fminf(fmaxf(iy, T(-4)), T(2e9f));
+        }
+        const T fx_floor = floor(ix), fy_floor = floor(iy);
+        const int ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
+        const bool interior = on & ordered & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(lw[s] - 1)) &
+            (static_cast<unsigned>(iy_nw) < static_cast<unsigned>(lh[s] - 1));
+        // corner weights (bilinear_quad: (ix_se - ix) with ix_se = ix_nw + 1, an exact float) times the level's weight
+        const T wx1 = (fx_floor + T(1)) - ix, wx0 = ix - fx_floor;
+        const T al = interior ? (s == 0 ? alpha_2 : alpha_1) : T(0);
+        const T wy1 = ((fy_floor + T(1)) - iy) * al, wy0 = (iy - fy_floor) * al;
+        const T w_nw = wx1 * wy1, w_ne = wx0 * wy1, w_sw = wx1 * wy0, w_se = wx0 * wy0;
+        const int o_nw = iy_nw * lw[s] + ix_nw;
+        const int o_top = interior ? o_nw : 0;
+        const int o_bot = interior ? o_nw + lw[s] : 0;
+        const int plane = lw[s] * lh[s]; // < 2^31 (fill_table)
+        const GlobalPtr<const T> b = lbase[s] + int64_t(c0) * plane;
+        Pair<T> top[CB], bot[CB];
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) {
+          top[cc] = *(GlobalPtr<const Pair<T>>)(b + (cc * plane + o_top));
+          bot[cc] = *(GlobalPtr<const Pair<T>>)(b + (cc * plane + o_bot));
+        }
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) {
+          acc[cc] = __builtin_fmaf(top[cc].x, w_nw, acc[cc]);
+          acc[cc] = __builtin_fmaf(top[cc].y, w_ne, acc[cc]);
+          acc[cc] = __builtin_fmaf(bot[cc].x, w_sw, acc[cc]);
+          acc[cc] = __builtin_fmaf(bot[cc].y, w_se, acc[cc]);
+        }
+        if (__ballot(on & !interior) != 0) {
+          // a tap on the border of its level (or a non-finite coordinate) somewhere in the wave: those lanes alone, corner by
+          // corner (the reference's form)
+          if (on & !interior) {
+            const Quad<T> q = bilinear_quad<T>(x, y, lh[s], lw[s], padding, align_corners);
+            const T aq = s == 0 ? alpha_2 : alpha_1;
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) {
+              const GlobalPtr<const T> pch = b + cc * plane;
+              if (q.o_nw >= 0) acc[cc] += pch[q.o_nw] * q.nw * aq;
+              if (q.o_ne >= 0) acc[cc] += pch[q.o_ne] * q.ne * aq;
+              if (q.o_sw >= 0) acc[cc] += pch[q.o_sw] * q.sw * aq;
+              if (q.o_se >= 0) acc[cc] += pch[q.o_se] * q.se * aq;
+            }
+          }
+        }
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) out_px[int64_t(c0 + cc) * HW] = acc[cc];
+    }
+  }
+}
+
 // ---- Forward, bilinear: K (tap, level) items of a pixel in flight (round 5) ------------------------------------------
 // mipmap_forward_kernel above walks a pixel's taps one by one, and every (tap, level) is a dependent round trip --
 // geometry -> 2 C texel loads -> products -> next tap: counters show its waves parked on s_waitcnt 58 % of their life at 4
@@ -524,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
 // by item on the general form, recomputed from k -- so nothing of that form is live across the fast path.  (Round 3 had
 // measured "taps in groups of 2 or 4" at 258 / 434 VGPRs and 2.0 ms: the groups carried whole Quads and both forms.)
 #ifndef DRTK_MIP_FWD_BATCH
-#define DRTK_MIP_FWD_BATCH 2
+#define DRTK_MIP_FWD_BATCH 1
 #endif
 template <typename T, int PAD, int K>
 __global__ __launch_bounds__(kBlock) void mipmap_forward_batched_kernel(
@@ -802,29 +970,6 @@ __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
 // ds_add_f32 and flushed once, row-major, so the global atomics are coalesced and each touched texel costs
 // one request per tile instead of one per tap.  Corners outside the window, or on other levels, go to
 // global memory directly, so any uv field is handled.
-// Wave-wide min / max of an int, every lane active: four DPP steps leave each 16-lane row's result in all of its lanes,
-// four v_readlane + scalar min / max join the rows (a __shfl_xor ladder is six dependent ds_bpermute round trips).
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
-}
-__device__ __forceinline__ int wave_min_i32(int v) {
-  v = min(v, dpp_i32<0xB1>(v));  // quad_perm [1,0,3,2]
-  v = min(v, dpp_i32<0x4E>(v));  // quad_perm [2,3,0,1]
-  v = min(v, dpp_i32<0x141>(v)); // row_half_mirror
-  v = min(v, dpp_i32<0x140>(v)); // row_mirror
-  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-  v = max(v, dpp_i32<0xB1>(v));
-  v = max(v, dpp_i32<0x4E>(v));
-  v = max(v, dpp_i32<0x141>(v));
-  v = max(v, dpp_i32<0x140>(v));
-  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
 // Pixel tile: kTileW x kTileH pixels, one thread each.  16 x 16 is a sweet spot, same-box A/B on the textured benchmark /
 // kernel_bench at 1 and 4 texels per pixel: 16 x 32 (8 waves per workgroup over the same 48 KB of windows, twice the
 // waves per CU) 3.11 / 4.61 / 10.8 ms against 1.94 / 2.99 / 8.13 -- the taller tile's taps spread over more texels than a
@@ -2347,13 +2492,27 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
       (mipmap_forward_batched_kernel<T, PAD, DRTK_MIP_FWD_BATCH>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps,  \
       static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso,    \
       force_max_aniso != 0, clip_grad != 0, static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
-  if (dtype == DRTK_F32) {
+#ifndef DRTK_MIP_FWD_LEAN
+#define DRTK_MIP_FWD_LEAN 1
+#endif
+#define LAUNCH_L(PAD, CB)                                                                                      \
+  DRTK_LAUNCH(                                                                                                 \
+      (mipmap_forward_lean_kernel<PAD, CB>), dim3(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N)), \
+      dim3(kBlock), 0, s, lv, mipmaps, static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)C, \
+      H * W, max_aniso, force_max_aniso != 0, clip_grad != 0, static_cast<float*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
+#define LAUNCH_LC(PAD)                                                                    \
+  if (C % 4 == 0) LAUNCH_L(PAD, 4); else if (C % 3 == 0) LAUNCH_L(PAD, 3); else if (C % 2 == 0) LAUNCH_L(PAD, 2); else LAUNCH_L(PAD, 1)
+  if (dtype == DRTK_F32 && interpolation_mode == 0 && padding_mode != 2 && N <= kMaxViewsPerLaunch && DRTK_MIP_FWD_LEAN) {
+    if (padding_mode == 0) { LAUNCH_LC(0); } else { LAUNCH_LC(1); }
+  } else if (dtype == DRTK_F32) {
     if (interpolation_mode == 0 && DRTK_MIP_FWD_BATCH > 1) {
       if (padding_mode == 0) LAUNCH_B(float, 0); else if (padding_mode == 1) LAUNCH_B(float, 1); else LAUNCH_B(float, 2);
     } else if (interpolation_mode == 0) { LAUNCH(float, 0); } else { LAUNCH(float, 2); }
   } else {
     if (interpolation_mode == 0) { LAUNCH(double, 0); } else { LAUNCH(double, 2); }
   }
+#undef LAUNCH_LC
+#undef LAUNCH_L
 #undef LAUNCH_B
 #undef LAUNCH
 #undef LAUNCH_P

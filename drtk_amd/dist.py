@@ -72,6 +72,11 @@ class _StagedCast(th.autograd.Function):
             r._check_not_in_flight(ctx.index)
             r._begin_round()
             r.segments[ctx.index].add_(g.reshape(-1))
+            if not r._staged_seen:
+                # Fallback for the hook above not firing on an undefined gradient (engine behaviour, not API): at the END of
+                # this backward pass every staged leaf that was seen and is not marked ready yet is marked then -- later than
+                # the hook would have (no overlap with the rest of the pass), still from inside backward(), never wrong
+                th.autograd.Variable._execution_engine.queue_callback(r._staged_leaves_fallback)
             r._staged_seen.add(ctx.index)
             return None, None, None  # the leaf's .grad is written once, by finish(), from the reduced sum
         return g.to(ctx.dtype), None, None
@@ -233,6 +238,13 @@ class SharedGradReducer:
         if i in self._staged_seen and self._active():
             self._absorb_direct_use(i)
         self._on_grad_ready(i)
+
+    def _staged_leaves_fallback(self) -> None:
+        if not self._active() or self._defer:
+            return
+        for i in sorted(self._staged_seen):
+            if i not in self._ready and self.group_of[i] not in self._pending:
+                self._on_leaf_grad(i)
 
     def _absorb_direct_use(self, i: int) -> None:
         p = self.params[i]

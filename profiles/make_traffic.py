@@ -33,7 +33,15 @@ def main(d, out):
             continue
         f, w = fetch[k], write.get(k, 0.0)
         kernels[short(k)] = {"fetch_kb": round(f, 1), "write_kb": round(w, 1), "hbm_bytes": int((2 * f + w) * 1024)}
+    import hashlib
+    import os
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drtk_amd", "csrc")
+    sources = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()
+               for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".hpp"))}
     doc = {
+        # what the counters were taken on: bench.py compares these with the tree it runs from (roofline.traffic_stale)
+        "sources": sources,
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 profiles/kernel_bench.py --reps 2`, "
                 "bench workload (8 views, 100k tris, 2048^2, C=16); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per "
                 "MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read on gfx950)",

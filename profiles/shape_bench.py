@@ -36,6 +36,7 @@ ap.add_argument("--out", default="")
 ap.add_argument("--split-dir", default="", help="also write interp_bwd_by_C.json / raster_regimes.json / f64_and_odd_width.json there")
 ap.add_argument("--grads", default="both,attr_only,bary_only")
 ap.add_argument("--dtypes", default="f32", help="interp_c: f32, f64 or f32,f64")
+ap.add_argument("--misalign", action="store_true", help="interp_c: the attribute tensor one element into a flat buffer (rows only element-aligned)")
 ap.add_argument("--flags", type=int, default=0, help="ablation mask (needs profiles/libdrtk_amd_ablate.so: python drtk_amd/build.py --ablation)")
 a = ap.parse_args()
 if a.lib:
@@ -112,6 +113,10 @@ if "interp_c" in a.what:
           _, bary_d = capi.render(v_d, vi, index)
       for C in [int(c) for c in a.channels.split(",")]:
         attr = S.random_attributes(a.views, v.shape[1], C, shared=False, device=dev).to(dt)
+        if a.misalign:
+            flat = th.empty(attr.numel() + 1, device=dev, dtype=dt)
+            flat[1:].copy_(attr.reshape(-1))
+            attr = flat[1:].view_as(attr)
         g = th.Generator(device=dev).manual_seed(C)
         go = (th.rand(a.views, C, H, W, device=dev, generator=g) * 2 - 1).to(dt)
         px = a.views * H * W

@@ -172,6 +172,24 @@ def _worker(rank, world, port, out_dir):
     assert launched == [0] and w16.grad is None  # launched from the leaf's hook, the direct part moved into the segment
     red.finish()
     out.update({"mixed_grad": w16.grad.clone(), "mixed_f32": red.segments[0].clone()})
+    for h in red._handles:
+        h.remove()
+
+    # (h) upcast() as the leaf's ONLY use: _StagedCast.backward returns no gradient for the leaf, so the leaf's
+    # post-accumulate hook has to fire with an undefined gradient for the group to be launched from inside the backward pass
+    # (that it does is engine behaviour, not documented API).  If it ever stops firing, results stay correct -- finish()
+    # launches what is left -- but the overlap is lost silently: pinned here, beside the reducer's own end-of-backward
+    # fallback (dist.py: _StagedCast queues an engine callback that marks such leaves ready)
+    c16 = th.full((4,), 0.25, dtype=th.float16, requires_grad=True)
+    red = ddist.SharedGradReducer([c16], dtype=th.float32)
+    launched = []
+    launch = red._launch
+    red._launch = lambda g, launch=launch: (launched.append(g), launch(g))[1]
+    ((red.upcast(c16) ** 2).sum() * float(rank + 1)).backward()
+    assert launched == [0], "the cast-only staged leaf's group was not launched from the backward pass"
+    red.finish()
+    assert launched == [0]
+    out.update({"castonly_grad": c16.grad.clone()})
     ddist.barrier_and_sync()
     th.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     th.distributed.destroy_process_group()

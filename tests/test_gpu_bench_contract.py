@@ -51,6 +51,10 @@ def _check_common(d, n_gpus):
     rf = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "frac_traffic"} <= set(rf)
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    # `traffic` is replayed from a committed PMC collection: the line says whether the priced kernel's source still is what the
+    # counters were taken on (None where no collection covers the shape, as on these small test shapes)
+    assert "traffic_stale" in rf and (rf["traffic_stale"] is None) == (rf["traffic"] is None)
+    assert d["config"]["grad_reset"] == ("set_to_none" if n_gpus == 1 and d["all_reduce"] is None else "flat_zero")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
     assert "ms_per_step_median_hipevent" in d and 0 < d["ms_per_step_median_hipevent"] <= d["ms_per_step"] * 1.5
     # ONE HIP kernel is priced: the one with the largest per-launch time among the kernels that stream per-pixel tensors
@@ -92,6 +96,9 @@ def test_single_process_line_carries_roofline_and_cpu_baseline():
     assert "error" not in g, g
     assert g["ms_per_step"] > 0 and abs(g["loss"] - d["loss"]) <= 1e-5 * max(1.0, abs(d["loss"]))
     # the operators alone (no user-side mask / loss), wall clock: beside the headline, and necessarily faster than it
+    # ... and the N = 1 step the way the ranks of a group clear their gradients (the scaling curve's like-for-like point)
+    fz = d["extensions"]["grad_reset_flat_zero"]
+    assert fz["ms_per_step"] > 0 and 0.5 < fz["ms_per_step"] / d["ms_per_step"] < 2.0
     oo = d["extensions"]["operators_only"]
     assert 0 < oo["ms_per_step"] < d["ms_per_step"] and oo["value"] > d["value"]
     assert oo["ms_per_step"] >= d["path_roofline"]["t_ops_ms"] * 0.9  # ... and not faster than its own kernels

@@ -591,3 +591,31 @@ def test_sampler_inputs_that_are_read_in_place_and_those_that_are_copied():
                 th.rand(N, C, w, h).transpose(2, 3)):
         kept, _, _, _, lsn = capi._level_table([bad])
         assert kept[0] is not bad and kept[0].is_contiguous() and list(lsn) == [C * h * w]
+
+
+def test_bench_flags_a_stale_traffic_collection(tmp_path, monkeypatch):
+    """roofline.traffic is replayed from the committed PMC collection (profiles/rNN/traffic.json); the collection records the
+    SHA-256 of every kernel source (profiles/make_traffic.py) and bench.py reports `traffic_stale` when the file that
+    defines the priced kernel, or a shared header, has changed since -- so a driver-run line cannot quote the traffic of a
+    kernel that no longer exists.  Pure host logic: exercised here without a GPU."""
+    import hashlib
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    csrc = os.path.join(ROOT, "drtk_amd", "csrc")
+    now = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))}
+    bench.measured_traffic_table.sources = dict(now)
+    assert bench.traffic_staleness("interpolate_backward_wide_kernel") == (False, [])
+    bench.measured_traffic_table.sources = dict(now, **{"interpolate.hip": "0" * 64})
+    assert bench.traffic_staleness("interpolate_backward_wide_kernel") == (True, ["interpolate.hip"])
+    assert bench.traffic_staleness("render_kernel") == (False, [])  # another file's kernel is unaffected
+    bench.measured_traffic_table.sources = dict(now, **{"common.hpp": "0" * 64})
+    assert bench.traffic_staleness("render_kernel") == (True, ["common.hpp"])  # a shared header touches every kernel
+    bench.measured_traffic_table.sources = None  # collections of rounds 1-4: provenance unknown
+    assert bench.traffic_staleness("render_kernel")[0] is True
+    # the committed collection itself parses, and make_traffic.py writes the record the check needs
+    table, path = bench.measured_traffic_table()
+    assert path is None or len(table) > 0
+    assert '"sources": sources' in open(os.path.join(ROOT, "profiles", "make_traffic.py")).read()
