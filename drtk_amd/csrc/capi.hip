@@ -197,7 +197,7 @@ extern "C" int drtk_amd_kernel_timing_report(char* buf, size_t capacity, size_t*
 
 #ifdef DRTK_AMD_ABLATION
 // profiling build only (profiles/libdrtk_amd_ablate.so); not declared in include/drtk_amd.h, not in libdrtk_amd.so
-extern "C" void drtk_amd_debug_set_flags(int flags) {
+extern "C" __attribute__((visibility("default"))) void drtk_amd_debug_set_flags(int flags) {
   drtk_amd::g_debug_flags = flags;
 }
 #endif

@@ -24,6 +24,24 @@
 #include "common.hpp"
 #include "segscatter.hpp" // wave_lds_sync
 
+#ifdef DRTK_AMD_ABLATION
+// Profiling build only: what the tiled backward's rounds are made of (profiles/mipmap_bench.py --rounds-stats).
+// [0] tiles with upstream gradient, [r] tiles that enter round r (1..7), [8] (tap, level) pairs walked in the first pass,
+// [9] pairs left pending by it, [10] pairs that end in global memory after the last round
+namespace drtk_amd {
+__device__ unsigned long long g_mip_stats[16];
+}
+extern "C" __attribute__((visibility("default"))) int drtk_amd_debug_read_mip_stats(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(drtk_amd::g_mip_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -3;
+  unsigned long long z[16] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(drtk_amd::g_mip_stats), z, sizeof(z)) != hipSuccess) return -3;
+  return 0;
+}
+#define DRTK_MIP_STAT(i, v) do { if (DRTK_DBG(dbg, 64)) atomicAdd(&::drtk_amd::g_mip_stats[i], static_cast<unsigned long long>(v)); } while (0)
+#else
+#define DRTK_MIP_STAT(i, v) do { } while (0)
+#endif
+
 namespace drtk_amd {
 namespace {
 
@@ -1493,6 +1511,9 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : 3))
 #ifndef DRTK_MIP_T2_OCC
 #define DRTK_MIP_T2_OCC 3
 #endif
+#ifndef DRTK_MIP_HOPELESS
+#define DRTK_MIP_HOPELESS 1
+#endif
 template <typename T, int PAD, bool ALIGN>
 // (3 workgroups per CU by registers as by LDS; reflection padding needs ~200: 2)
 __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRTK_MIP_T2_OCC)) void mipmap_backward_tiled2_kernel(
@@ -1506,10 +1527,10 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
   __shared__ long long s_sn[kMaxLevels];
-  __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels];
+  __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels], s_hx[kWinLevels], s_hy[kWinLevels];
   // first-round placement per ABSOLUTE level (so that the reference level and the origins come out of ONE phase):
-  // north-west minimum of the tile's taps on level d, and the largest north-west row
-  __shared__ int s_lox[kMaxLevels + 1], s_loy[kMaxLevels + 1], s_hiy[kMaxLevels + 1];
+  // bounding box of the north-west texels of the tile's taps on level d
+  __shared__ int s_lox[kMaxLevels + 1], s_loy[kMaxLevels + 1], s_hix[kMaxLevels + 1], s_hiy[kMaxLevels + 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char s_win_raw[];
   double* const s_win = reinterpret_cast<double*>(s_win_raw);
   const int tid = threadIdx.x;
@@ -1539,7 +1560,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
     const int i = tid < mipmaps ? tid : 0;
     s_ptr[tid] = lv.ptr[i], s_grad[tid] = lv.grad[i], s_sn[tid] = lv.sn[i], s_h[tid] = lv.h[i], s_w[tid] = lv.w[i];
   }
-  if (tid <= kMaxLevels) s_lox[tid] = s_loy[tid] = INT32_MAX, s_hiy[tid] = INT32_MIN;
+  if (tid <= kMaxLevels) s_lox[tid] = s_loy[tid] = INT32_MAX, s_hix[tid] = s_hiy[tid] = INT32_MIN;
   if (tid == 0) s_ref = kMaxLevels;
   {
     double2* w2 = reinterpret_cast<double2*>(s_win);
@@ -1587,7 +1608,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
   {
     // ONE phase for the reference level and the origins: the extremes go into cells of their ABSOLUTE level, wave by
     // wave over the (one to three) levels a wave's pixels use
-    int lo_x[2] = {INT32_MAX, INT32_MAX}, lo_y[2] = {INT32_MAX, INT32_MAX}, hi_y[2] = {INT32_MIN, INT32_MIN};
+    int lo_x[2] = {INT32_MAX, INT32_MAX}, lo_y[2] = {INT32_MAX, INT32_MAX}, hi_x[2] = {INT32_MIN, INT32_MIN}, hi_y[2] = {INT32_MIN, INT32_MIN};
     if (live[0] || live[1]) {
       for (int e = 0; e < 2; ++e) {
         T x, y;
@@ -1596,7 +1617,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
         for (int s = 0; s < 2; ++s) {
           if (s < n_lv && live[s]) {
             const int ox = texel_floor(x, s_w[t.d1 + s]), oy = texel_floor(y, s_h[t.d1 + s]);
-            lo_x[s] = min(lo_x[s], ox), lo_y[s] = min(lo_y[s], oy), hi_y[s] = max(hi_y[s], oy);
+            lo_x[s] = min(lo_x[s], ox), lo_y[s] = min(lo_y[s], oy), hi_x[s] = max(hi_x[s], ox), hi_y[s] = max(hi_y[s], oy);
           }
         }
       }
@@ -1608,9 +1629,11 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
       const int a = wave_min_i32(min(m0 ? lo_x[0] : INT32_MAX, m1 ? lo_x[1] : INT32_MAX));
       const int b = wave_min_i32(min(m0 ? lo_y[0] : INT32_MAX, m1 ? lo_y[1] : INT32_MAX));
       const int e = wave_max_i32(max(m0 ? hi_y[0] : INT32_MIN, m1 ? hi_y[1] : INT32_MIN));
+      const int g = wave_max_i32(max(m0 ? hi_x[0] : INT32_MIN, m1 ? hi_x[1] : INT32_MIN));
       if ((tid & (kWave - 1)) == 0 && a != INT32_MAX) {
         atomicMin(&s_lox[d], a);
         atomicMin(&s_loy[d], b);
+        atomicMax(&s_hix[d], g);
         atomicMax(&s_hiy[d], e);
       }
     }
@@ -1618,16 +1641,51 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
   }
   __syncthreads();
   const int ref = s_ref;
-  // rows of each window that the first round can touch (flush: only those are read) -- exact for zeros / border padding,
-  // where the extremes above are the true north-west texels; under reflection padding every row
-  int win_rows[kWinLevels], wox[kWinLevels], woy[kWinLevels]; // the same for every thread: scalar registers
+  // ---- the two window SLOTS (round 5: shaped, not square).  Slot l holds level ref + l.  The windows' memory is
+  // kWinLevels x kWinSlotCells accumulators per channel; a tile with no live tap on level ref + 1 -- every tile of a magnified
+  // texture -- gives it all to slot 0; a slot is 2^sx cells wide, sx chosen by the bounding box of the taps it has to
+  // hold (16 ... 128 wide: the elongated footprints of a limb tile fit where a 32 x 32 square needed four rounds).
+  // Wave-uniform values: scalar registers.
+  constexpr int kWinSlotCells = kWin * kWin;
+  static_assert(kWinPad == 0 && kWinB == kWin && kWinCells == kWinLevels * kWinSlotCells, "the shaped slots re-partition the square windows' memory");
+  int wox[kWinLevels], woy[kWinLevels], wsx[kWinLevels], wny[kWinLevels], wcells[kWinLevels], win_rows[kWinLevels];
+  auto shape_slots = [&](const int (&lox)[kWinLevels], const int (&loy)[kWinLevels], const int (&hix)[kWinLevels], const int (&hiy)[kWinLevels], bool all_rows) {
+    const bool two = lox[1] != INT32_MAX;
 #pragma unroll
-  for (int l = 0; l < kWinLevels; ++l) {
-    const int d = min(ref + l, kMaxLevels);
-    wox[l] = __builtin_amdgcn_readfirstlane(s_lox[d]), woy[l] = __builtin_amdgcn_readfirstlane(s_loy[d]);
-    const long long need = static_cast<long long>(__builtin_amdgcn_readfirstlane(s_hiy[d])) - woy[l] + 2;
-    win_rows[l] = (padding == 2 || need > win_side(l)) ? win_side(l) : static_cast<int>(need < 0 ? 0 : need);
+    for (int l = 0; l < kWinLevels; ++l) {
+      wox[l] = lox[l], woy[l] = loy[l];
+      wcells[l] = l == 0 ? (two ? kWinSlotCells : kWinLevels * kWinSlotCells) : (two ? kWinSlotCells : 0);
+      const long long need_w = static_cast<long long>(hix[l]) - lox[l] + 2, need_h = static_cast<long long>(hiy[l]) - loy[l] + 2;
+      int sx = need_w <= 16 ? 4 : need_w <= 32 ? 5 : (need_w <= 64 && need_h <= (wcells[l] >> 6)) ? 6 : (need_w > 64 && need_h <= (wcells[l] >> 7)) ? 7 : 5;
+      if (lox[l] == INT32_MAX) sx = 5;
+      wsx[l] = sx;
+      wny[l] = wcells[l] > 0 ? (wcells[l] >> sx) : 1; // (1: no cell passes the row test of an empty slot)
+      win_rows[l] = (all_rows || need_h > wny[l]) ? wny[l] : static_cast<int>(need_h < 0 ? 0 : need_h);
+      if (wcells[l] == 0) win_rows[l] = 0;
+    }
+  };
+  {
+    int lox[kWinLevels], loy[kWinLevels], hix[kWinLevels], hiy[kWinLevels];
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l) {
+      const int d = min(ref + l, kMaxLevels);
+      lox[l] = __builtin_amdgcn_readfirstlane(s_lox[d]), loy[l] = __builtin_amdgcn_readfirstlane(s_loy[d]);
+      hix[l] = __builtin_amdgcn_readfirstlane(s_hix[d]), hiy[l] = __builtin_amdgcn_readfirstlane(s_hiy[d]);
+    }
+    // rows the first round can touch: exact for zeros / border padding, where the extremes are the true north-west texels;
+    // under reflection padding every row
+    shape_slots(lox, loy, hix, hiy, padding == 2);
   }
+  // cell of a north-west texel in slot l (the other three corners are +1, +stride, +stride+1), or -1
+  auto slot_cell = [&](int l, int ix_nw, int iy_nw) -> int {
+    if (l < 0 || l >= kWinLevels) return -1;
+    const int wx = ix_nw - (l == 0 ? wox[0] : wox[1]), wy = iy_nw - (l == 0 ? woy[0] : woy[1]);
+    const int sx = l == 0 ? wsx[0] : wsx[1], ny = l == 0 ? wny[0] : wny[1];
+    return (static_cast<unsigned>(wx) < (1u << sx) - 1u && static_cast<unsigned>(wy) < static_cast<unsigned>(ny - 1)) ? (wy << sx) + wx : -1;
+  };
+  auto slot_stride = [&](int l) -> int { return 1 << (l == 0 ? wsx[0] : wsx[1]); };
+  auto slot_chan = [&](int l) -> int { return l == 0 ? wcells[0] : wcells[1]; };  // cells per channel
+  auto slot_base = [&](int l) -> int { return l == 0 ? 0 : C * wcells[0]; };        // first cell of the slot's channel 0
 
   // (tap, level) pairs that find no window cell in this round: not sent to global memory one corner and channel at a
   // time -- scattered float atomics of single lanes, 0.72 of this kernel's 2.2 ms on the textured benchmark although
@@ -1655,8 +1713,8 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
     T run_w[4] = {T(0), T(0), T(0), T(0)};
     auto emit_run = [&](int l, const T (&g)[4]) {
       if (run_cell < 0) return;
-      double* wp = s_win + C * win_cells_before(l) + run_cell;
-      const int stride = win_stride(l), chan = win_cells(l);
+      double* wp = s_win + slot_base(l) + run_cell;
+      const int stride = slot_stride(l), chan = slot_chan(l);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (c >= C) break;
@@ -1682,12 +1740,8 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
         const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
         // window cell of the north-west corner (the other three are +1 in x / y), or -1 if not windowed
         const int l = d - ref;
-        int cell = -1;
-        const int side = win_side(l), stride = win_stride(l), chan = win_cells(l);
-        if (l < kWinLevels) {
-          const int wx = q.ix_nw - (l == 0 ? wox[0] : wox[1]), wy = q.iy_nw - (l == 0 ? woy[0] : woy[1]);
-          if (wx >= 0 && wx < side - 1 && wy >= 0 && wy < side - 1) cell = wy * stride + wx;
-        }
+        const int cell = slot_cell(l, q.ix_nw, q.iy_nw);
+        const int stride = slot_stride(l), chan = slot_chan(l);
         T g[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) g[c] = c < C ? go[c] * alpha : T(0);
@@ -1712,7 +1766,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
             // them -- are merged before they touch LDS: their corner weights add up in registers and the cell gets one
             // set of adds when the run ends (a different cell, or the last tap)
             if (s == 1) {
-              double* wp = s_win + C * win_cells_before(l) + cell;
+              double* wp = s_win + slot_base(l) + cell;
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 if (c >= C) break;
@@ -1777,7 +1831,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
           }
           if (!DRTK_DBG(dbg, 1)) {
             if (cell >= 0) {
-              double* wp = s_win + C * win_cells_before(l) + c * chan + cell;
+              double* wp = s_win + slot_base(l) + c * chan + cell;
               if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * gOut));
               if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * gOut));
               if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * gOut));
@@ -1820,7 +1874,10 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
       emit_run(t.d1 - ref, g);
     }
     store_grid_grad<T>(grad_grid, ggl, n, pix, acc_x, acc_y);
+    DRTK_MIP_STAT(8, (live[0] ? t.n : 0) + (live[1] ? t.n : 0));
+    DRTK_MIP_STAT(9, __popc(pending));
   }
+  if (tid == 0) DRTK_MIP_STAT(0, 1);
   __syncthreads();
   // flush the windows: consecutive threads = consecutive texels of a row; cells that stayed 0 cost nothing,
   // cells outside the level were never written (only in-bounds corners are accumulated).  With `rearm` the cells are
@@ -1834,15 +1891,15 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
       const int64_t plane = int64_t(h) * w;
       const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
       for (int c = 0; c < C; ++c) {
-        // two cells per lane and step (one 16-byte LDS read); a row of 32 cells = 16 consecutive lanes
-        const int stride = win_stride(l), chan = win_cells(l);
-        double2* win2 = reinterpret_cast<double2*>(s_win + C * win_cells_before(l) + c * chan);
+        // two cells per lane and step (one 16-byte LDS read); a window row = consecutive lanes
+        const int stride = 1 << wsx[l], chan = wcells[l];
+        double2* win2 = reinterpret_cast<double2*>(s_win + (l == 0 ? 0 : C * wcells[0]) + c * chan);
         for (int i2 = tid; i2 < win_rows[l] * stride / 2; i2 += kMipBlock) { // rows beyond win_rows were never written
           const double2 q = win2[i2];
           if (rearm && (q.x != 0.0 || q.y != 0.0)) win2[i2] = double2{0.0, 0.0};
           const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
           const int i = i2 * 2;
-          const int gx = wox[l] + i % stride, gy = woy[l] + i / stride;
+          const int gx = wox[l] + (i & (stride - 1)), gy = woy[l] + (i >> wsx[l]);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
@@ -1860,18 +1917,28 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
   // ---- further rounds: the windows are moved onto the taps that are still pending and those taps alone are accumulated
   // (texture gradient only: the grid gradient is complete).  What is still pending after the last round -- a region of
   // the texture or a level too many -- goes to global memory corner by corner, as all misses did before.
-  int ref_now = ref;
+  // HOPELESS tiles (round 5): where a round catches less than a quarter of the pixels that still had pending taps, the taps
+  // are scattered beyond what windows can hold -- the poles of an atlas, where neighbouring pixels sample texels
+  // thousands of columns apart: on the textured benchmark 1.7 % of the tiles ran all five further rounds and still sent
+  // nearly all of their taps to global memory afterwards (profiles/mipmap_bench.py --rounds-stats) -- 39 % of all tile-rounds.
+  // The next round of such a tile is its last (what is pending goes to global memory at once).  A seam tile, whose taps
+  // form two far-apart clusters, halves its pending pixels per round and carries on.
+  int ref_now = ref, pending_px_before = kMipBlock + 1;
   for (int round = 1;; ++round) {
-    const bool again = __syncthreads_or(pending != 0) && !DRTK_DBG(dbg, 8);
+    const int pending_px = __syncthreads_count(pending != 0);
+    const bool again = pending_px != 0 && !DRTK_DBG(dbg, 8);
     flush(ref_now, again);
     if (!again) return;
-    const bool last = round >= DRTK_MIP_ROUNDS - 1;
+    if (tid == 0) DRTK_MIP_STAT(round < 7 ? round : 7, 1);
+    const bool hopeless = DRTK_MIP_HOPELESS && round >= 2 && pending_px * 4 > pending_px_before * 3;
+    pending_px_before = pending_px;
+    const bool last = round >= DRTK_MIP_ROUNDS - 1 || hopeless;
     __syncthreads(); // everybody has finished its flush (it reads the origins)
     if (tid == 0) s_ref = kMaxLevels;
-    if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
-    // where this pixel's pending taps are: north-west minimum per level
+    if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX, s_hx[tid] = s_hy[tid] = INT32_MIN;
+    // where this pixel's pending taps are: bounding box of their north-west texels per level
     bool miss[2] = {false, false};
-    int miss_x[2] = {INT32_MAX, INT32_MAX}, miss_y[2] = {INT32_MAX, INT32_MAX};
+    int miss_x[2] = {INT32_MAX, INT32_MAX}, miss_y[2] = {INT32_MAX, INT32_MAX}, miss_hx[2] = {INT32_MIN, INT32_MIN}, miss_hy[2] = {INT32_MIN, INT32_MIN};
     for (uint32_t todo = pending; todo;) {
       const int bit = __builtin_ctz(todo);
       todo &= todo - 1;
@@ -1882,8 +1949,10 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
       const Quad<T> q = bilinear_quad<T>(x, y, s_h[d], s_w[d], padding, align_corners);
       if (s2 == 0) {
         miss[0] = true, miss_x[0] = min(miss_x[0], q.ix_nw), miss_y[0] = min(miss_y[0], q.iy_nw);
+        miss_hx[0] = max(miss_hx[0], q.ix_nw), miss_hy[0] = max(miss_hy[0], q.iy_nw);
       } else {
         miss[1] = true, miss_x[1] = min(miss_x[1], q.ix_nw), miss_y[1] = min(miss_y[1], q.iy_nw);
+        miss_hx[1] = max(miss_hx[1], q.ix_nw), miss_hy[1] = max(miss_hy[1], q.iy_nw);
       }
     }
     __syncthreads();
@@ -1894,31 +1963,44 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
     __syncthreads();
     ref_now = s_ref;
     {
-      int lo_x[kWinLevels], lo_y[kWinLevels];
+      int lo_x[kWinLevels], lo_y[kWinLevels], hi_x[kWinLevels], hi_y[kWinLevels];
 #pragma unroll
-      for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX;
+      for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX, hi_x[l] = hi_y[l] = INT32_MIN;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int l = t.d1 + s2 - ref_now;
 #pragma unroll
         for (int k = 0; k < kWinLevels; ++k) {
-          if (miss[s2] && k == l) lo_x[k] = min(lo_x[k], miss_x[s2]), lo_y[k] = min(lo_y[k], miss_y[s2]);
+          if (miss[s2] && k == l) {
+            lo_x[k] = min(lo_x[k], miss_x[s2]), lo_y[k] = min(lo_y[k], miss_y[s2]);
+            hi_x[k] = max(hi_x[k], miss_hx[s2]), hi_y[k] = max(hi_y[k], miss_hy[s2]);
+          }
         }
       }
 #pragma unroll
       for (int l = 0; l < kWinLevels; ++l) {
         const int a = wave_min_i32(lo_x[l]), b = wave_min_i32(lo_y[l]);
+        const int g = wave_max_i32(hi_x[l]), e = wave_max_i32(hi_y[l]);
         if ((tid & (kWave - 1)) == 0 && a != INT32_MAX) {
           atomicMin(&s_ox[l], a);
           atomicMin(&s_oy[l], b);
+          atomicMax(&s_hx[l], g);
+          atomicMax(&s_hy[l], e);
         }
       }
     }
     __syncthreads();
+    {
+      int lox[kWinLevels], loy[kWinLevels], hix[kWinLevels], hiy[kWinLevels];
 #pragma unroll
-    for (int l = 0; l < kWinLevels; ++l) {
-      wox[l] = __builtin_amdgcn_readfirstlane(s_ox[l]), woy[l] = __builtin_amdgcn_readfirstlane(s_oy[l]);
-      win_rows[l] = win_side(l);
+      for (int l = 0; l < kWinLevels; ++l) {
+        lox[l] = __builtin_amdgcn_readfirstlane(s_ox[l]), loy[l] = __builtin_amdgcn_readfirstlane(s_oy[l]);
+        hix[l] = __builtin_amdgcn_readfirstlane(s_hx[l]), hiy[l] = __builtin_amdgcn_readfirstlane(s_hy[l]);
+      }
+      // (slot 0 always has pending taps: ref_now is the finest level that has any.  The boxes are those of the pending
+      // taps' true north-west texels -- whatever the padding mode -- and only pending taps are accumulated in a round, so
+      // the flush may stop at the box's last row)
+      shape_slots(lox, loy, hix, hiy, false);
     }
     if (pending != 0) {
       uint32_t todo = pending;
@@ -1934,14 +2016,11 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
         const T alpha = s2 == 0 ? alpha_2 : alpha_1;
         const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
         const int l = d - ref_now;
-        int cell = -1;
-        const int side = win_side(l), stride = win_stride(l), chan = win_cells(l);
-        if (l >= 0 && l < kWinLevels) {
-          const int wx = q.ix_nw - (l == 0 ? wox[0] : wox[1]), wy = q.iy_nw - (l == 0 ? woy[0] : woy[1]);
-          if (wx >= 0 && wx < side - 1 && wy >= 0 && wy < side - 1) cell = wy * stride + wx;
-        }
+        const int cell = slot_cell(l, q.ix_nw, q.iy_nw);
+        const int stride = slot_stride(l), chan = slot_chan(l);
         if (cell < 0 && !last) continue; // stays pending: the next round's windows
         pending &= ~(1u << bit);
+        if (cell < 0) DRTK_MIP_STAT(10, 1);
         const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1949,7 +2028,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
           const T gc = go[c] * alpha;
           if (gc == T(0)) continue;
           if (cell >= 0) {
-            double* wp = s_win + C * win_cells_before(l) + c * chan + cell;
+            double* wp = s_win + slot_base(l) + c * chan + cell;
             if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * gc));
             if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * gc));
             if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * gc));
@@ -2602,16 +2681,20 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
 #define DRTK_MIP_TILED2 1
 #endif
 #if DRTK_MIP_TILED2
-#define DRTK_MIP_TILED_KERNEL mipmap_backward_tiled2_kernel
-#else
-#define DRTK_MIP_TILED_KERNEL mipmap_backward_tiled_kernel
-#endif
 #define TILED(PAD, ALIGN)                                                                                                \
   DRTK_LAUNCH(                                                                                                           \
-      (DRTK_MIP_TILED_KERNEL<T, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      (mipmap_backward_tiled2_kernel<T, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
       dim3(kMipBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const T*>(grad_out),              \
       static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
       force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
+#else
+#define TILED(PAD, ALIGN)                                                                                                \
+  DRTK_LAUNCH(                                                                                                           \
+      (mipmap_backward_tiled_kernel<T, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      dim3(kMipBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const T*>(grad_out),              \
+      static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
+      force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
+#endif
     if (align_corners) {
       if (padding_mode == 0) TILED(0, true); else if (padding_mode == 1) TILED(1, true); else TILED(2, true);
     } else {

@@ -36,7 +36,7 @@
 namespace drtk_amd {
 __device__ unsigned long long g_phase_clocks[16];
 }
-extern "C" int drtk_amd_debug_read_phases(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int drtk_amd_debug_read_phases(unsigned long long* out) {
   if (hipDeviceSynchronize() != hipSuccess) return DRTK_ERR_LAUNCH;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(drtk_amd::g_phase_clocks), 16 * sizeof(unsigned long long)) != hipSuccess) return DRTK_ERR_LAUNCH;
   const unsigned long long zero[16] = {};

@@ -24,6 +24,7 @@ ap.add_argument("--f64", action="store_true", help="the sampler's inputs in doub
 ap.add_argument("--flags", default="0")
 ap.add_argument("--lib", default="")
 ap.add_argument("--stats", action="store_true")
+ap.add_argument("--rounds-stats", action="store_true", help="ablation build: how many tiles of the tiled backward enter each further round, how many taps stay pending")
 ap.add_argument("--dump", default="", help="save the backward's outputs (compare two libraries with --compare A B)")
 ap.add_argument("--compare", nargs=2, default=None)
 a = ap.parse_args()
@@ -32,7 +33,7 @@ if a.compare:
     worst = max((x.double() - y.double()).abs().max().item() / y.abs().max().item() for x, y in zip(A, B))
     print(f"compare {a.compare[0]} {a.compare[1]}: worst difference / max magnitude = {worst:.2e}")
     sys.exit(0 if worst < 2e-5 else 1)
-ABLATE = a.flags != "0"
+ABLATE = a.flags != "0" or a.rounds_stats
 if a.lib:
     capi.use_profiling_library(os.path.abspath(a.lib))
 elif ABLATE:
@@ -121,6 +122,21 @@ for flags in [int(x) for x in a.flags.split(",")]:
     b = timeit(lambda: capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, MODE))
     print(f"flags={flags} C={a.channels}{' bicubic' if a.bicubic else ''}{' f64' if a.f64 else ''}: mipmap fwd {f:.3f} ms   bwd (incl. zero-fill of the pyramid) {b:.3f} ms")
 set_flags(0)
+
+if a.rounds_stats:
+    import ctypes
+
+    L = capi.lib()
+    buf = (ctypes.c_ulonglong * 16)()
+    L.drtk_amd_debug_read_mip_stats(buf)  # clear
+    L.drtk_amd_debug_set_flags(64)
+    capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0)
+    th.cuda.synchronize()
+    L.drtk_amd_debug_read_mip_stats(buf)
+    L.drtk_amd_debug_set_flags(0)
+    st = list(buf)
+    print(f"tiles with gradient {st[0]}; entering round 1..7: {st[1:8]}; (tap, level) pairs {st[8]}, pending after the first pass {st[9]} "
+          f"({100.0 * st[9] / max(st[8], 1):.2f} %), to global memory after the last round {st[10]}")
 
 if a.dump:
     gl, gg = capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0)
