@@ -127,6 +127,7 @@ TEXTURED_KERNELS = {  # additional kernels of the textured workload: (stage, byt
     "mipmap_forward_lean_kernel": ("mipmap_grid_sample", 8 + 16 + 12),
     "mipmap_forward_batched_kernel": ("mipmap_grid_sample", 8 + 16 + 12),
     "mipmap_backward_tiled2_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),
+    "mipmap_backward_lean_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),
     "mipmap_backward_tiled_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),  # grad_out, grid, Jacobian read; grad_grid written
     "mipmap_backward_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),
     "mipmap_backward_wave_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),  # (C > 4; the textured workload's RGB takes the tiled one)

@@ -2046,6 +2046,575 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
   }
 }
 
+// ---- Backward, bilinear, float, zeros / border padding, C <= 4: the tile kernel with the LEAN tap loop (round 5) -------
+// mipmap_backward_tiled2_kernel's placement, shaped window slots, rounds and flush, with the tap loop rewritten the way
+// the lean forward was (one straight line per (tap, level) for the whole wave: no Quad, no per-corner logic, regrouped
+// products, texture channels a template parameter) -- for the instructions, and for the REGISTERS: the tile kernels sat at
+// 151-168 VGPRs = 3 waves per SIMD with every tile's chain (loads -> barrier -> placement -> barrier -> taps -> barrier ->
+// flush) exposed; at <= 128 a CU holds four tiles instead of three.
+#ifndef DRTK_MIP_T3_OCC
+#define DRTK_MIP_T3_OCC 4
+#endif
+// window accumulators per channel and slot (two slots; one slot of twice the size where a tile has one live level).  1024 =
+// the square windows' memory (48 KB for RGB: 3 tiles per CU); 768 -> 36 KB: 4 tiles; 640 -> 30 KB: 5 tiles = 5 waves per
+// SIMD, which the lean loop's 94-98 VGPRs allow.
+#ifndef DRTK_MIP_T3_SLOT_CELLS
+#define DRTK_MIP_T3_SLOT_CELLS 768
+#endif
+constexpr int kLeanSlotCells = DRTK_MIP_T3_SLOT_CELLS, kLeanCells = kWinLevels * kLeanSlotCells;
+static_assert(kLeanSlotCells % 128 == 0, "whole rows at every slot width (16 ... 128 cells), cells in pairs");
+template <int PAD, bool ALIGN, int CN>
+__global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_lean_kernel(
+    LevelTable lv, int mipmaps, const float* __restrict__ grad_out, const float* __restrict__ grid, GridLayout gl,
+    const float* __restrict__ vt, int H, int W, int tiles_x, int max_aniso,
+    bool force_max_aniso, bool clip_grad, float* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
+  using T = float;
+  static_assert(PAD == 0 || PAD == 1, "zeros or border padding");
+  static_assert(CN >= 1 && CN <= 4, "texture channels");
+  constexpr int C = CN;
+  constexpr int padding = PAD;
+  constexpr bool align_corners = ALIGN;
+  __shared__ double s_f[kTapTab * kTapTab];
+  __shared__ const void* s_ptr[kMaxLevels];
+  __shared__ void* s_grad[kMaxLevels];
+  __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
+  __shared__ long long s_sn[kMaxLevels];
+  __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels], s_hx[kWinLevels], s_hy[kWinLevels];
+  // first-round placement per ABSOLUTE level (so that the reference level and the origins come out of ONE phase):
+  // bounding box of the north-west texels of the tile's taps on level d
+  __shared__ int s_lox[kMaxLevels + 1], s_loy[kMaxLevels + 1], s_hix[kMaxLevels + 1], s_hiy[kMaxLevels + 1];
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_win_raw[];
+  double* const s_win = reinterpret_cast<double*>(s_win_raw);
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int tile = tile_index(strip);
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileH + tid / kTileW;
+  const bool valid = px < W && py < H;
+  const int64_t HW = int64_t(H) * W;
+  const int64_t index = int64_t(n) * HW + int64_t(py) * W + px;
+  // the pixel's upstream gradient, uv and Jacobian: one batch of loads ...
+  T go[CN];
+#pragma unroll
+  for (int c = 0; c < CN; ++c) go[c] = T(0);
+  if (valid) {
+    const T* gout_px = grad_out + int64_t(n) * C * HW + (int64_t(py) * W + px);
+#pragma unroll
+    for (int c = 0; c < CN; ++c) go[c] = gout_px[int64_t(c) * HW];
+  }
+  PixelUV<T> uv = {};
+  const int64_t pix = int64_t(py) * W + px;
+  if (valid) uv = load_pixel_uv<T>(grid, gl, vt, n, pix, index);
+  // ... and under them everything that needs no data: the tables, the placement cells, the windows' zero-fill (a tile
+  // that turns out to have no upstream gradient has zeroed its windows for nothing; the stores wait for nobody)
+  stage_tap_table(s_f);
+  if (tid < kMaxLevels) {
+    const int i = tid < mipmaps ? tid : 0;
+    s_ptr[tid] = lv.ptr[i], s_grad[tid] = lv.grad[i], s_sn[tid] = lv.sn[i], s_h[tid] = lv.h[i], s_w[tid] = lv.w[i];
+  }
+  if (tid <= kMaxLevels) s_lox[tid] = s_loy[tid] = INT32_MAX, s_hix[tid] = s_hiy[tid] = INT32_MIN;
+  if (tid == 0) s_ref = kMaxLevels;
+  {
+    double2* w2 = reinterpret_cast<double2*>(s_win);
+    const double2 z = {0.0, 0.0};
+    for (int i = tid; i < C * kLeanCells / 2; i += kMipBlock) w2[i] = z;
+  }
+  bool has_go = false;
+#pragma unroll
+  for (int c = 0; c < CN; ++c) has_go = has_go | (go[c] != T(0));
+  if (!__syncthreads_or(has_go)) { // (also publishes the tables and the zero-fill)
+    if (valid) store_grid_grad<T>(grad_grid, ggl, n, pix, T(0), T(0));
+    return;
+  }
+
+  Taps<T> t = {};
+  if (has_go) t = setup_taps<T>(uv, lv.h[0], lv.w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
+  const int n_lv = mipmaps > 1 ? 2 : 1;
+  // the levels' weights a / n and (1 - a) / n: continuous quantities, in float from one reciprocal (as in the lean forward)
+  const T rn = T(1) / static_cast<T>(max(t.n, 1));
+  const T alpha_1 = has_go ? t.a * rn : T(0);
+  const T alpha_2 = has_go ? (T(1) - t.a) * rn : T(0);
+  // A (pixel, level) whose weighted upstream gradient is zero in every channel adds nothing anywhere (every term is
+  // +-0 * finite): the masked background of a silhouette tile, and the second level of a magnified pixel (a == 0).
+  // Such pairs neither place the windows nor run their taps.
+  bool live[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const T alpha = s == 0 ? alpha_2 : alpha_1;
+    live[s] = false;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) live[s] = live[s] || (go[c] * alpha != T(0));
+    live[s] = live[s] && s < n_lv;
+  }
+  auto tap_xy = [&](int i, T& x, T& y) {
+    const double f = tap_f(s_f, i, t.n);
+    x = t.u + static_cast<T>(t.du * f);
+    y = t.v + static_cast<T>(t.dv * f);
+  };
+  // window origins: the taps of a pixel are collinear, so their extreme texels are those of the first and the last
+  // tap.  ANY origin is correct -- a corner is windowed iff its exact cell lies inside, tested below -- so the origin
+  // comes from a short form of the coordinate pipeline: unnormalise, clamp to the level, floor (the exact north-west
+  // texel for zeros / border padding; under reflection padding taps beyond the border miss the window).
+  auto texel_floor = [&](T coord, int size) -> int {
+    T unused;
+    const T c = unnormalize(coord, size, align_corners, &unused);
+    const T lo = padding == 0 ? T(-1) : T(0);
+    return static_cast<int>(floor(fmin(fmax(c, lo), static_cast<T>(size - 1)))); // fmax(NaN, lo) = lo
+  };
+  {
+    // ONE phase for the reference level and the origins: the extremes go into cells of their ABSOLUTE level, wave by
+    // wave over the (one to three) levels a wave's pixels use
+    int lo_x[2] = {INT32_MAX, INT32_MAX}, lo_y[2] = {INT32_MAX, INT32_MAX}, hi_x[2] = {INT32_MIN, INT32_MIN}, hi_y[2] = {INT32_MIN, INT32_MIN};
+    if (live[0] || live[1]) {
+      for (int e = 0; e < 2; ++e) {
+        T x, y;
+        tap_xy(e == 0 ? 0 : t.n - 1, x, y);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s < n_lv && live[s]) {
+            const int ox = texel_floor(x, s_w[t.d1 + s]), oy = texel_floor(y, s_h[t.d1 + s]);
+            lo_x[s] = min(lo_x[s], ox), lo_y[s] = min(lo_y[s], oy), hi_x[s] = max(hi_x[s], ox), hi_y[s] = max(hi_y[s], oy);
+          }
+        }
+      }
+    }
+    const int d_lo = wave_min_i32(live[0] ? t.d1 : live[1] ? t.d1 + 1 : kMaxLevels);
+    const int d_hi = wave_max_i32(live[1] ? t.d1 + 1 : live[0] ? t.d1 : -1);
+    for (int d = d_lo; d <= d_hi; ++d) { // wave-uniform
+      const bool m0 = live[0] && t.d1 == d, m1 = live[1] && t.d1 + 1 == d;
+      const int a = wave_min_i32(min(m0 ? lo_x[0] : INT32_MAX, m1 ? lo_x[1] : INT32_MAX));
+      const int b = wave_min_i32(min(m0 ? lo_y[0] : INT32_MAX, m1 ? lo_y[1] : INT32_MAX));
+      const int e = wave_max_i32(max(m0 ? hi_y[0] : INT32_MIN, m1 ? hi_y[1] : INT32_MIN));
+      const int g = wave_max_i32(max(m0 ? hi_x[0] : INT32_MIN, m1 ? hi_x[1] : INT32_MIN));
+      if ((tid & (kWave - 1)) == 0 && a != INT32_MAX) {
+        atomicMin(&s_lox[d], a);
+        atomicMin(&s_loy[d], b);
+        atomicMax(&s_hix[d], g);
+        atomicMax(&s_hiy[d], e);
+      }
+    }
+    if ((tid & (kWave - 1)) == 0 && d_lo < kMaxLevels) atomicMin(&s_ref, d_lo);
+  }
+  __syncthreads();
+  const int ref = s_ref;
+  // ---- the two window SLOTS (round 5: shaped, not square).  Slot l holds level ref + l.  The windows' memory is
+  // kWinLevels x kWinSlotCells accumulators per channel; a tile with no live tap on level ref + 1 -- every tile of a magnified
+  // texture -- gives it all to slot 0; a slot is 2^sx cells wide, sx chosen by the bounding box of the taps it has to
+  // hold (16 ... 128 wide: the elongated footprints of a limb tile fit where a 32 x 32 square needed four rounds).
+  // Wave-uniform values: scalar registers.
+  constexpr int kWinSlotCells = kLeanSlotCells;
+  int wox[kWinLevels], woy[kWinLevels], wsx[kWinLevels], wny[kWinLevels], wcells[kWinLevels], win_rows[kWinLevels];
+  auto shape_slots = [&](const int (&lox)[kWinLevels], const int (&loy)[kWinLevels], const int (&hix)[kWinLevels], const int (&hiy)[kWinLevels], bool all_rows) {
+    const bool two = lox[1] != INT32_MAX;
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l) {
+      wox[l] = lox[l], woy[l] = loy[l];
+      wcells[l] = l == 0 ? (two ? kWinSlotCells : kWinLevels * kWinSlotCells) : (two ? kWinSlotCells : 0);
+      const long long need_w = static_cast<long long>(hix[l]) - lox[l] + 2, need_h = static_cast<long long>(hiy[l]) - loy[l] + 2;
+      int sx = need_w <= 16 ? 4 : need_w <= 32 ? 5 : (need_w <= 64 && need_h <= (wcells[l] >> 6)) ? 6 : (need_w > 64 && need_h <= (wcells[l] >> 7)) ? 7 : 5;
+      if (lox[l] == INT32_MAX) sx = 5;
+      wsx[l] = sx;
+      wny[l] = wcells[l] > 0 ? (wcells[l] >> sx) : 1; // (1: no cell passes the row test of an empty slot)
+      win_rows[l] = (all_rows || need_h > wny[l]) ? wny[l] : static_cast<int>(need_h < 0 ? 0 : need_h);
+      if (wcells[l] == 0) win_rows[l] = 0;
+    }
+  };
+  {
+    int lox[kWinLevels], loy[kWinLevels], hix[kWinLevels], hiy[kWinLevels];
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l) {
+      const int d = min(ref + l, kMaxLevels);
+      lox[l] = __builtin_amdgcn_readfirstlane(s_lox[d]), loy[l] = __builtin_amdgcn_readfirstlane(s_loy[d]);
+      hix[l] = __builtin_amdgcn_readfirstlane(s_hix[d]), hiy[l] = __builtin_amdgcn_readfirstlane(s_hiy[d]);
+    }
+    // rows the first round can touch: exact for zeros / border padding, where the extremes are the true north-west texels;
+    // under reflection padding every row
+    shape_slots(lox, loy, hix, hiy, padding == 2);
+  }
+  // cell of a north-west texel in slot l (the other three corners are +1, +stride, +stride+1), or -1
+  auto slot_cell = [&](int l, int ix_nw, int iy_nw) -> int {
+    if (l < 0 || l >= kWinLevels) return -1;
+    const int wx = ix_nw - (l == 0 ? wox[0] : wox[1]), wy = iy_nw - (l == 0 ? woy[0] : woy[1]);
+    const int sx = l == 0 ? wsx[0] : wsx[1], ny = l == 0 ? wny[0] : wny[1];
+    return (static_cast<unsigned>(wx) < (1u << sx) - 1u && static_cast<unsigned>(wy) < static_cast<unsigned>(ny - 1)) ? (wy << sx) + wx : -1;
+  };
+  auto slot_stride = [&](int l) -> int { return 1 << (l == 0 ? wsx[0] : wsx[1]); };
+  auto slot_chan = [&](int l) -> int { return l == 0 ? wcells[0] : wcells[1]; };  // cells per channel
+  auto slot_base = [&](int l) -> int { return l == 0 ? 0 : C * wcells[0]; };        // first cell of the slot's channel 0
+
+  // (tap, level) pairs that find no window cell in this round: not sent to global memory one corner and channel at a
+  // time -- scattered float atomics of single lanes, 0.72 of this kernel's 2.2 ms on the textured benchmark although
+  // only a few per cent of the taps miss -- but remembered (per level of the pixel: did any tap miss, and where) for a
+  // further round with the windows moved onto them (below, up to DRTK_MIP_ROUNDS rounds).
+  // (where they missed is NOT carried through the tap loop -- six registers at its bound: a round recomputes the
+  // north-west texels of its pending taps, which it walks anyway)
+  uint32_t pending = 0; // bit 2 i + s: tap i on the pixel's level s found no window cell yet (taps >= 16 are never deferred)
+
+  // ---- the tap loop, lean (see mipmap_forward_lean_kernel): ONE straight line per (tap, level) for the whole wave.  Cell
+  // decisions are the reference's operations in the reference's order; the continuous quantities are regrouped (corner
+  // weights as products of the two axis weights, the grid gradient as differences of texels: 10 operations per channel
+  // instead of 24).  A lane whose tap is not interior runs the same loads and products with offset 0 and weight 0; border
+  // taps and the (rare) taps beyond the deferral range are added by a branch the wave only takes if it has one.
+  T acc_x = T(0), acc_y = T(0);
+  {
+    const int n_max = wave_max_i32((live[0] || live[1]) ? t.n : 0);
+    const bool table = max_aniso <= kTapTab; // kernel-uniform
+    const int tn1 = max(t.n, 1);
+    const double du_d = t.du, dv_d = t.dv;
+    auto grad_base = [&](int d, int64_t plane) -> GlobalPtr<T> { return (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane); };
+    // (one run slot, for the pixel's FINER level: a magnified pixel has no other live level, and the taps of a minified
+    // one are a texel apart on the finer level -- half a texel on the coarser, whose adds go to LDS tap by tap)
+    int run_cell = -1;
+    T run_w[4] = {T(0), T(0), T(0), T(0)};
+    auto emit_run = [&](int l, const T (&g)[CN]) {
+      if (run_cell < 0) return;
+      double* wp = s_win + slot_base(l) + run_cell;
+      const int stride = slot_stride(l), chan = slot_chan(l);
+#pragma unroll
+      for (int c = 0; c < CN; ++c) {
+        lds_add(wp + c * chan, static_cast<double>(run_w[0] * g[c]));
+        lds_add(wp + c * chan + 1, static_cast<double>(run_w[1] * g[c]));
+        lds_add(wp + c * chan + stride, static_cast<double>(run_w[2] * g[c]));
+        lds_add(wp + c * chan + stride + 1, static_cast<double>(run_w[3] * g[c]));
+      }
+      run_cell = -1;
+    };
+    for (int i = 0; i < n_max && !DRTK_DBG(dbg, 32); ++i) {
+      const bool has_tap = i < t.n;
+      const int ic = min(i, tn1 - 1); // a lane that has no tap i recomputes its last one (its weights are zeroed)
+      const double f = table ? s_f[(tn1 - 1) * kTapTab + ic] : (ic + 1.0) / (t.n + 1.0) * 2.0 - 1.0;
+      const T x = t.u + static_cast<T>(du_d * f), y = t.v + static_cast<T>(dv_d * f);
+      const bool ordered = (x == x) & (y == y); // a NaN coordinate samples nothing (safe_downgrade_to_int_range: -100)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bool on = has_tap & live[s];
+        if (__ballot(on) == 0) continue; // wave-uniform
+        const int d = on ? t.d1 + s : 0;
+        const int w = s_w[d], h = s_h[d];
+        const T wm1 = static_cast<T>(w - 1), hm1 = static_cast<T>(h - 1);
+        // unnormalize (GridSampler.cuh): the position and the gradient multiplier of the coordinate transform
+        T ixu, iyu, mx, my;
+        if (align_corners) {
+          ixu = ((x + 1.f) / 2) * wm1, iyu = ((y + 1.f) / 2) * hm1;
+          mx = wm1 / 2, my = hm1 / 2;
+        } else {
+          ixu = ((x + 1.f) * static_cast<T>(w) - 1) / 2, iyu = ((y + 1.f) * static_cast<T>(h) - 1) / 2;
+          mx = static_cast<T>(w) / 2, my = static_cast<T>(h) / 2;
+        }
+        T ix, iy;
+        if (padding == 1) { // clip_coord: clamped coordinates have a zero gradient
+          mx = ((ixu > T(0)) & (ixu < wm1)) ? mx : T(0), my = ((iyu > T(0)) & (iyu < hm1)) ? my : T(0);
+          ix = fminf(fmaxf(ixu, T(0)), wm1), iy = fminf(fmaxf(iyu, T(0)), hm1);
+        } else { // (made finite; a tap whose cell lies inside the level is not moved)
+          ix = fminf(fmaxf(ixu, T(-4)), T(2e9f)), iy = fminf(fmaxf(iyu, T(-4)), T(2e9f));
+        }
+        const T fx_floor = floor(ix), fy_floor = floor(iy);
+        const int ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
+        const bool interior = on & ordered & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(w - 1)) &
+            (static_cast<unsigned>(iy_nw) < static_cast<unsigned>(h - 1));
+        const T wx1 = (fx_floor + T(1)) - ix, wx0 = ix - fx_floor, wy1 = (fy_floor + T(1)) - iy, wy0 = iy - fy_floor;
+        const int l = d - ref;
+        const int cell = interior ? slot_cell(l, ix_nw, iy_nw) : -1;
+        const T al = interior ? (s == 0 ? alpha_2 : alpha_1) : T(0);
+        T g[CN];
+#pragma unroll
+        for (int c = 0; c < CN; ++c) g[c] = go[c] * al;
+        // ---- texture gradient: into the window (merged per cell on the finer level), or pending
+        if (!DRTK_DBG(dbg, 1)) {
+          if (cell >= 0) {
+            const T q_nw = wx1 * wy1, q_ne = wx0 * wy1, q_sw = wx1 * wy0, q_se = wx0 * wy0;
+            if (s == 1) {
+              double* wp = s_win + slot_base(l) + cell;
+              const int stride = slot_stride(l), chan = slot_chan(l);
+#pragma unroll
+              for (int c = 0; c < CN; ++c) {
+                lds_add(wp + c * chan, static_cast<double>(q_nw * g[c]));
+                lds_add(wp + c * chan + 1, static_cast<double>(q_ne * g[c]));
+                lds_add(wp + c * chan + stride, static_cast<double>(q_sw * g[c]));
+                lds_add(wp + c * chan + stride + 1, static_cast<double>(q_se * g[c]));
+              }
+            } else if (cell != run_cell) {
+              emit_run(l, g);
+              run_cell = cell;
+              run_w[0] = q_nw, run_w[1] = q_ne, run_w[2] = q_sw, run_w[3] = q_se;
+            } else {
+              run_w[0] += q_nw, run_w[1] += q_ne, run_w[2] += q_sw, run_w[3] += q_se;
+            }
+          } else if (interior & (i < 16)) {
+            pending |= 1u << (2 * i + s);
+          }
+        }
+        // ---- grid gradient: texels of the (interior) tap; d/dx of the bilinear form = differences of texels
+        const int plane = w * h; // < 2^31 (fill_table)
+        const int o_top = interior ? iy_nw * w + ix_nw : 0;
+        const int o_bot = interior ? o_top + w : 0;
+        const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]);
+        Pair<T> top[CN], bot[CN];
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+          top[c] = bot[c] = Pair<T>{T(0), T(0)};
+          if (!DRTK_DBG(dbg, 2)) {
+            top[c] = *(GlobalPtr<const Pair<T>>)(inp + (c * plane + o_top));
+            bot[c] = *(GlobalPtr<const Pair<T>>)(inp + (c * plane + o_bot));
+          }
+        }
+        T gix = T(0), giy = T(0);
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+          if (DRTK_DBG(dbg, 16)) break;
+          // (with a zero upstream gradient every term is +-0 * finite in the reference: the texels count as 0)
+          const T tx = (top[c].y - top[c].x) * wy1 + (bot[c].y - bot[c].x) * wy0;
+          const T ty = (bot[c].x - top[c].x) * wx1 + (bot[c].y - top[c].y) * wx0;
+          gix += g[c] != T(0) ? g[c] * tx : T(0);
+          giy += g[c] != T(0) ? g[c] * ty : T(0);
+        }
+        acc_x += mx * gix;
+        acc_y += my * giy;
+        // ---- the lanes the straight line does not serve: a tap on the border of its level (or with a non-finite coordinate),
+        // and interior taps beyond the deferral range that found no window (texture gradient straight to global memory)
+        const bool slow = on & (!interior | ((cell < 0) & (i >= 16)));
+        if (__ballot(slow) != 0) {
+          if (slow) {
+            const T alpha = s == 0 ? alpha_2 : alpha_1;
+            const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
+            const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
+            const int qcell = slot_cell(l, q.ix_nw, q.iy_nw);
+            const int stride = slot_stride(l), chan = slot_chan(l);
+            const bool defer = !interior && !DRTK_DBG(dbg, 1) && qcell < 0 && i < 16 && (q.o_nw & q.o_ne & q.o_sw & q.o_se) != -1; // (all four corners outside the level: nothing to add anywhere)
+            if (defer) pending |= 1u << (2 * i + s);
+            T sgx = T(0), sgy = T(0);
+#pragma unroll 1
+            for (int c = 0; c < CN; ++c) {
+              const T gOut = (c == 0 ? go[0] : c == 1 ? go[CN > 1 ? 1 : 0] : c == 2 ? go[CN > 2 ? 2 : 0] : go[CN > 3 ? 3 : 0]) * alpha;
+              if (gOut == T(0)) continue; // a zero upstream gradient (masked channel) adds nothing; its texels count as 0
+              if (!DRTK_DBG(dbg, 1)) {
+                if (qcell >= 0 && !interior) {
+                  double* wp = s_win + slot_base(l) + c * chan + qcell;
+                  if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * gOut));
+                  if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * gOut));
+                  if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * gOut));
+                  if (q.o_se >= 0) lds_add(wp + stride + 1, static_cast<double>(q.se * gOut));
+                } else if (!defer) {
+                  const GlobalPtr<T> gp = grad_base(d, plane) + c * plane;
+                  if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * gOut);
+                  if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * gOut);
+                  if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * gOut);
+                  if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gOut);
+                }
+              }
+              if (interior) continue; // (its grid gradient is in the straight line above)
+              const GlobalPtr<const T> pch = inp + c * plane;
+              T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
+              if (!DRTK_DBG(dbg, 2)) {
+                if (q.o_nw >= 0) v_nw = pch[q.o_nw];
+                if (q.o_ne >= 0) v_ne = pch[q.o_ne];
+                if (q.o_sw >= 0) v_sw = pch[q.o_sw];
+                if (q.o_se >= 0) v_se = pch[q.o_se];
+              }
+              if (q.o_nw >= 0) {
+                sgx -= v_nw * (iy_se - q.iy) * gOut;
+                sgy -= v_nw * (ix_se - q.ix) * gOut;
+              }
+              if (q.o_ne >= 0) {
+                sgx += v_ne * (iy_se - q.iy) * gOut;
+                sgy -= v_ne * (q.ix - q.ix_nw) * gOut;
+              }
+              if (q.o_sw >= 0) {
+                sgx -= v_sw * (q.iy - q.iy_nw) * gOut;
+                sgy += v_sw * (ix_se - q.ix) * gOut;
+              }
+              if (q.o_se >= 0) {
+                sgx += v_se * (q.iy - q.iy_nw) * gOut;
+                sgy += v_se * (q.ix - q.ix_nw) * gOut;
+              }
+            }
+            acc_x += q.mx * sgx;
+            acc_y += q.my * sgy;
+          }
+        }
+      }
+    }
+    // the last run
+    if (live[0]) {
+      T g[CN];
+#pragma unroll
+      for (int c = 0; c < CN; ++c) g[c] = go[c] * alpha_2;
+      emit_run(t.d1 - ref, g);
+    }
+  }
+  if (valid) {
+    store_grid_grad<T>(grad_grid, ggl, n, pix, acc_x, acc_y);
+    DRTK_MIP_STAT(8, (live[0] ? t.n : 0) + (live[1] ? t.n : 0));
+    DRTK_MIP_STAT(9, __popc(pending));
+  }
+  if (tid == 0) DRTK_MIP_STAT(0, 1);
+  __syncthreads();
+  // flush the windows: consecutive threads = consecutive texels of a row; cells that stayed 0 cost nothing,
+  // cells outside the level were never written (only in-bounds corners are accumulated).  With `rearm` the cells are
+  // zeroed as they are read: the windows serve a second round.
+  auto flush = [&](int ref_level, bool rearm) {
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l) {
+      const int d = ref_level + l;
+      if (d >= mipmaps || wox[l] == INT32_MAX || DRTK_DBG(dbg, 4)) continue;
+      const int h = s_h[d], w = s_w[d];
+      const int64_t plane = int64_t(h) * w;
+      const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+      for (int c = 0; c < C; ++c) {
+        // two cells per lane and step (one 16-byte LDS read); a window row = consecutive lanes
+        const int stride = 1 << wsx[l], chan = wcells[l];
+        double2* win2 = reinterpret_cast<double2*>(s_win + (l == 0 ? 0 : C * wcells[0]) + c * chan);
+        for (int i2 = tid; i2 < win_rows[l] * stride / 2; i2 += kMipBlock) { // rows beyond win_rows were never written
+          const double2 q = win2[i2];
+          if (rearm && (q.x != 0.0 || q.y != 0.0)) win2[i2] = double2{0.0, 0.0};
+          const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
+          const int i = i2 * 2;
+          const int gx = wox[l] + (i & (stride - 1)), gy = woy[l] + (i >> wsx[l]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
+          }
+        }
+      }
+    }
+  };
+  // Does any pixel of the tile have taps the windows did not hold?  (16 % of the tiles of the minified benchmark scenes;
+  // on the textured benchmark the atlas seam -- neighbouring pixels sample opposite ends of the texture -- and the limb,
+  // where eight anisotropic taps spread over more texels than a window is wide.)  `pending` says which.
+#ifndef DRTK_MIP_ROUNDS
+#define DRTK_MIP_ROUNDS 6 // same-box A/B (textured benchmark / kernel_bench at 1 texel per pixel / at 4): 1 round (all misses to
+#endif                    // global memory, rounds 1-2) 2.15 / 4.58 / 11.7 ms; 2: 2.00 / 3.80 / 9.85; 3: 1.95 / 3.41 / 9.10; 4: 1.94 / 3.11 / 8.63; 6: 1.97 / 2.97 / 8.09
+  // ---- further rounds: the windows are moved onto the taps that are still pending and those taps alone are accumulated
+  // (texture gradient only: the grid gradient is complete).  What is still pending after the last round -- a region of
+  // the texture or a level too many -- goes to global memory corner by corner, as all misses did before.
+  // HOPELESS tiles (round 5): where a round catches less than a quarter of the pixels that still had pending taps, the taps
+  // are scattered beyond what windows can hold -- the poles of an atlas, where neighbouring pixels sample texels
+  // thousands of columns apart: on the textured benchmark 1.7 % of the tiles ran all five further rounds and still sent
+  // nearly all of their taps to global memory afterwards (profiles/mipmap_bench.py --rounds-stats) -- 39 % of all tile-rounds.
+  // The next round of such a tile is its last (what is pending goes to global memory at once).  A seam tile, whose taps
+  // form two far-apart clusters, halves its pending pixels per round and carries on.
+  int ref_now = ref, pending_px_before = kMipBlock + 1;
+  for (int round = 1;; ++round) {
+    const int pending_px = __syncthreads_count(pending != 0);
+    const bool again = pending_px != 0 && !DRTK_DBG(dbg, 8);
+    flush(ref_now, again);
+    if (!again) return;
+    if (tid == 0) DRTK_MIP_STAT(round < 7 ? round : 7, 1);
+    const bool hopeless = DRTK_MIP_HOPELESS && round >= 2 && pending_px * 4 > pending_px_before * 3;
+    pending_px_before = pending_px;
+    const bool last = round >= DRTK_MIP_ROUNDS - 1 || hopeless;
+    __syncthreads(); // everybody has finished its flush (it reads the origins)
+    if (tid == 0) s_ref = kMaxLevels;
+    if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX, s_hx[tid] = s_hy[tid] = INT32_MIN;
+    // where this pixel's pending taps are: bounding box of their north-west texels per level
+    bool miss[2] = {false, false};
+    int miss_x[2] = {INT32_MAX, INT32_MAX}, miss_y[2] = {INT32_MAX, INT32_MAX}, miss_hx[2] = {INT32_MIN, INT32_MIN}, miss_hy[2] = {INT32_MIN, INT32_MIN};
+    for (uint32_t todo = pending; todo;) {
+      const int bit = __builtin_ctz(todo);
+      todo &= todo - 1;
+      const int i = bit >> 1, s2 = bit & 1;
+      T x, y;
+      tap_xy(i, x, y);
+      const int d = t.d1 + s2;
+      const Quad<T> q = bilinear_quad<T>(x, y, s_h[d], s_w[d], padding, align_corners);
+      if (s2 == 0) {
+        miss[0] = true, miss_x[0] = min(miss_x[0], q.ix_nw), miss_y[0] = min(miss_y[0], q.iy_nw);
+        miss_hx[0] = max(miss_hx[0], q.ix_nw), miss_hy[0] = max(miss_hy[0], q.iy_nw);
+      } else {
+        miss[1] = true, miss_x[1] = min(miss_x[1], q.ix_nw), miss_y[1] = min(miss_y[1], q.iy_nw);
+        miss_hx[1] = max(miss_hx[1], q.ix_nw), miss_hy[1] = max(miss_hy[1], q.iy_nw);
+      }
+    }
+    __syncthreads();
+    {
+      const int d_min = wave_min_i32(miss[0] ? t.d1 : miss[1] ? t.d1 + 1 : kMaxLevels);
+      if ((tid & (kWave - 1)) == 0) atomicMin(&s_ref, d_min);
+    }
+    __syncthreads();
+    ref_now = s_ref;
+    {
+      int lo_x[kWinLevels], lo_y[kWinLevels], hi_x[kWinLevels], hi_y[kWinLevels];
+#pragma unroll
+      for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX, hi_x[l] = hi_y[l] = INT32_MIN;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int l = t.d1 + s2 - ref_now;
+#pragma unroll
+        for (int k = 0; k < kWinLevels; ++k) {
+          if (miss[s2] && k == l) {
+            lo_x[k] = min(lo_x[k], miss_x[s2]), lo_y[k] = min(lo_y[k], miss_y[s2]);
+            hi_x[k] = max(hi_x[k], miss_hx[s2]), hi_y[k] = max(hi_y[k], miss_hy[s2]);
+          }
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < kWinLevels; ++l) {
+        const int a = wave_min_i32(lo_x[l]), b = wave_min_i32(lo_y[l]);
+        const int g = wave_max_i32(hi_x[l]), e = wave_max_i32(hi_y[l]);
+        if ((tid & (kWave - 1)) == 0 && a != INT32_MAX) {
+          atomicMin(&s_ox[l], a);
+          atomicMin(&s_oy[l], b);
+          atomicMax(&s_hx[l], g);
+          atomicMax(&s_hy[l], e);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      int lox[kWinLevels], loy[kWinLevels], hix[kWinLevels], hiy[kWinLevels];
+#pragma unroll
+      for (int l = 0; l < kWinLevels; ++l) {
+        lox[l] = __builtin_amdgcn_readfirstlane(s_ox[l]), loy[l] = __builtin_amdgcn_readfirstlane(s_oy[l]);
+        hix[l] = __builtin_amdgcn_readfirstlane(s_hx[l]), hiy[l] = __builtin_amdgcn_readfirstlane(s_hy[l]);
+      }
+      // a window whose slot has no pending tap on level ref_now must still exist as slot 0: ref_now IS a level with pending taps
+      shape_slots(lox, loy, hix, hiy, true);
+    }
+    if (pending != 0) {
+      uint32_t todo = pending;
+      while (todo) {
+        const int bit = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int i = bit >> 1, s2 = bit & 1;
+        T x, y;
+        tap_xy(i, x, y);
+        const int d = t.d1 + s2;
+        const int h = s_h[d], w = s_w[d];
+        const int64_t plane = int64_t(h) * w;
+        const T alpha = s2 == 0 ? alpha_2 : alpha_1;
+        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
+        const int l = d - ref_now;
+        const int cell = slot_cell(l, q.ix_nw, q.iy_nw);
+        const int stride = slot_stride(l), chan = slot_chan(l);
+        if (cell < 0 && !last) continue; // stays pending: the next round's windows
+        pending &= ~(1u << bit);
+        if (cell < 0) DRTK_MIP_STAT(10, 1);
+        const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+          const T gc = go[c] * alpha;
+          if (gc == T(0)) continue;
+          if (cell >= 0) {
+            double* wp = s_win + slot_base(l) + c * chan + cell;
+            if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * gc));
+            if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * gc));
+            if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * gc));
+            if (q.o_se >= 0) lds_add(wp + stride + 1, static_cast<double>(q.se * gc));
+          } else {
+            const GlobalPtr<T> gp = ginp + c * plane;
+            if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * gc);
+            if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * gc);
+            if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * gc);
+            if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gc);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- Backward, bilinear, f32, any C: WAVE-PRIVATE windows (round 4) -------------------------------------------------
+
 // ---- Backward, bilinear, f32, any C: WAVE-PRIVATE windows (round 4) -------------------------------------------------
 // mipmap_backward_tiled_kernel above is bound by its chain of dependent round trips at 3 waves per SIMD: 48 KB of
 // workgroup-shared windows and 157 VGPRs hold the occupancy there, and every phase of a tile (window placement, taps,
@@ -2695,6 +3264,35 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
       static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
       force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
 #endif
+#ifndef DRTK_MIP_BWD_LEAN
+#define DRTK_MIP_BWD_LEAN 1
+#endif
+    if constexpr (sizeof(T) == 4 && DRTK_MIP_BWD_LEAN) {
+      if (padding_mode != 2 && C >= 1) { // float, zeros / border padding: the lean tap loop, channels a template parameter
+#define LEANK(PAD, ALIGN, CN)                                                                                           \
+  DRTK_LAUNCH(                                                                                                          \
+      (mipmap_backward_lean_kernel<PAD, ALIGN, CN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      dim3(kMipBlock), sizeof(double) * CN * kLeanCells, s, lv, mipmaps, static_cast<const float*>(grad_out),          \
+      static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, tiles_x, max_aniso, \
+      force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
+#define LEANC(PAD, ALIGN)                                                                       \
+  switch (C) {                                                                                  \
+    case 1: LEANK(PAD, ALIGN, 1); break;                                                        \
+    case 2: LEANK(PAD, ALIGN, 2); break;                                                        \
+    case 3: LEANK(PAD, ALIGN, 3); break;                                                        \
+    default: LEANK(PAD, ALIGN, 4); break;                                                       \
+  }
+        if (align_corners) {
+          if (padding_mode == 0) { LEANC(0, true) } else { LEANC(1, true) }
+        } else {
+          if (padding_mode == 0) { LEANC(0, false) } else { LEANC(1, false) }
+        }
+#undef LEANC
+#undef LEANK
+        DRTK_RETURN_IF_LAUNCH_FAILED();
+        return DRTK_OK;
+      }
+    }
     if (align_corners) {
       if (padding_mode == 0) TILED(0, true); else if (padding_mode == 1) TILED(1, true); else TILED(2, true);
     } else {
