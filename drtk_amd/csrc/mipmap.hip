@@ -1512,7 +1512,10 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : 3))
 #define DRTK_MIP_T2_OCC 3
 #endif
 #ifndef DRTK_MIP_HOPELESS
-#define DRTK_MIP_HOPELESS 1
+#define DRTK_MIP_HOPELESS 0 // measured and left OFF (below): -1.5 % on the textured benchmark at its best threshold, +3 ... +10 % on minified scenes
+#endif
+#ifndef DRTK_MIP_HOPELESS_PAIRS
+#define DRTK_MIP_HOPELESS_PAIRS 96 // (a round costs about as much as sending this many pairs' 12 atomics each to global memory)
 #endif
 template <typename T, int PAD, bool ALIGN>
 // (3 workgroups per CU by registers as by LDS; reflection padding needs ~200: 2)
@@ -1527,7 +1530,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
   __shared__ long long s_sn[kMaxLevels];
-  __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels], s_hx[kWinLevels], s_hy[kWinLevels];
+  __shared__ int s_ref, s_npend, s_ox[kWinLevels], s_oy[kWinLevels], s_hx[kWinLevels], s_hy[kWinLevels];
   // first-round placement per ABSOLUTE level (so that the reference level and the origins come out of ONE phase):
   // bounding box of the north-west texels of the tile's taps on level d
   __shared__ int s_lox[kMaxLevels + 1], s_loy[kMaxLevels + 1], s_hix[kMaxLevels + 1], s_hiy[kMaxLevels + 1];
@@ -1917,24 +1920,25 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
   // ---- further rounds: the windows are moved onto the taps that are still pending and those taps alone are accumulated
   // (texture gradient only: the grid gradient is complete).  What is still pending after the last round -- a region of
   // the texture or a level too many -- goes to global memory corner by corner, as all misses did before.
-  // HOPELESS tiles (round 5): where a round catches less than a quarter of the pixels that still had pending taps, the taps
-  // are scattered beyond what windows can hold -- the poles of an atlas, where neighbouring pixels sample texels
-  // thousands of columns apart: on the textured benchmark 1.7 % of the tiles ran all five further rounds and still sent
-  // nearly all of their taps to global memory afterwards (profiles/mipmap_bench.py --rounds-stats) -- 39 % of all tile-rounds.
-  // The next round of such a tile is its last (what is pending goes to global memory at once).  A seam tile, whose taps
-  // form two far-apart clusters, halves its pending pixels per round and carries on.
-  int ref_now = ref, pending_px_before = kMipBlock + 1;
+  // HOPELESS tiles (round 5): where a round catches only a handful of (tap, level) pairs, the taps are scattered beyond what
+  // windows can hold -- the poles of an atlas, where neighbouring pixels sample texels thousands of columns apart: on the
+  // textured benchmark 1.7 % of the tiles ran all five further rounds and still sent nearly all of their taps to global
+  // memory afterwards (profiles/mipmap_bench.py --rounds-stats), 39 % of all tile-rounds.  The round after such a round is
+  // the tile's last (what is pending goes to global memory at once).  The test is on PAIRS caught, not on a share: a tile
+  // of a minified texture needs many windows and every one of its rounds catches hundreds of pairs -- cutting those short
+  // (a first version tested the share of pixels that still had pending taps) cost 11 % on the minified scenes.
+  // Same-box A/B of the threshold (textured benchmark / kernel_bench at 1 and 4 texels per pixel, ms): off 1.565 / 2.755 /
+  // 7.74; 32 pairs 1.565 / 2.80 / 7.94; 96 1.56 / 2.98 / 8.23; 256 1.538 / 3.03 / 8.50 -- what the pole tiles save, the
+  // tiles of a minified texture lose several times over: the switch stays off.
+  int ref_now = ref, npend_before = 0;
   for (int round = 1;; ++round) {
-    const int pending_px = __syncthreads_count(pending != 0);
-    const bool again = pending_px != 0 && !DRTK_DBG(dbg, 8);
+    const bool again = __syncthreads_or(pending != 0) && !DRTK_DBG(dbg, 8);
     flush(ref_now, again);
     if (!again) return;
     if (tid == 0) DRTK_MIP_STAT(round < 7 ? round : 7, 1);
-    const bool hopeless = DRTK_MIP_HOPELESS && round >= 2 && pending_px * 4 > pending_px_before * 3;
-    pending_px_before = pending_px;
-    const bool last = round >= DRTK_MIP_ROUNDS - 1 || hopeless;
+    bool last = round >= DRTK_MIP_ROUNDS - 1; // (or hopeless, below)
     __syncthreads(); // everybody has finished its flush (it reads the origins)
-    if (tid == 0) s_ref = kMaxLevels;
+    if (tid == 0) s_ref = kMaxLevels, s_npend = 0;
     if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX, s_hx[tid] = s_hy[tid] = INT32_MIN;
     // where this pixel's pending taps are: bounding box of their north-west texels per level
     bool miss[2] = {false, false};
@@ -1958,10 +1962,26 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
     __syncthreads();
     {
       const int d_min = wave_min_i32(miss[0] ? t.d1 : miss[1] ? t.d1 + 1 : kMaxLevels);
-      if ((tid & (kWave - 1)) == 0) atomicMin(&s_ref, d_min);
+      // the tile's pending (tap, level) pairs: a wave's count from five ballots over the bits of its lanes' counts (<= 32)
+      const int pc = __popc(pending);
+      int wave_pc = 0;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) wave_pc += __popcll(__ballot((pc >> b) & 1)) << b;
+      if ((tid & (kWave - 1)) == 0) {
+        atomicMin(&s_ref, d_min);
+        atomicAdd(&s_npend, wave_pc);
+      }
     }
     __syncthreads();
     ref_now = s_ref;
+    {
+      // HOPELESS: the round before this one caught fewer than kHopelessPairs pairs -- scattered taps; this round is the last
+      const int npend = s_npend;
+      const bool hopeless = DRTK_MIP_HOPELESS && round >= 2 && npend_before - npend < DRTK_MIP_HOPELESS_PAIRS;
+      if (tid == 0 && hopeless) DRTK_MIP_STAT(11, 1);
+      npend_before = npend;
+      last = last || hopeless;
+    }
     {
       int lo_x[kWinLevels], lo_y[kWinLevels], hi_x[kWinLevels], hi_y[kWinLevels];
 #pragma unroll
@@ -2079,7 +2099,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   __shared__ void* s_grad[kMaxLevels];
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
   __shared__ long long s_sn[kMaxLevels];
-  __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels], s_hx[kWinLevels], s_hy[kWinLevels];
+  __shared__ int s_ref, s_npend, s_ox[kWinLevels], s_oy[kWinLevels], s_hx[kWinLevels], s_hy[kWinLevels];
   // first-round placement per ABSOLUTE level (so that the reference level and the origins come out of ONE phase):
   // bounding box of the north-west texels of the tile's taps on level d
   __shared__ int s_lox[kMaxLevels + 1], s_loy[kMaxLevels + 1], s_hix[kMaxLevels + 1], s_hiy[kMaxLevels + 1];
@@ -2487,24 +2507,25 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   // ---- further rounds: the windows are moved onto the taps that are still pending and those taps alone are accumulated
   // (texture gradient only: the grid gradient is complete).  What is still pending after the last round -- a region of
   // the texture or a level too many -- goes to global memory corner by corner, as all misses did before.
-  // HOPELESS tiles (round 5): where a round catches less than a quarter of the pixels that still had pending taps, the taps
-  // are scattered beyond what windows can hold -- the poles of an atlas, where neighbouring pixels sample texels
-  // thousands of columns apart: on the textured benchmark 1.7 % of the tiles ran all five further rounds and still sent
-  // nearly all of their taps to global memory afterwards (profiles/mipmap_bench.py --rounds-stats) -- 39 % of all tile-rounds.
-  // The next round of such a tile is its last (what is pending goes to global memory at once).  A seam tile, whose taps
-  // form two far-apart clusters, halves its pending pixels per round and carries on.
-  int ref_now = ref, pending_px_before = kMipBlock + 1;
+  // HOPELESS tiles (round 5): where a round catches only a handful of (tap, level) pairs, the taps are scattered beyond what
+  // windows can hold -- the poles of an atlas, where neighbouring pixels sample texels thousands of columns apart: on the
+  // textured benchmark 1.7 % of the tiles ran all five further rounds and still sent nearly all of their taps to global
+  // memory afterwards (profiles/mipmap_bench.py --rounds-stats), 39 % of all tile-rounds.  The round after such a round is
+  // the tile's last (what is pending goes to global memory at once).  The test is on PAIRS caught, not on a share: a tile
+  // of a minified texture needs many windows and every one of its rounds catches hundreds of pairs -- cutting those short
+  // (a first version tested the share of pixels that still had pending taps) cost 11 % on the minified scenes.
+  // Same-box A/B of the threshold (textured benchmark / kernel_bench at 1 and 4 texels per pixel, ms): off 1.565 / 2.755 /
+  // 7.74; 32 pairs 1.565 / 2.80 / 7.94; 96 1.56 / 2.98 / 8.23; 256 1.538 / 3.03 / 8.50 -- what the pole tiles save, the
+  // tiles of a minified texture lose several times over: the switch stays off.
+  int ref_now = ref, npend_before = 0;
   for (int round = 1;; ++round) {
-    const int pending_px = __syncthreads_count(pending != 0);
-    const bool again = pending_px != 0 && !DRTK_DBG(dbg, 8);
+    const bool again = __syncthreads_or(pending != 0) && !DRTK_DBG(dbg, 8);
     flush(ref_now, again);
     if (!again) return;
     if (tid == 0) DRTK_MIP_STAT(round < 7 ? round : 7, 1);
-    const bool hopeless = DRTK_MIP_HOPELESS && round >= 2 && pending_px * 4 > pending_px_before * 3;
-    pending_px_before = pending_px;
-    const bool last = round >= DRTK_MIP_ROUNDS - 1 || hopeless;
+    bool last = round >= DRTK_MIP_ROUNDS - 1; // (or hopeless, below)
     __syncthreads(); // everybody has finished its flush (it reads the origins)
-    if (tid == 0) s_ref = kMaxLevels;
+    if (tid == 0) s_ref = kMaxLevels, s_npend = 0;
     if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX, s_hx[tid] = s_hy[tid] = INT32_MIN;
     // where this pixel's pending taps are: bounding box of their north-west texels per level
     bool miss[2] = {false, false};
@@ -2528,10 +2549,26 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     __syncthreads();
     {
       const int d_min = wave_min_i32(miss[0] ? t.d1 : miss[1] ? t.d1 + 1 : kMaxLevels);
-      if ((tid & (kWave - 1)) == 0) atomicMin(&s_ref, d_min);
+      // the tile's pending (tap, level) pairs: a wave's count from five ballots over the bits of its lanes' counts (<= 32)
+      const int pc = __popc(pending);
+      int wave_pc = 0;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) wave_pc += __popcll(__ballot((pc >> b) & 1)) << b;
+      if ((tid & (kWave - 1)) == 0) {
+        atomicMin(&s_ref, d_min);
+        atomicAdd(&s_npend, wave_pc);
+      }
     }
     __syncthreads();
     ref_now = s_ref;
+    {
+      // HOPELESS: the round before this one caught fewer than kHopelessPairs pairs -- scattered taps; this round is the last
+      const int npend = s_npend;
+      const bool hopeless = DRTK_MIP_HOPELESS && round >= 2 && npend_before - npend < DRTK_MIP_HOPELESS_PAIRS;
+      if (tid == 0 && hopeless) DRTK_MIP_STAT(11, 1);
+      npend_before = npend;
+      last = last || hopeless;
+    }
     {
       int lo_x[kWinLevels], lo_y[kWinLevels], hi_x[kWinLevels], hi_y[kWinLevels];
 #pragma unroll
@@ -2589,6 +2626,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
         if (cell < 0 && !last) continue; // stays pending: the next round's windows
         pending &= ~(1u << bit);
         if (cell < 0) DRTK_MIP_STAT(10, 1);
+        if (cell < 0) DRTK_MIP_STAT(12 + min(max(d - ref, 0), 3), 1);
         const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
 #pragma unroll
         for (int c = 0; c < CN; ++c) {

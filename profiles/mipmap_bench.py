@@ -136,7 +136,8 @@ if a.rounds_stats:
     L.drtk_amd_debug_set_flags(0)
     st = list(buf)
     print(f"tiles with gradient {st[0]}; entering round 1..7: {st[1:8]}; (tap, level) pairs {st[8]}, pending after the first pass {st[9]} "
-          f"({100.0 * st[9] / max(st[8], 1):.2f} %), to global memory after the last round {st[10]}")
+          f"({100.0 * st[9] / max(st[8], 1):.2f} %), to global memory after the last round {st[10]} (by level above the tile's finest: {st[12:16]}); "
+          f"tiles cut short as hopeless {st[11]}")
 
 if a.dump:
     gl, gg = capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0)

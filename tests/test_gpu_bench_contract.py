@@ -118,7 +118,7 @@ def test_textured_workload_line():
               "--steps", "3", "--warmup", "1", "--kernel-steps", "2", "--cpu-sample-views", "1"])
     assert TOP <= set(d) and "textured" in d["metric"] and "fp16" in d["config"]["workload"]
     ks = d["path_roofline"]["kernels"]
-    for k in ("uv_derivative_kernel", "mipmap_forward_kernel", "mipmap_backward_tiled_kernel", "tile_raster_kernel", "edge_dots_kernel"):
+    for k in ("uv_derivative_kernel", "mipmap_forward_lean_kernel", "mipmap_backward_lean_kernel", "tile_raster_kernel", "edge_dots_kernel"):
         assert k in ks and ks[k]["ms_per_step"] > 0, k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert "error" not in d["graph_step"]
