@@ -419,8 +419,10 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPasses = kTileRows / kWaves;
   constexpr int kSlots = kTableSlots;
+  constexpr int kStride = CN <= 4 ? 4 : 8; // table entries per vertex
+  static_assert(CN >= 1 && CN <= 8, "channels in registers");
   __shared__ int32_t t_keys[HAS_VERT ? kWaves : 1][HAS_VERT ? kSlots : 1];
-  __shared__ TableAcc t_vals[HAS_VERT ? kWaves : 1][HAS_VERT ? kSlots * 4 : 1];
+  __shared__ TableAcc t_vals[HAS_VERT ? kWaves : 1][HAS_VERT ? kSlots * kStride : 1];
 
   const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
 
   if constexpr (HAS_VERT) {
     table_init<kSlots>(t_keys[wave]);
-    for (int i = lane; i < kSlots * 4; i += kWave) t_vals[wave][i] = 0;
+    for (int i = lane; i < kSlots * kStride; i += kWave) t_vals[wave][i] = 0;
     wave_lds_sync();
   }
   auto load_tr = [&](int ps) -> int32_t {
@@ -501,13 +503,13 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
           for (int c = 0; c < CN; ++c) p[k * CN + c] = g[c] * B[k];
         }
         run_sums_rows16<T, 3 * CN>(p, dist);
-        if (tail && covered) table_add<T, 3, CN, kSlots>(t_keys[wave], t_vals[wave], 4, cur, p, attr_grad_n, CN);
+        if (tail && covered) table_add<T, 3, CN, kSlots>(t_keys[wave], t_vals[wave], kStride, cur, p, attr_grad_n, CN);
       }
     }
   }
   if constexpr (HAS_VERT) {
     wave_lds_sync();
-    table_flush<T, TableAcc, kSlots>(t_keys[wave], t_vals[wave], 4, CN, attr_grad_n, CN, 0);
+    table_flush<T, TableAcc, kSlots>(t_keys[wave], t_vals[wave], kStride, CN, attr_grad_n, CN, 0);
   }
 }
 
@@ -976,10 +978,13 @@ int interpolate_backward_impl(
       (interpolate_backward_kernel<T, HV, HB, CV, CH>), grid, block, 0, stream, grad_out, attrs, \
       vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad,  \
       debug_flags(), strip)
-  const bool small_c = C <= 4;
+#ifndef DRTK_INTERP_SMALL_MAXC
+#define DRTK_INTERP_SMALL_MAXC 4 // the register-scan kernel up to this many channels (5..8 instantiated for A/B)
+#endif
+  const bool small_c = C <= DRTK_INTERP_SMALL_MAXC;
   // wide path: the vertex gradient (+ bary gradient) for any C >= 5, float and double (round 5; round 4: C % 4 == 0,
   // C >= 8, float only -- every other shape took the generic kernel, a chain of dependent waits per row)
-  const bool wide = attr_grad && C >= 5 && HW * int64_t(sizeof(T)) < (int64_t(1) << 32) && !DRTK_DBG(debug_flags(), 128);
+  const bool wide = attr_grad && C > DRTK_INTERP_SMALL_MAXC && HW * int64_t(sizeof(T)) < (int64_t(1) << 32) && !DRTK_DBG(debug_flags(), 128);
   // (the bary gradient alone stays with the generic kernel: no scatter, covered pixels only -- 0.95 of the HBM peak on
   // SURVEY 8d's bytes at the bench coverage; a forward-shaped streaming kernel with four pixels per lane, which cannot
   // skip the background of a partly covered quad, was measured slower: 0.55 vs 0.40 ms at C = 16)
@@ -1039,6 +1044,19 @@ int interpolate_backward_impl(
   DRTK_LAUNCH(                                                                                                              \
       (interpolate_backward_small_kernel<T, HV, HB, CN>), grid, block, 0, stream, grad_out, attrs, vi, index_img, bary_img, \
       V, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, strip)
+#if DRTK_INTERP_SMALL_MAXC > 4
+#define SMALL_C(HV, HB)          \
+  switch (C) {                   \
+    case 1: SMALL(HV, HB, 1); break; \
+    case 2: SMALL(HV, HB, 2); break; \
+    case 3: SMALL(HV, HB, 3); break; \
+    case 4: SMALL(HV, HB, 4); break; \
+    case 5: SMALL(HV, HB, 5); break; \
+    case 6: SMALL(HV, HB, 6); break; \
+    case 7: SMALL(HV, HB, 7); break; \
+    default: SMALL(HV, HB, 8); break; \
+  }
+#else
 #define SMALL_C(HV, HB)          \
   switch (C) {                   \
     case 1: SMALL(HV, HB, 1); break; \
@@ -1046,6 +1064,7 @@ int interpolate_backward_impl(
     case 3: SMALL(HV, HB, 3); break; \
     default: SMALL(HV, HB, 4); break; \
   }
+#endif
     if (attr_grad && bary_grad) {
       SMALL_C(true, true)
     } else if (attr_grad) {

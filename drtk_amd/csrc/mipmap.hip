@@ -2072,6 +2072,8 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 // products, texture channels a template parameter) -- for the instructions, and for the REGISTERS: the tile kernels sat at
 // 151-168 VGPRs = 3 waves per SIMD with every tile's chain (loads -> barrier -> placement -> barrier -> taps -> barrier ->
 // flush) exposed; at <= 128 a CU holds four tiles instead of three.
+// Wider textures (C > 4: neural textures) run it once per block of four channels (`C_total`, `c0`; the grid gradient
+// accumulates over the blocks, the tap geometry is recomputed per block) instead of the wave-private kernel below.
 #ifndef DRTK_MIP_T3_OCC
 #define DRTK_MIP_T3_OCC 4
 #endif
@@ -2081,13 +2083,17 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #ifndef DRTK_MIP_T3_SLOT_CELLS
 #define DRTK_MIP_T3_SLOT_CELLS 768
 #endif
-constexpr int kLeanSlotCells = DRTK_MIP_T3_SLOT_CELLS, kLeanCells = kWinLevels * kLeanSlotCells;
-static_assert(kLeanSlotCells % 128 == 0, "whole rows at every slot width (16 ... 128 cells), cells in pairs");
+#ifndef DRTK_MIP_T3_SLOT_CELLS4
+#define DRTK_MIP_T3_SLOT_CELLS4 512 // four channels: 2 x 512 x 4 x 8 B = 32 KB keeps four tiles per CU (768: 48 KB, three)
+#endif
+template <int CN>
+constexpr int lean_slot_cells() { return CN == 4 ? DRTK_MIP_T3_SLOT_CELLS4 : DRTK_MIP_T3_SLOT_CELLS; }
+static_assert(DRTK_MIP_T3_SLOT_CELLS % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS4 % 128 == 0, "whole rows at every slot width (16 ... 128 cells), cells in pairs");
 template <int PAD, bool ALIGN, int CN>
 __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_lean_kernel(
     LevelTable lv, int mipmaps, const float* __restrict__ grad_out, const float* __restrict__ grid, GridLayout gl,
     const float* __restrict__ vt, int H, int W, int tiles_x, int max_aniso,
-    bool force_max_aniso, bool clip_grad, float* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
+    bool force_max_aniso, bool clip_grad, float* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg, int C_total, int c0) {
   using T = float;
   static_assert(PAD == 0 || PAD == 1, "zeros or border padding");
   static_assert(CN >= 1 && CN <= 4, "texture channels");
@@ -2118,7 +2124,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
 #pragma unroll
   for (int c = 0; c < CN; ++c) go[c] = T(0);
   if (valid) {
-    const T* gout_px = grad_out + int64_t(n) * C * HW + (int64_t(py) * W + px);
+    const T* gout_px = grad_out + (int64_t(n) * C_total + c0) * HW + (int64_t(py) * W + px);
 #pragma unroll
     for (int c = 0; c < CN; ++c) go[c] = gout_px[int64_t(c) * HW];
   }
@@ -2137,13 +2143,13 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   {
     double2* w2 = reinterpret_cast<double2*>(s_win);
     const double2 z = {0.0, 0.0};
-    for (int i = tid; i < C * kLeanCells / 2; i += kMipBlock) w2[i] = z;
+    for (int i = tid; i < C * (kWinLevels * lean_slot_cells<CN>()) / 2; i += kMipBlock) w2[i] = z;
   }
   bool has_go = false;
 #pragma unroll
   for (int c = 0; c < CN; ++c) has_go = has_go | (go[c] != T(0));
   if (!__syncthreads_or(has_go)) { // (also publishes the tables and the zero-fill)
-    if (valid) store_grid_grad<T>(grad_grid, ggl, n, pix, T(0), T(0));
+    if (valid && c0 == 0) store_grid_grad<T>(grad_grid, ggl, n, pix, T(0), T(0)); // (a later channel block adds nothing)
     return;
   }
 
@@ -2222,7 +2228,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   // texture -- gives it all to slot 0; a slot is 2^sx cells wide, sx chosen by the bounding box of the taps it has to
   // hold (16 ... 128 wide: the elongated footprints of a limb tile fit where a 32 x 32 square needed four rounds).
   // Wave-uniform values: scalar registers.
-  constexpr int kWinSlotCells = kLeanSlotCells;
+  constexpr int kWinSlotCells = lean_slot_cells<CN>();
   int wox[kWinLevels], woy[kWinLevels], wsx[kWinLevels], wny[kWinLevels], wcells[kWinLevels], win_rows[kWinLevels];
   auto shape_slots = [&](const int (&lox)[kWinLevels], const int (&loy)[kWinLevels], const int (&hix)[kWinLevels], const int (&hiy)[kWinLevels], bool all_rows) {
     const bool two = lox[1] != INT32_MAX;
@@ -2281,7 +2287,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     const bool table = max_aniso <= kTapTab; // kernel-uniform
     const int tn1 = max(t.n, 1);
     const double du_d = t.du, dv_d = t.dv;
-    auto grad_base = [&](int d, int64_t plane) -> GlobalPtr<T> { return (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane); };
+    auto grad_base = [&](int d, int64_t plane) -> GlobalPtr<T> { return (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C_total + c0) * plane); };
     // (one run slot, for the pixel's FINER level: a magnified pixel has no other live level, and the taps of a minified
     // one are a texel apart on the finer level -- half a texel on the coarser, whose adds go to LDS tap by tap)
     int run_cell = -1;
@@ -2368,7 +2374,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
         const int plane = w * h; // < 2^31 (fill_table)
         const int o_top = interior ? iy_nw * w + ix_nw : 0;
         const int o_bot = interior ? o_top + w : 0;
-        const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]);
+        const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]) + int64_t(c0) * plane;
         Pair<T> top[CN], bot[CN];
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
@@ -2463,6 +2469,10 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     }
   }
   if (valid) {
+    if (c0 != 0) { // a further block of channels of a wide texture: the grid gradient accumulates (one thread per pixel, launches in stream order)
+      const T* gq = grad_grid + int64_t(n) * ggl.sN + pix * ggl.sP;
+      acc_x += gq[0], acc_y += gq[ggl.sC];
+    }
     store_grid_grad<T>(grad_grid, ggl, n, pix, acc_x, acc_y);
     DRTK_MIP_STAT(8, (live[0] ? t.n : 0) + (live[1] ? t.n : 0));
     DRTK_MIP_STAT(9, __popc(pending));
@@ -2479,7 +2489,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
       if (d >= mipmaps || wox[l] == INT32_MAX || DRTK_DBG(dbg, 4)) continue;
       const int h = s_h[d], w = s_w[d];
       const int64_t plane = int64_t(h) * w;
-      const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+      const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C_total + c0) * plane);
       for (int c = 0; c < C; ++c) {
         // two cells per lane and step (one 16-byte LDS read); a window row = consecutive lanes
         const int stride = 1 << wsx[l], chan = wcells[l];
@@ -2627,7 +2637,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
         pending &= ~(1u << bit);
         if (cell < 0) DRTK_MIP_STAT(10, 1);
         if (cell < 0) DRTK_MIP_STAT(12 + min(max(d - ref, 0), 3), 1);
-        const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
+        const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C_total + c0) * plane);
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
           const T gc = go[c] * alpha;
@@ -3245,6 +3255,43 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   // reference dispatches both (kernel_utils.h:35-57).  Returns 1 when the shape is not theirs.
   auto windowed = [&](auto tag) -> int {
     using T = decltype(tag);
+#ifndef DRTK_MIP_BWD_LEAN
+#define DRTK_MIP_BWD_LEAN 1
+#endif
+#ifndef DRTK_MIP_BWD_LEAN_WIDE
+#define DRTK_MIP_BWD_LEAN_WIDE 1 // C > 4: the lean tile kernel once per block of four channels instead of the wave-private kernel
+#endif
+    if constexpr (sizeof(T) == 4 && DRTK_MIP_BWD_LEAN) {
+      if (interpolation_mode == 0 && padding_mode != 2 && C >= 1 && N <= 65535 && !DRTK_DBG(debug_flags(), 512) &&
+          (C <= 4 || DRTK_MIP_BWD_LEAN_WIDE)) { // float, bilinear, zeros / border padding: the lean tap loop, four channels a launch
+        const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
+#define LEANK(PAD, ALIGN, CN)                                                                                           \
+  DRTK_LAUNCH(                                                                                                          \
+      (mipmap_backward_lean_kernel<PAD, ALIGN, CN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      dim3(kMipBlock), sizeof(double) * CN * kWinLevels * lean_slot_cells<CN>(), s, lv, mipmaps, static_cast<const float*>(grad_out), \
+      static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, tiles_x, max_aniso, \
+      force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags(), (int)C, c0)
+#define LEANC(PAD, ALIGN)                                                                       \
+  switch (cn) {                                                                                 \
+    case 1: LEANK(PAD, ALIGN, 1); break;                                                        \
+    case 2: LEANK(PAD, ALIGN, 2); break;                                                        \
+    case 3: LEANK(PAD, ALIGN, 3); break;                                                        \
+    default: LEANK(PAD, ALIGN, 4); break;                                                       \
+  }
+        for (int c0 = 0; c0 < C; c0 += 4) {
+          const int cn = static_cast<int>(C - c0 < 4 ? C - c0 : 4);
+          if (align_corners) {
+            if (padding_mode == 0) { LEANC(0, true) } else { LEANC(1, true) }
+          } else {
+            if (padding_mode == 0) { LEANC(0, false) } else { LEANC(1, false) }
+          }
+          DRTK_RETURN_IF_LAUNCH_FAILED();
+        }
+#undef LEANC
+#undef LEANK
+        return DRTK_OK;
+      }
+    }
   // bilinear: C <= 4 takes the workgroup-tiled kernel, wider textures (neural textures, 8-16 channels) the
   // wave-private one in blocks of four channels -- before round 4 they fell to the direct kernel, bound by the float-atomic
   // request rate.  (-DDRTK_MIP_BACKWARD_WAVE_ALL: the wave kernel for every C, for A/B; at C = 3 it is slower than the
@@ -3302,35 +3349,6 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
       static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
       force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
 #endif
-#ifndef DRTK_MIP_BWD_LEAN
-#define DRTK_MIP_BWD_LEAN 1
-#endif
-    if constexpr (sizeof(T) == 4 && DRTK_MIP_BWD_LEAN) {
-      if (padding_mode != 2 && C >= 1) { // float, zeros / border padding: the lean tap loop, channels a template parameter
-#define LEANK(PAD, ALIGN, CN)                                                                                           \
-  DRTK_LAUNCH(                                                                                                          \
-      (mipmap_backward_lean_kernel<PAD, ALIGN, CN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
-      dim3(kMipBlock), sizeof(double) * CN * kLeanCells, s, lv, mipmaps, static_cast<const float*>(grad_out),          \
-      static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, tiles_x, max_aniso, \
-      force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
-#define LEANC(PAD, ALIGN)                                                                       \
-  switch (C) {                                                                                  \
-    case 1: LEANK(PAD, ALIGN, 1); break;                                                        \
-    case 2: LEANK(PAD, ALIGN, 2); break;                                                        \
-    case 3: LEANK(PAD, ALIGN, 3); break;                                                        \
-    default: LEANK(PAD, ALIGN, 4); break;                                                       \
-  }
-        if (align_corners) {
-          if (padding_mode == 0) { LEANC(0, true) } else { LEANC(1, true) }
-        } else {
-          if (padding_mode == 0) { LEANC(0, false) } else { LEANC(1, false) }
-        }
-#undef LEANC
-#undef LEANK
-        DRTK_RETURN_IF_LAUNCH_FAILED();
-        return DRTK_OK;
-      }
-    }
     if (align_corners) {
       if (padding_mode == 0) TILED(0, true); else if (padding_mode == 1) TILED(1, true); else TILED(2, true);
     } else {
