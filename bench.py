@@ -125,10 +125,8 @@ TEXTURED_KERNELS = {  # additional kernels of the textured workload: (stage, byt
     "uv_derivative_kernel": ("screen_space_uv_derivative", 16 + 16),   # index 4 + bary 12 read, Jacobian 16 written
     "mipmap_forward_kernel": ("mipmap_grid_sample", 8 + 16 + 12),      # grid 8 + Jacobian 16 read, RGB 12 written (+ texel gathers)
     "mipmap_forward_lean_kernel": ("mipmap_grid_sample", 8 + 16 + 12),
-    "mipmap_forward_batched_kernel": ("mipmap_grid_sample", 8 + 16 + 12),
     "mipmap_backward_tiled2_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),
     "mipmap_backward_lean_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),
-    "mipmap_backward_tiled_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),  # grad_out, grid, Jacobian read; grad_grid written
     "mipmap_backward_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),
     "mipmap_backward_wave_kernel": ("mipmap_grid_sample backward", 12 + 8 + 16 + 8),  # (C > 4; the textured workload's RGB takes the tiled one)
 }

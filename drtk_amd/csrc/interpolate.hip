@@ -419,8 +419,8 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPasses = kTileRows / kWaves;
   constexpr int kSlots = kTableSlots;
-  constexpr int kStride = CN <= 4 ? 4 : 8; // table entries per vertex
-  static_assert(CN >= 1 && CN <= 8, "channels in registers");
+  constexpr int kStride = CN <= 4 ? 4 : CN <= 8 ? 8 : 12; // table entries per vertex
+  static_assert(CN >= 1 && CN <= 12, "channels in registers");
   __shared__ int32_t t_keys[HAS_VERT ? kWaves : 1][HAS_VERT ? kSlots : 1];
   __shared__ TableAcc t_vals[HAS_VERT ? kWaves : 1][HAS_VERT ? kSlots * kStride : 1];
 
@@ -978,13 +978,29 @@ int interpolate_backward_impl(
       (interpolate_backward_kernel<T, HV, HB, CV, CH>), grid, block, 0, stream, grad_out, attrs, \
       vi, index_img, bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad,  \
       debug_flags(), strip)
-#ifndef DRTK_INTERP_SMALL_MAXC
-#define DRTK_INTERP_SMALL_MAXC 4 // the register-scan kernel up to this many channels (5..8 instantiated for A/B)
+  // The register-scan kernel (interpolate_backward_small_kernel: lane = pixel, the 3 C products of a pixel in registers, a
+  // segmented DPP scan, a wave-private vertex table) beats the wide pipeline while 3 C values per lane are few: the wide
+  // pipeline's phase 2 runs one (corner, channel) pair per lane, so a row of 8 channels keeps 24 of 64 lanes busy and costs
+  // what a row of 16 does.  Round 5, 8 x 2048^2, both gradients, ms (register scan / wide): C = 5 0.33 / 0.54, 6 0.38 / 0.59,
+  // 7 0.44 / 0.60, 8 0.50 / 0.55, 9 0.55 / 0.67, 10 0.58 / 0.67, 11 0.67 / 0.68, 12 0.69 / 0.64; double: 6 0.61 / 0.82,
+  // 7 0.65 / 0.82, 8 0.80 / 0.80 (attributes only 0.60 / 0.46), 9 0.88 / 1.11.  The bary gradient alone (no scatter): register
+  // scan up to 12 (C = 11: 0.32 against the generic kernel's 0.46).
+#ifndef DRTK_INTERP_SMALL_MAXC_F32
+#define DRTK_INTERP_SMALL_MAXC_F32 10
 #endif
-  const bool small_c = C <= DRTK_INTERP_SMALL_MAXC;
+#ifndef DRTK_INTERP_SMALL_MAXC_F64
+#define DRTK_INTERP_SMALL_MAXC_F64 7
+#endif
+#ifndef DRTK_INTERP_SMALL_INST
+#define DRTK_INTERP_SMALL_INST 12
+#endif
+  constexpr int kSmallMaxC = sizeof(T) == 4 ? DRTK_INTERP_SMALL_MAXC_F32 : DRTK_INTERP_SMALL_MAXC_F64;
+  static_assert(kSmallMaxC <= DRTK_INTERP_SMALL_INST && DRTK_INTERP_SMALL_INST <= 12, "instantiated channel counts");
+  const bool small_c = C <= kSmallMaxC || (!attr_grad && C <= DRTK_INTERP_SMALL_INST) ||
+      (sizeof(T) == 8 && C % 4 != 0 && C <= 11 && C <= DRTK_INTERP_SMALL_INST); // (double, rows not 32-byte aligned: 9 measured, 10 / 11 by the trend)
   // wide path: the vertex gradient (+ bary gradient) for any C >= 5, float and double (round 5; round 4: C % 4 == 0,
   // C >= 8, float only -- every other shape took the generic kernel, a chain of dependent waits per row)
-  const bool wide = attr_grad && C > DRTK_INTERP_SMALL_MAXC && HW * int64_t(sizeof(T)) < (int64_t(1) << 32) && !DRTK_DBG(debug_flags(), 128);
+  const bool wide = attr_grad && !small_c && HW * int64_t(sizeof(T)) < (int64_t(1) << 32) && !DRTK_DBG(debug_flags(), 128);
   // (the bary gradient alone stays with the generic kernel: no scatter, covered pixels only -- 0.95 of the HBM peak on
   // SURVEY 8d's bytes at the bench coverage; a forward-shaped streaming kernel with four pixels per lane, which cannot
   // skip the background of a partly covered quad, was measured slower: 0.55 vs 0.40 ms at C = 16)
@@ -1044,27 +1060,16 @@ int interpolate_backward_impl(
   DRTK_LAUNCH(                                                                                                              \
       (interpolate_backward_small_kernel<T, HV, HB, CN>), grid, block, 0, stream, grad_out, attrs, vi, index_img, bary_img, \
       V, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, strip)
-#if DRTK_INTERP_SMALL_MAXC > 4
+#define SMALL_CASE(HV, HB, K) \
+  case K:                     \
+    if constexpr (K <= DRTK_INTERP_SMALL_INST) SMALL(HV, HB, (K <= DRTK_INTERP_SMALL_INST ? K : 1)); \
+    break;
 #define SMALL_C(HV, HB)          \
   switch (C) {                   \
-    case 1: SMALL(HV, HB, 1); break; \
-    case 2: SMALL(HV, HB, 2); break; \
-    case 3: SMALL(HV, HB, 3); break; \
-    case 4: SMALL(HV, HB, 4); break; \
-    case 5: SMALL(HV, HB, 5); break; \
-    case 6: SMALL(HV, HB, 6); break; \
-    case 7: SMALL(HV, HB, 7); break; \
-    default: SMALL(HV, HB, 8); break; \
+    SMALL_CASE(HV, HB, 1) SMALL_CASE(HV, HB, 2) SMALL_CASE(HV, HB, 3) SMALL_CASE(HV, HB, 4) SMALL_CASE(HV, HB, 5) SMALL_CASE(HV, HB, 6) \
+    SMALL_CASE(HV, HB, 7) SMALL_CASE(HV, HB, 8) SMALL_CASE(HV, HB, 9) SMALL_CASE(HV, HB, 10) SMALL_CASE(HV, HB, 11) SMALL_CASE(HV, HB, 12) \
+    default: break;              \
   }
-#else
-#define SMALL_C(HV, HB)          \
-  switch (C) {                   \
-    case 1: SMALL(HV, HB, 1); break; \
-    case 2: SMALL(HV, HB, 2); break; \
-    case 3: SMALL(HV, HB, 3); break; \
-    default: SMALL(HV, HB, 4); break; \
-  }
-#endif
     if (attr_grad && bary_grad) {
       SMALL_C(true, true)
     } else if (attr_grad) {
@@ -1073,15 +1078,16 @@ int interpolate_backward_impl(
       SMALL_C(false, true)
     }
 #undef SMALL_C
+#undef SMALL_CASE
 #undef SMALL
-  } else if (attr_grad && bary_grad) {
-    if (small_c) {
+  } else if (attr_grad && bary_grad) { // (the generic kernel: the profiling build's flag 128, shapes beyond the pipelines)
+    if (C <= 4) {
       if (cvec) LAUNCH(true, true, 4, 4); else LAUNCH(true, true, 1, 4);
     } else {
       if (cvec) LAUNCH(true, true, 4, 16); else LAUNCH(true, true, 1, 16);
     }
   } else if (attr_grad) {
-    if (small_c) LAUNCH(true, false, 1, 4); else LAUNCH(true, false, 1, 16);
+    if (C <= 4) LAUNCH(true, false, 1, 4); else LAUNCH(true, false, 1, 16);
   } else {
     if (cvec) LAUNCH(false, true, 4, 16); else LAUNCH(false, true, 1, 16);
   }

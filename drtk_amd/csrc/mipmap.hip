@@ -387,7 +387,7 @@ constexpr int kChBlock = 4; // channels accumulated in registers per sweep over 
 // per-pixel chain quad -> texels -> products -> next tap: 2.01 / 2.09 ms against 0.76 on the textured benchmark.  The
 // group's quads and texels take the kernel from 110 to 258 / 434 registers, and this kernel lives on occupancy.)
 
-// PAD: the padding mode as a compile-time constant (see mipmap_backward_tiled_kernel).
+// PAD: the padding mode as a compile-time constant (see the tile kernels of the backward pass).
 template <typename T, int MODE, int PAD>
 __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grid, GridLayout gl, const T* __restrict__ vt, int64_t count, int C,
@@ -558,7 +558,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // instruction occupies its SIMD for ~2.3 cycles, f64 / conversions / 64-bit adds / DPP 4.2, transcendentals 8, and scalar
 // instructions take issue slots too): SQ_ACTIVE_INST_ANY of mipmap_forward_kernel is 420 M quad-cycles per launch = 1.64 M
 // cycles per SIMD = 0.73 of its 0.76 ms -- the kernel is INSTRUCTION-bound, not latency-bound (which is why keeping K items in
-// flight, mipmap_forward_batched_kernel below, bought nothing: 0.79 vs 0.77 ms).  Per (tap, level) it issues ~170 vector and
+// flight bought nothing: 0.79 vs 0.77 ms, note further down).  Per (tap, level) it issues ~170 vector and
 // ~60 scalar instructions: per-corner validity logic in 87 exec-mask regions, 64-bit address arithmetic per texel load, three
 // dependent operations per product, the backward pass's gradient multipliers.  Here the common case -- every corner of the
 // tap inside its level -- is ONE straight line for the whole wave:
@@ -698,174 +698,9 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_lean_kernel(
   }
 }
 
-// ---- Forward, bilinear: K (tap, level) items of a pixel in flight (round 5) ------------------------------------------
-// mipmap_forward_kernel above walks a pixel's taps one by one, and every (tap, level) is a dependent round trip --
-// geometry -> 2 C texel loads -> products -> next tap: counters show its waves parked on s_waitcnt 58 % of their life at 4
-// waves per SIMD (profiles/r04/mipmap_pmc_sq.txt), 4.7 round trips per wave on the textured configuration.  Here the live
-// (tap, level) pairs of a pixel -- a level whose weight is exactly zero is not one, as above -- form ONE sequence
-// k = 0 .. n * levels - 1 (tap-major, the finer level first: the accumulation order of the kernel above and of the
-// reference), and the wave takes them K at a time: geometry of the K items (lean: two offsets, four weights, the level's
-// weight -- not the 14-field Quad), then the texel loads of all K in one batch, then the products in sequence order.  A
-// batch in which some lane's item touches the border of its level (not all four corners inside: rare) is walked item
-// by item on the general form, recomputed from k -- so nothing of that form is live across the fast path.  (Round 3 had
-// measured "taps in groups of 2 or 4" at 258 / 434 VGPRs and 2.0 ms: the groups carried whole Quads and both forms.)
-#ifndef DRTK_MIP_FWD_BATCH
-#define DRTK_MIP_FWD_BATCH 1
-#endif
-template <typename T, int PAD, int K>
-__global__ __launch_bounds__(kBlock) void mipmap_forward_batched_kernel(
-    LevelTable lv, int mipmaps, const T* __restrict__ grid, GridLayout gl, const T* __restrict__ vt, int64_t count, int C,
-    int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, T* __restrict__ out, int strip) {
-  constexpr int padding = PAD;
-  __shared__ const void* s_ptr[kMaxLevels];
-  __shared__ void* s_grad[kMaxLevels];
-  __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
-  __shared__ long long s_sn[kMaxLevels];
-  __shared__ double s_f[kTapTab * kTapTab];
-  stage_tap_table(s_f);
-  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w, s_sn);
-  const int64_t index = int64_t(tile_index(strip)) * kBlock + threadIdx.x;
-  const bool valid = index < count;
-  const int64_t n = valid ? index / HW : 0;
-  const int64_t pix = valid ? index - n * HW : 0;
-  const bool align_corners = false; // mipmap_grid_sampler_kernel.cu:423
-  Taps<T> t = {};
-  if (valid) t = setup_taps<T>(load_pixel_uv<T>(grid, gl, vt, n, pix, index), s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
-  const int n_lv = mipmaps > 1 ? 2 : 1;
-  const T alpha_1 = valid ? t.a / t.n : T(0);
-  const T alpha_2 = valid ? static_cast<T>((1.0 - t.a) / t.n) : T(0);
-  // live levels of the pixel (s = 0: level d1, weight alpha_2; s = 1: level d1 + 1, weight alpha_1)
-  const bool live0 = valid && alpha_2 != T(0), live1 = valid && n_lv == 2 && alpha_1 != T(0);
-  const int nl = (live0 ? 1 : 0) + (live1 ? 1 : 0);
-  const int m = t.n * nl; // items of this pixel
-  int lv_h[2], lv_w[2];
-  GlobalPtr<const T> lv_base[2];
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    const int d = (s2 == 0 ? live0 : live1) ? t.d1 + s2 : 0;
-    lv_h[s2] = s_h[d], lv_w[s2] = s_w[d];
-    lv_base[s2] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * s_sn[d]);
-  }
-  T* out_px = out + n * C * HW + pix;
-  // item k of the pixel: tap, level slot, position
-  auto item_of = [&](int k, int& s2, T& x, T& y) {
-    const int i = nl == 2 ? k >> 1 : k;
-    s2 = nl == 2 ? (k & 1) : (live0 ? 0 : 1);
-    const double f = tap_f(s_f, i, t.n);
-    x = t.u + static_cast<T>(t.du * f), y = t.v + static_cast<T>(t.dv * f);
-  };
-  int m_wave = m;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m_wave = max(m_wave, __shfl_xor(m_wave, o));
-
-  for (int c0 = 0; c0 < C; c0 += kChBlock) {
-    T acc[kChBlock];
-#pragma unroll
-    for (int cc = 0; cc < kChBlock; ++cc) acc[cc] = T(0);
-    for (int k0 = 0; k0 < m_wave; k0 += K) {
-      // ---- geometry of the batch
-      int o_top[K], o_bot[K];
-      T w_nw[K], w_ne[K], w_sw[K], w_se[K], w_al[K];
-      int64_t pl[K];
-      GlobalPtr<const T> bs[K];
-      bool on[K], border = false;
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        on[j] = k0 + j < m;
-        o_top[j] = o_bot[j] = 0;
-        w_nw[j] = w_ne[j] = w_sw[j] = w_se[j] = w_al[j] = T(0);
-        pl[j] = 0;
-        bs[j] = lv_base[0];
-        if (on[j]) {
-          int s2;
-          T x, y;
-          item_of(k0 + j, s2, x, y);
-          const int h = s2 == 0 ? lv_h[0] : lv_h[1], w = s2 == 0 ? lv_w[0] : lv_w[1];
-          T mx, my;
-          const T ix = source_index(x, w, padding, align_corners, &mx);
-          const T iy = source_index(y, h, padding, align_corners, &my);
-          const int ix_nw = static_cast<int>(floor(ix)), iy_nw = static_cast<int>(floor(iy));
-          const int ix_se = ix_nw + 1, iy_se = iy_nw + 1;
-          w_nw[j] = (ix_se - ix) * (iy_se - iy);
-          w_ne[j] = (ix - ix_nw) * (iy_se - iy);
-          w_sw[j] = (ix_se - ix) * (iy - iy_nw);
-          w_se[j] = (ix - ix_nw) * (iy - iy_nw);
-          w_al[j] = s2 == 0 ? alpha_2 : alpha_1;
-          const bool inside = ix_nw >= 0 && ix_se < w && iy_nw >= 0 && iy_se < h;
-          border = border || !inside;
-          o_top[j] = inside ? iy_nw * w + ix_nw : 0;
-          o_bot[j] = inside ? iy_se * w + ix_nw : 0;
-          pl[j] = int64_t(h) * w;
-          bs[j] = (s2 == 0 ? lv_base[0] : lv_base[1]) + c0 * pl[j];
-        }
-      }
-      if (__ballot(border) == 0) {
-        // ---- every item of the batch is interior: all texel loads first, then the products in sequence order
-        Pair<T> top[K][kChBlock], bot[K][kChBlock];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-#pragma unroll
-          for (int cc = 0; cc < kChBlock; ++cc) {
-            top[j][cc] = bot[j][cc] = Pair<T>{T(0), T(0)};
-            if (c0 + cc < C && on[j]) {
-              top[j][cc] = *(GlobalPtr<const Pair<T>>)(bs[j] + cc * pl[j] + o_top[j]);
-              bot[j][cc] = *(GlobalPtr<const Pair<T>>)(bs[j] + cc * pl[j] + o_bot[j]);
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          if (on[j]) {
-#pragma unroll
-            for (int cc = 0; cc < kChBlock; ++cc) {
-              if (c0 + cc < C) {
-                acc[cc] += top[j][cc].x * w_nw[j] * w_al[j];
-                acc[cc] += top[j][cc].y * w_ne[j] * w_al[j];
-                acc[cc] += bot[j][cc].x * w_sw[j] * w_al[j];
-                acc[cc] += bot[j][cc].y * w_se[j] * w_al[j];
-              }
-            }
-          }
-        }
-      } else {
-        // ---- a border item somewhere in the wave: the batch item by item on the general form
-#pragma unroll 1
-        for (int j = 0; j < K; ++j) {
-          if (k0 + j >= m) continue;
-          int s2;
-          T x, y;
-          item_of(k0 + j, s2, x, y);
-          const int h = s2 == 0 ? lv_h[0] : lv_h[1], w = s2 == 0 ? lv_w[0] : lv_w[1];
-          const int64_t plane = int64_t(h) * w;
-          const GlobalPtr<const T> base = (s2 == 0 ? lv_base[0] : lv_base[1]) + c0 * plane;
-          const T alpha = s2 == 0 ? alpha_2 : alpha_1;
-          const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
-#pragma unroll
-          for (int cc = 0; cc < kChBlock; ++cc) {
-            if (c0 + cc < C) {
-              const GlobalPtr<const T> p = base + cc * plane;
-              T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
-              if (q.o_nw >= 0) v_nw = p[q.o_nw];
-              if (q.o_ne >= 0) v_ne = p[q.o_ne];
-              if (q.o_sw >= 0) v_sw = p[q.o_sw];
-              if (q.o_se >= 0) v_se = p[q.o_se];
-              if (q.o_nw >= 0) acc[cc] += v_nw * q.nw * alpha;
-              if (q.o_ne >= 0) acc[cc] += v_ne * q.ne * alpha;
-              if (q.o_sw >= 0) acc[cc] += v_sw * q.sw * alpha;
-              if (q.o_se >= 0) acc[cc] += v_se * q.se * alpha;
-            }
-          }
-        }
-      }
-    }
-    if (valid) {
-#pragma unroll
-      for (int cc = 0; cc < kChBlock; ++cc) {
-        if (c0 + cc < C) out_px[int64_t(c0 + cc) * HW] = acc[cc];
-      }
-    }
-  }
-}
+// (Round 5 also built the forward with K (tap, level) items of a pixel in flight -- lean per-item state, the texel loads of all
+// K issued together, 108 / 118 / 158 VGPRs at K = 2 / 3 / 4: 0.79 / 0.80 / 0.93 ms against 0.77 for the kernel at the top of this
+// file.  The forward is not a chain of exposed round trips; removed, profiles/NOTES.md R5.2.)
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void mipmap_backward_kernel(
@@ -1047,458 +882,14 @@ constexpr int kWinCells = win_cells_before(kWinLevels);
 // gradient's eight products regrouped into 10 operations per channel with written-out fmas (1.967 vs 1.955 ms).
 // PAD / ALIGN: padding mode and align_corners as compile-time constants (the coordinate pipeline of every tap branches on
 // them: SQ counters of the runtime-parameter version showed 490 scalar and 950 vector instructions per wave).
-template <typename T, int PAD, bool ALIGN>
-// (3 workgroups per CU by registers as by LDS; reflection padding needs ~190: 2)
-__global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : 3)) void mipmap_backward_tiled_kernel(
-    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
-    const T* __restrict__ vt, int H, int W, int C, int tiles_x, int max_aniso,
-    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg) {
-  constexpr int padding = PAD;
-  constexpr bool align_corners = ALIGN;
-  __shared__ double s_f[kTapTab * kTapTab];
-  __shared__ const void* s_ptr[kMaxLevels];
-  __shared__ void* s_grad[kMaxLevels];
-  __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
-  __shared__ long long s_sn[kMaxLevels];
-  __shared__ int s_ref, s_ox[kWinLevels], s_oy[kWinLevels];
-  // windows [level][channel][kWin * kWin], C channels, accumulated in DOUBLE whatever T is: ds_add_f32 retires one lane
-  // every three clocks on MI355X, ds_add_f64 twenty times as many (profiles/micro/lds_atomics.hip) -- the float windows
-  // were this kernel's floor.  Dynamic LDS sized by the launch (C = 3: 72 KB -> 2 workgroups/CU).
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_win_raw[];
-  double* const s_win = reinterpret_cast<double*>(s_win_raw);
-  const int tid = threadIdx.x;
-  const int n = blockIdx.y;
-  const int tile = tile_index(strip);
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileH + tid / kTileW;
-  const bool valid = px < W && py < H;
-  const int64_t HW = int64_t(H) * W;
-  const int64_t index = int64_t(n) * HW + int64_t(py) * W + px;
-  // the pixel's upstream gradient, all channels in one batch of loads (C <= 4 here)
-  T go[4] = {T(0), T(0), T(0), T(0)};
-  if (valid) {
-    const T* gout_px = grad_out + int64_t(n) * C * HW + (int64_t(py) * W + px);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c < C) go[c] = gout_px[int64_t(c) * HW];
-    }
-  }
-  // (uv and Jacobian are requested in the same batch: one memory round trip for everything the pixel reads but texels)
-  PixelUV<T> uv = {};
-  const int64_t pix = int64_t(py) * W + px;
-  if (valid) uv = load_pixel_uv<T>(grid, gl, vt, n, pix, index);
-  // A pixel whose upstream gradient is zero in every channel (the masked background of a render) adds nothing to the
-  // texture and has a zero grid gradient: it skips its tap set-up, and a tile of such pixels -- 44 % of the tiles of the
-  // textured benchmark -- leaves here, before any window is touched.
-  const bool has_go = go[0] != T(0) || go[1] != T(0) || go[2] != T(0) || go[3] != T(0);
-  if (!__syncthreads_or(has_go)) {
-    if (valid) store_grid_grad<T>(grad_grid, ggl, n, pix, T(0), T(0));
-    return;
-  }
-  stage_tap_table(s_f);
-  stage_levels(lv, mipmaps, s_ptr, s_grad, s_h, s_w, s_sn);
-  if (tid == 0) s_ref = kMaxLevels;
-  if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
-  {
-    double2* w2 = reinterpret_cast<double2*>(s_win);
-    const double2 z = {0.0, 0.0};
-    for (int i = tid; i < C * kWinCells / 2; i += kMipBlock) w2[i] = z;
-  }
-  __syncthreads();
+// (mipmap_backward_tiled_kernel, the kernel these notes are about -- square 32 x 32 windows, the general tap loop, five
+// barriers per tile -- was replaced in round 5 by the two kernels below: git history, profiles/NOTES.md R5.2.)
 
-  Taps<T> t = {};
-  if (has_go) t = setup_taps<T>(uv, s_h[0], s_w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
-  const int n_lv = mipmaps > 1 ? 2 : 1;
-  const T alpha_1 = has_go ? t.a / t.n : T(0);
-  const T alpha_2 = has_go ? static_cast<T>((1.0 - t.a) / t.n) : T(0);
-  // A (pixel, level) whose weighted upstream gradient is zero in every channel adds nothing anywhere (every term is
-  // +-0 * finite): the masked background of a silhouette tile, and the second level of a magnified pixel (a == 0).
-  // Such pairs neither place the windows -- a background pixel's uv is (0, 0) on level 0, far from the tile's texels
-  // -- nor run their taps.
-  bool live[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const T alpha = s == 0 ? alpha_2 : alpha_1;
-    live[s] = false;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) live[s] = live[s] || (go[c] * alpha != T(0));
-    live[s] = live[s] && s < n_lv;
-  }
-  {
-    // one LDS atomic per wave, not per lane: same-address LDS atomics are served one lane at a time
-    const int d_min = wave_min_i32(live[0] ? t.d1 : live[1] ? t.d1 + 1 : kMaxLevels);
-    if ((tid & (kWave - 1)) == 0) atomicMin(&s_ref, d_min);
-  }
-  __syncthreads();
-  const int ref = s_ref;
-  auto tap_xy = [&](int i, T& x, T& y) {
-    const double f = tap_f(s_f, i, t.n);
-    x = t.u + static_cast<T>(t.du * f);
-    y = t.v + static_cast<T>(t.dv * f);
-  };
-  // window origins: the taps of a pixel are collinear, so their extreme texels are those of the first and
-  // the last tap.  ANY origin is correct -- a corner is windowed iff its exact cell lies inside, tested below -- so the
-  // origin comes from a short form of the coordinate pipeline: unnormalise, clamp to the level, floor (the exact
-  // north-west texel for zeros / border padding; under reflection padding taps beyond the border miss the window).
-  auto texel_floor = [&](T coord, int size) -> int {
-    T unused;
-    const T c = unnormalize(coord, size, align_corners, &unused);
-    const T lo = padding == 0 ? T(-1) : T(0);
-    return static_cast<int>(floor(fmin(fmax(c, lo), static_cast<T>(size - 1)))); // fmax(NaN, lo) = lo
-  };
-  {
-    int lo_x[kWinLevels], lo_y[kWinLevels];
-#pragma unroll
-    for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX;
-    if (live[0] || live[1]) {
-      for (int e = 0; e < 2; ++e) {
-        T x, y;
-        tap_xy(e == 0 ? 0 : t.n - 1, x, y);
-        for (int s = 0; s < n_lv; ++s) {
-          const int l = t.d1 + s - ref;
-          if (l < kWinLevels && live[s]) {
-            const int ox = texel_floor(x, s_w[t.d1 + s]), oy = texel_floor(y, s_h[t.d1 + s]);
-#pragma unroll
-            for (int k = 0; k < kWinLevels; ++k) {
-              if (k == l) lo_x[k] = min(lo_x[k], ox), lo_y[k] = min(lo_y[k], oy);
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int l = 0; l < kWinLevels; ++l) {
-      const int a = wave_min_i32(lo_x[l]), b = wave_min_i32(lo_y[l]);
-      if ((tid & (kWave - 1)) == 0 && a != INT32_MAX) {
-        atomicMin(&s_ox[l], a);
-        atomicMin(&s_oy[l], b);
-      }
-    }
-  }
-  __syncthreads();
-
-  // (tap, level) pairs that find no window cell in this round: not sent to global memory one corner and channel at a
-  // time -- scattered float atomics of single lanes, 0.72 of this kernel's 2.2 ms on the textured benchmark although
-  // only a few per cent of the taps miss -- but remembered (per level of the pixel: did any tap miss, and where) for a
-  // further round with the windows moved onto them (below, up to DRTK_MIP_ROUNDS rounds).
-  bool miss[2] = {false, false};
-  int miss_x[2] = {INT32_MAX, INT32_MAX}, miss_y[2] = {INT32_MAX, INT32_MAX};
-  uint32_t pending = 0; // bit 2 i + s: tap i on the pixel's level s found no window cell yet (taps >= 16 are never deferred)
-  if (valid) {
-    T acc_x = T(0), acc_y = T(0);
-    // the pixel's two levels: sizes and base pointers once, not per tap
-    int lv_h[2], lv_w[2], lv_plane[2];
-    GlobalPtr<const T> lv_inp[2];
-    GlobalPtr<T> lv_ginp[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int d = live[s] ? t.d1 + s : 0;
-      lv_h[s] = s_h[d], lv_w[s] = s_w[d];
-      lv_plane[s] = lv_h[s] * lv_w[s]; // < 2^31, checked by fill_table()
-      lv_inp[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]);
-      lv_ginp[s] = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * lv_plane[s]);
-    }
-    for (int i = 0; (live[0] || live[1]) && i < t.n && !DRTK_DBG(dbg, 32); ++i) {
-      T x, y;
-      tap_xy(i, x, y);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (!live[s]) continue;
-        const int d = t.d1 + s;
-        const int h = lv_h[s], w = lv_w[s];
-        const int64_t plane = lv_plane[s];
-        const GlobalPtr<const T> inp = lv_inp[s];
-        const T alpha = s == 0 ? alpha_2 : alpha_1;
-        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
-        const int ix_se = q.ix_nw + 1, iy_se = q.iy_nw + 1;
-        // window cell of the north-west corner (the other three are +1 in x / y), or -1 if not windowed
-        const int l = d - ref;
-        int cell = -1;
-        const int side = win_side(l), stride = win_stride(l), chan = win_cells(l);
-        if (l < kWinLevels) {
-          const int wx = q.ix_nw - s_ox[l], wy = q.iy_nw - s_oy[l];
-          if (wx >= 0 && wx < side - 1 && wy >= 0 && wy < side - 1) cell = wy * stride + wx;
-        }
-        T g[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) g[c] = c < C ? go[c] * alpha : T(0);
-        T gix = T(0), giy = T(0);
-        // Interior taps -- all four corners inside the level, i.e. nearly all of them -- take a straight-line path: the
-        // per-corner validity tests of the general form below each cost a divergent branch (the general form compiled to
-        // 234 exec-mask regions), while here a tap is 2C 8-byte texel loads, 4C adds and the grid-gradient products with no
-        // branch but window / fallback.  A channel whose weighted gradient is zero adds +-0 (the general form skips it).
-        if ((q.o_nw | q.o_ne | q.o_sw | q.o_se) >= 0) {
-          Pair<T> top[4], bot[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            top[c] = bot[c] = Pair<T>{T(0), T(0)};
-            if (c < C && !DRTK_DBG(dbg, 2)) {
-              top[c] = *(GlobalPtr<const Pair<T>>)(inp + c * plane + q.o_nw);
-              bot[c] = *(GlobalPtr<const Pair<T>>)(inp + c * plane + q.o_sw);
-            }
-          }
-          if (DRTK_DBG(dbg, 1)) {
-          } else if (cell >= 0) {
-            double* wp = s_win + C * win_cells_before(l) + cell;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              if (c >= C) break;
-              lds_add(wp + c * chan, static_cast<double>(q.nw * g[c]));
-              lds_add(wp + c * chan + 1, static_cast<double>(q.ne * g[c]));
-              lds_add(wp + c * chan + stride, static_cast<double>(q.sw * g[c]));
-              lds_add(wp + c * chan + stride + 1, static_cast<double>(q.se * g[c]));
-            }
-          } else if (i < 16) {
-            miss[s] = true, pending |= 1u << (2 * i + s);
-            miss_x[s] = min(miss_x[s], q.ix_nw), miss_y[s] = min(miss_y[s], q.iy_nw);
-          } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              if (c >= C) break;
-              const GlobalPtr<T> gp = lv_ginp[s] + c * plane;
-              atomic_add_g1(gp + q.o_nw, q.nw * g[c]);
-              atomic_add_g1(gp + q.o_ne, q.ne * g[c]);
-              atomic_add_g1(gp + q.o_sw, q.sw * g[c]);
-              atomic_add_g1(gp + q.o_se, q.se * g[c]);
-            }
-          }
-          const T fy1 = iy_se - q.iy, fy0 = q.iy - q.iy_nw, fx1 = ix_se - q.ix, fx0 = q.ix - q.ix_nw;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c >= C || DRTK_DBG(dbg, 16)) break;
-            const T gOut = g[c];
-            // with a zero upstream gradient every term is +-0 * finite: the texels count as 0
-            const T v_nw = gOut != T(0) ? top[c].x : T(0), v_ne = gOut != T(0) ? top[c].y : T(0);
-            const T v_sw = gOut != T(0) ? bot[c].x : T(0), v_se = gOut != T(0) ? bot[c].y : T(0);
-            gix -= v_nw * fy1 * gOut;
-            giy -= v_nw * fx1 * gOut;
-            gix += v_ne * fy1 * gOut;
-            giy -= v_ne * fx0 * gOut;
-            gix -= v_sw * fy0 * gOut;
-            giy += v_sw * fx1 * gOut;
-            gix += v_se * fy0 * gOut;
-            giy += v_se * fx0 * gOut;
-          }
-        } else {
-        // General form.  One memory round trip per (tap, level): the texels of ALL channels are requested first
-        // row in one 8-byte load when both exist), the texture-gradient adds -- which wait for nothing -- are issued
-        // under them, and the grid gradient consumes the texels last.
-        T v[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c][0] = v[c][1] = v[c][2] = v[c][3] = T(0);
-        if (!DRTK_DBG(dbg, 2)) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c >= C) break;
-            const GlobalPtr<const T> p = inp + c * plane;
-            if (q.o_nw >= 0 && q.o_ne >= 0) {
-              const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_nw);
-              v[c][0] = t2.x, v[c][1] = t2.y;
-            } else {
-              if (q.o_nw >= 0) v[c][0] = p[q.o_nw];
-              if (q.o_ne >= 0) v[c][1] = p[q.o_ne];
-            }
-            if (q.o_sw >= 0 && q.o_se >= 0) {
-              const Pair<T> t2 = *(GlobalPtr<const Pair<T>>)(p + q.o_sw);
-              v[c][2] = t2.x, v[c][3] = t2.y;
-            } else {
-              if (q.o_sw >= 0) v[c][2] = p[q.o_sw];
-              if (q.o_se >= 0) v[c][3] = p[q.o_se];
-            }
-          }
-        }
-        if (!DRTK_DBG(dbg, 1)) {
-          const bool defer = cell < 0 && i < 16 && (q.o_nw & q.o_ne & q.o_sw & q.o_se) != -1; // (all four corners outside the level: nothing to add anywhere)
-          if (defer) {
-            miss[s] = true, pending |= 1u << (2 * i + s);
-            miss_x[s] = min(miss_x[s], q.ix_nw), miss_y[s] = min(miss_y[s], q.iy_nw);
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c >= C) break;
-            if (g[c] == T(0)) continue; // a zero upstream gradient (masked channel) adds nothing
-            if (cell >= 0) {
-              double* wp = s_win + C * win_cells_before(l) + c * chan + cell;
-              if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * g[c]));
-              if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * g[c]));
-              if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * g[c]));
-              if (q.o_se >= 0) lds_add(wp + stride + 1, static_cast<double>(q.se * g[c]));
-            } else if (!defer) {
-              const GlobalPtr<T> gp = lv_ginp[s] + c * plane;
-              if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * g[c]);
-              if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * g[c]);
-              if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * g[c]);
-              if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * g[c]);
-            }
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (c >= C) break;
-          const T gOut = g[c];
-          // with a zero upstream gradient every term below is +-0 * finite: the texels count as 0
-          const T v_nw = gOut != T(0) ? v[c][0] : T(0), v_ne = gOut != T(0) ? v[c][1] : T(0);
-          const T v_sw = gOut != T(0) ? v[c][2] : T(0), v_se = gOut != T(0) ? v[c][3] : T(0);
-          if (q.o_nw >= 0) {
-            gix -= v_nw * (iy_se - q.iy) * gOut;
-            giy -= v_nw * (ix_se - q.ix) * gOut;
-          }
-          if (q.o_ne >= 0) {
-            gix += v_ne * (iy_se - q.iy) * gOut;
-            giy -= v_ne * (q.ix - q.ix_nw) * gOut;
-          }
-          if (q.o_sw >= 0) {
-            gix -= v_sw * (q.iy - q.iy_nw) * gOut;
-            giy += v_sw * (ix_se - q.ix) * gOut;
-          }
-          if (q.o_se >= 0) {
-            gix += v_se * (q.iy - q.iy_nw) * gOut;
-            giy += v_se * (q.ix - q.ix_nw) * gOut;
-          }
-        }
-        } // general form
-        acc_x += q.mx * gix;
-        acc_y += q.my * giy;
-      }
-    }
-    store_grid_grad<T>(grad_grid, ggl, n, pix, acc_x, acc_y);
-  }
-  __syncthreads();
-  // flush the windows: consecutive threads = consecutive texels of a row; cells that stayed 0 cost nothing,
-  // cells outside the level were never written (only in-bounds corners are accumulated).  With `rearm` the cells are
-  // zeroed as they are read: the windows serve a second round.
-  auto flush = [&](int ref_level, bool rearm) {
-    for (int l = 0; l < kWinLevels; ++l) {
-      const int d = ref_level + l;
-      if (d >= mipmaps || s_ox[l] == INT32_MAX || DRTK_DBG(dbg, 4)) continue;
-      const int h = s_h[d], w = s_w[d];
-      const int64_t plane = int64_t(h) * w;
-      const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
-      for (int c = 0; c < C; ++c) {
-        // two cells per lane and step (one 16-byte LDS read); a row of 32 cells = 16 consecutive lanes
-        const int stride = win_stride(l), chan = win_cells(l);
-        double2* win2 = reinterpret_cast<double2*>(s_win + C * win_cells_before(l) + c * chan);
-        for (int i2 = tid; i2 < (chan - kWinPad) / 2; i2 += kMipBlock) { // the pad cells at the end of each row are never written: 0
-          const double2 q = win2[i2];
-          if (rearm && (q.x != 0.0 || q.y != 0.0)) win2[i2] = double2{0.0, 0.0};
-          const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
-          const int i = i2 * 2;
-          const int gx = s_ox[l] + i % stride, gy = s_oy[l] + i / stride;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
-          }
-        }
-      }
-    }
-  };
-  // Does any pixel of the tile have taps the windows did not hold?  (16 % of the tiles of the minified benchmark scenes;
-  // on the textured benchmark the atlas seam -- neighbouring pixels sample opposite ends of the texture -- and the limb,
-  // where eight anisotropic taps spread over more texels than a window is wide.)  `pending` says which.
-#ifndef DRTK_MIP_ROUNDS
-#define DRTK_MIP_ROUNDS 6 // same-box A/B (textured benchmark / kernel_bench at 1 texel per pixel / at 4): 1 round (all misses to
-#endif                    // global memory, rounds 1-2) 2.15 / 4.58 / 11.7 ms; 2: 2.00 / 3.80 / 9.85; 3: 1.95 / 3.41 / 9.10; 4: 1.94 / 3.11 / 8.63; 6: 1.97 / 2.97 / 8.09
-  // ---- further rounds: the windows are moved onto the taps that are still pending and those taps alone are accumulated
-  // (texture gradient only: the grid gradient is complete).  What is still pending after the last round -- a region of
-  // the texture or a level too many -- goes to global memory corner by corner, as all misses did before.
-  int ref_now = ref;
-  for (int round = 1;; ++round) {
-    const bool again = __syncthreads_or(pending != 0) && !DRTK_DBG(dbg, 8);
-    flush(ref_now, again);
-    if (!again) return;
-    const bool last = round >= DRTK_MIP_ROUNDS - 1;
-    __syncthreads(); // everybody has finished its flush (it reads the origins)
-    if (tid == 0) s_ref = kMaxLevels;
-    if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX;
-    __syncthreads();
-    {
-      const int d_min = wave_min_i32(miss[0] ? t.d1 : miss[1] ? t.d1 + 1 : kMaxLevels);
-      if ((tid & (kWave - 1)) == 0) atomicMin(&s_ref, d_min);
-    }
-    __syncthreads();
-    ref_now = s_ref;
-    {
-      int lo_x[kWinLevels], lo_y[kWinLevels];
-#pragma unroll
-      for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int l = t.d1 + s2 - ref_now;
-#pragma unroll
-        for (int k = 0; k < kWinLevels; ++k) {
-          if (miss[s2] && k == l) lo_x[k] = min(lo_x[k], miss_x[s2]), lo_y[k] = min(lo_y[k], miss_y[s2]);
-        }
-      }
-#pragma unroll
-      for (int l = 0; l < kWinLevels; ++l) {
-        const int a = wave_min_i32(lo_x[l]), b = wave_min_i32(lo_y[l]);
-        if ((tid & (kWave - 1)) == 0 && a != INT32_MAX) {
-          atomicMin(&s_ox[l], a);
-          atomicMin(&s_oy[l], b);
-        }
-      }
-    }
-    __syncthreads();
-    miss[0] = miss[1] = false;
-    miss_x[0] = miss_x[1] = miss_y[0] = miss_y[1] = INT32_MAX;
-    if (pending != 0) {
-      uint32_t todo = pending;
-      while (todo) {
-        const int bit = __builtin_ctz(todo);
-        todo &= todo - 1;
-        const int i = bit >> 1, s2 = bit & 1;
-        T x, y;
-        tap_xy(i, x, y);
-        const int d = t.d1 + s2;
-        const int h = s_h[d], w = s_w[d];
-        const int64_t plane = int64_t(h) * w;
-        const T alpha = s2 == 0 ? alpha_2 : alpha_1;
-        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
-        const int l = d - ref_now;
-        int cell = -1;
-        const int side = win_side(l), stride = win_stride(l), chan = win_cells(l);
-        if (l >= 0 && l < kWinLevels) {
-          const int wx = q.ix_nw - s_ox[l], wy = q.iy_nw - s_oy[l];
-          if (wx >= 0 && wx < side - 1 && wy >= 0 && wy < side - 1) cell = wy * stride + wx;
-        }
-        if (cell < 0 && !last) { // stays pending: the next round's windows
-          if (s2 == 0) {
-            miss[0] = true, miss_x[0] = min(miss_x[0], q.ix_nw), miss_y[0] = min(miss_y[0], q.iy_nw);
-          } else {
-            miss[1] = true, miss_x[1] = min(miss_x[1], q.ix_nw), miss_y[1] = min(miss_y[1], q.iy_nw);
-          }
-          continue;
-        }
-        pending &= ~(1u << bit);
-        const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (c >= C) break;
-          const T gc = go[c] * alpha;
-          if (gc == T(0)) continue;
-          if (cell >= 0) {
-            double* wp = s_win + C * win_cells_before(l) + c * chan + cell;
-            if (q.o_nw >= 0) lds_add(wp, static_cast<double>(q.nw * gc));
-            if (q.o_ne >= 0) lds_add(wp + 1, static_cast<double>(q.ne * gc));
-            if (q.o_sw >= 0) lds_add(wp + stride, static_cast<double>(q.sw * gc));
-            if (q.o_se >= 0) lds_add(wp + stride + 1, static_cast<double>(q.se * gc));
-          } else {
-            const GlobalPtr<T> gp = ginp + c * plane;
-            if (q.o_nw >= 0) atomic_add_g1(gp + q.o_nw, q.nw * gc);
-            if (q.o_ne >= 0) atomic_add_g1(gp + q.o_ne, q.ne * gc);
-            if (q.o_sw >= 0) atomic_add_g1(gp + q.o_sw, q.sw * gc);
-            if (q.o_se >= 0) atomic_add_g1(gp + q.o_se, q.se * gc);
-          }
-        }
-      }
-    }
-  }
-}
-
-// ---- round 5: the same tile kernel with a shorter chain per tile -------------------------------------------------------
-// The ablation of round 4 had left 0.75 of this kernel's 1.95 ms outside the tap loop and ~0.95 in the scatter (LDS
-// accumulation, rounds, flush), with the waves parked half of their life at 3 per SIMD.  Changes against
-// mipmap_backward_tiled_kernel above (kept: -DDRTK_MIP_TILED2=0 switches back, for A/B):
+// ---- round 5: the tile kernel with a shorter chain per tile (reflection padding, double; everything else: the lean kernel
+// further down) -----------------------------------------------------------------------------------------------------------
+// The ablation of round 4 had left 0.75 of the tile kernel's 1.95 ms outside the tap loop and ~0.95 in the scatter (LDS
+// accumulation, rounds, flush), with the waves parked half of their life at 3 per SIMD.  Changes against round 4's
+// mipmap_backward_tiled_kernel:
 //   * the level tables, the placement cells and the windows' zero-fill are issued UNDER the loads of the upstream
 //     gradient / uv / Jacobian, in front of the first barrier (the level-0 size that the tap set-up needs comes from the
 //     kernel argument) -- one barrier and one exposed phase less;
@@ -2664,7 +2055,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
 // ---- Backward, bilinear, f32, any C: WAVE-PRIVATE windows (round 4) -------------------------------------------------
 
 // ---- Backward, bilinear, f32, any C: WAVE-PRIVATE windows (round 4) -------------------------------------------------
-// mipmap_backward_tiled_kernel above is bound by its chain of dependent round trips at 3 waves per SIMD: 48 KB of
+// Round 4's tile kernel was bound by its chain of dependent round trips at 3 waves per SIMD: 48 KB of
 // workgroup-shared windows and 157 VGPRs hold the occupancy there, and every phase of a tile (window placement, taps,
 // flush, each further round) is fenced by workgroup barriers -- 0.85 of its 1.95 ms remain with no accumulation at all
 // (profiles/r03/mipmap_pmc_sq.txt).  Here a WAVE owns its 16 x 4 pixels and a window of its own:
@@ -3183,11 +2574,6 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
       static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
 #define LAUNCH(T, MODE)                                                                    \
   if (padding_mode == 0) LAUNCH_P(T, MODE, 0); else if (padding_mode == 1) LAUNCH_P(T, MODE, 1); else LAUNCH_P(T, MODE, 2)
-#define LAUNCH_B(T, PAD)                                                                                       \
-  DRTK_LAUNCH(                                                                                                 \
-      (mipmap_forward_batched_kernel<T, PAD, DRTK_MIP_FWD_BATCH>), grid_dim, dim3(kBlock), 0, s, lv, mipmaps,  \
-      static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), count, (int)C, H * W, max_aniso,    \
-      force_max_aniso != 0, clip_grad != 0, static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
 #ifndef DRTK_MIP_FWD_LEAN
 #define DRTK_MIP_FWD_LEAN 1
 #endif
@@ -3201,15 +2587,12 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
   if (dtype == DRTK_F32 && interpolation_mode == 0 && padding_mode != 2 && N <= kMaxViewsPerLaunch && DRTK_MIP_FWD_LEAN) {
     if (padding_mode == 0) { LAUNCH_LC(0); } else { LAUNCH_LC(1); }
   } else if (dtype == DRTK_F32) {
-    if (interpolation_mode == 0 && DRTK_MIP_FWD_BATCH > 1) {
-      if (padding_mode == 0) LAUNCH_B(float, 0); else if (padding_mode == 1) LAUNCH_B(float, 1); else LAUNCH_B(float, 2);
-    } else if (interpolation_mode == 0) { LAUNCH(float, 0); } else { LAUNCH(float, 2); }
+    if (interpolation_mode == 0) { LAUNCH(float, 0); } else { LAUNCH(float, 2); }
   } else {
     if (interpolation_mode == 0) { LAUNCH(double, 0); } else { LAUNCH(double, 2); }
   }
 #undef LAUNCH_LC
 #undef LAUNCH_L
-#undef LAUNCH_B
 #undef LAUNCH
 #undef LAUNCH_P
   DRTK_RETURN_IF_LAUNCH_FAILED();
@@ -3331,24 +2714,12 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
   }
   if (interpolation_mode == 0 && C <= 4 && N <= 65535 && !DRTK_DBG(debug_flags(), 512)) {
     const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
-#ifndef DRTK_MIP_TILED2
-#define DRTK_MIP_TILED2 1
-#endif
-#if DRTK_MIP_TILED2
 #define TILED(PAD, ALIGN)                                                                                                \
   DRTK_LAUNCH(                                                                                                           \
       (mipmap_backward_tiled2_kernel<T, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
       dim3(kMipBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const T*>(grad_out),              \
       static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
       force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
-#else
-#define TILED(PAD, ALIGN)                                                                                                \
-  DRTK_LAUNCH(                                                                                                           \
-      (mipmap_backward_tiled_kernel<T, PAD, ALIGN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
-      dim3(kMipBlock), sizeof(double) * C * kWinCells, s, lv, mipmaps, static_cast<const T*>(grad_out),              \
-      static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, (int)C, tiles_x, max_aniso, \
-      force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags())
-#endif
     if (align_corners) {
       if (padding_mode == 0) TILED(0, true); else if (padding_mode == 1) TILED(1, true); else TILED(2, true);
     } else {

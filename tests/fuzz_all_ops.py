@@ -28,11 +28,11 @@ def _close(a, ref, what, atol=1e-5, rtol=1e-5):
     assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
 
 
-# channel counts of the wide interpolate-backward path (any C % 4 == 0, C >= 8: chunks of 16 + a tail of 4 / 8 / 12) and
-# their neighbours; drawn instead of the list below with `make_case(seed, wide_channels=True)` / `--wide-channels`.  A
+# channel counts of the wide interpolate-backward path (round 4: any C % 4 == 0, C >= 8; round 5: any C, with the counts up
+# to 8 on the register-scan kernel) and their neighbours; drawn instead of the list below with `make_case(seed, wide_channels=True)` / `--wide-channels`.  A
 # separate list so that the cases of the plain seeds -- among them the harvested regression seeds of
 # test_edge_grad_sign_decisions_at_near_parallel_normals_follow_the_reference -- stay what they were.
-WIDE_CHANNELS = [8, 12, 16, 20, 24, 28, 32, 36, 48, 64, 7, 13, 18, 30]
+WIDE_CHANNELS = [8, 12, 16, 20, 24, 28, 32, 36, 48, 64, 7, 13, 18, 30, 5, 6, 9, 10, 11, 15, 17, 21]
 
 
 def _close_or_f64(a, ref32, ref64_fn, what, **tol):

@@ -793,9 +793,9 @@ def test_randomised_shapes(block):
 
 @pytest.mark.parametrize("block", range(2))
 def test_randomised_shapes_wide_channel_counts(block):
-    """24 seeded cases per block of the same fuzzer with the channel count drawn from 8 ... 64 (multiples of 4 -- the wide
-    interpolate-backward path with its 4 / 8 / 12-channel tails -- and their odd neighbours, which take the generic
-    kernel): all three gradient requests (both, attributes only, barycentrics only) against the oracle."""
+    """24 seeded cases per block of the same fuzzer with the channel count drawn from 5 ... 64 (the wide interpolate-backward
+    pipeline with its tails, partial last groups included, and the register-scan kernel's 5-8): all three gradient requests
+    (both, attributes only, barycentrics only) against the oracle."""
     import fuzz_all_ops as F
 
     for seed in range(900 + 24 * block, 900 + 24 * block + 24):
@@ -806,10 +806,12 @@ def test_randomised_shapes_wide_channel_counts(block):
             raise AssertionError(f"seed {seed}: {F.describe(c)}: {e}") from e
 
 
-@pytest.mark.parametrize("C", [8, 12, 16, 20, 24, 32, 64])
+@pytest.mark.parametrize("C", [5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 19, 20, 24, 32, 37, 64])
 @pytest.mark.parametrize("width", [320, 203])
 def test_interpolate_backward_channel_counts_and_gradient_requests(C, width):
-    """interpolate backward at every chunking of the wide path (16 / 16+4 / 16+8 / 2 x 16 / 4 x 16, a lone 8 or 12) for
+    """interpolate backward at every channel count class of its pipelines -- the register-scan kernel (C <= 8), the wide
+    pipeline's chunkings (a lone 12 or 16, 16+4 / 16+8 / 2 x 16 / 4 x 16) and, since round 5, counts that are not a multiple of
+    four (partial last group: 9-11, 13, 15, 17, 19, 37; one chunk of 12 on element-aligned rows) -- for
     the three gradient requests the reference instantiates (interpolate_kernel.cu:610-639: attributes and barycentrics,
     attributes only, barycentrics only) against the oracle at the 1e-5 bar; the bary gradient's channel order is the
     reference's, so with the attribute gradient left out it is compared at 1e-6 of its magnitude.  Width 320 takes the
