@@ -554,6 +554,9 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
 #ifndef DRTK_INTERP_CH12
 #define DRTK_INTERP_CH12 1
 #endif
+#ifndef DRTK_INTERP_CH12_MAXC
+#define DRTK_INTERP_CH12_MAXC 12
+#endif
 #ifndef DRTK_INTERP_CH8_ANYC
 #define DRTK_INTERP_CH8_ANYC 0 // 9 <= C <= 15, C % 4 != 0: chunks of 8 + a tail (4 waves per SIMD) instead of one chunk (3)
 #endif
@@ -1030,7 +1033,7 @@ int interpolate_backward_impl(
     const bool ch8 = sizeof(T) == 4 && DRTK_INTERP_CH8 && (C <= 8 || (DRTK_INTERP_CH8_ANYC && !cvec && C < 16));
     // 9 <= C <= 12 on element-aligned rows: ONE chunk of 12 (the 16-channel chunk's registers put the kernel at 3 waves per
     // SIMD there: 0.81 against 0.63 ms at C = 12, aligned vs not, same loads)
-    const bool ch12 = sizeof(T) == 4 && DRTK_INTERP_CH12 && !cvec && C > 8 && C <= 12 && bary_grad;
+    const bool ch12 = sizeof(T) == 4 && DRTK_INTERP_CH12 && !cvec && C > 8 && C <= DRTK_INTERP_CH12_MAXC && bary_grad;
 #define WIDE(HB, TB, AC)                                                                                                   \
   do {                                                                                                                     \
     if (ch8)                                                                                                               \

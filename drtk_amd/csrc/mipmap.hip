@@ -38,8 +38,32 @@ extern "C" __attribute__((visibility("default"))) int drtk_amd_debug_read_mip_st
   return 0;
 }
 #define DRTK_MIP_STAT(i, v) do { if (DRTK_DBG(dbg, 64)) atomicAdd(&::drtk_amd::g_mip_stats[i], static_cast<unsigned long long>(v)); } while (0)
+// ... and WHERE the pairs are that end in global memory (flag 64 as well): {view << 24 | tile, thread << 16 | level, x, y} of
+// the pair's north-west texel, the first 2^20 of them (profiles/mipmap_bench.py --leftover-dump)
+namespace drtk_amd {
+constexpr unsigned kMipDumpMax = 1u << 20;
+__device__ unsigned int g_mip_dump_n;
+__device__ uint4 g_mip_dump[kMipDumpMax];
+}
+extern "C" __attribute__((visibility("default"))) int drtk_amd_debug_read_mip_dump(unsigned int* out, unsigned int* n) {
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(drtk_amd::g_mip_dump_n), sizeof(unsigned int)) != hipSuccess) return -3;
+  if (*n > drtk_amd::kMipDumpMax) *n = drtk_amd::kMipDumpMax;
+  if (*n && hipMemcpyFromSymbol(out, HIP_SYMBOL(drtk_amd::g_mip_dump), sizeof(uint4) * *n) != hipSuccess) return -3;
+  const unsigned int z = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(drtk_amd::g_mip_dump_n), &z, sizeof(z)) != hipSuccess) return -3;
+  return 0;
+}
+#define DRTK_MIP_DUMP_IF(flag, a, b, c, d) do { if (DRTK_DBG(dbg, flag)) { const unsigned int k_ = atomicAdd(&::drtk_amd::g_mip_dump_n, 1u); \
+  if (k_ < ::drtk_amd::kMipDumpMax) ::drtk_amd::g_mip_dump[k_] = make_uint4(a, b, c, d); } } while (0)
+#define DRTK_MIP_DUMP(a, b, c, d) DRTK_MIP_DUMP_IF(64, a, b, c, d)
+// flag 1024: a tile's timeline instead -- {view << 24 | tile, further rounds, start, end} in 10 ns ticks (--tile-times)
+#define DRTK_MIP_TILE_T0() const unsigned int tile_t0_ = static_cast<unsigned int>(wall_clock64())
+#define DRTK_MIP_TILE_DONE(rounds) do { if (tid == 0) DRTK_MIP_DUMP_IF(1024, static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), rounds, tile_t0_, static_cast<unsigned int>(wall_clock64())); } while (0)
 #else
 #define DRTK_MIP_STAT(i, v) do { } while (0)
+#define DRTK_MIP_DUMP(a, b, c, d) do { } while (0)
+#define DRTK_MIP_TILE_T0() do { } while (0)
+#define DRTK_MIP_TILE_DONE(rounds) do { } while (0)
 #endif
 
 namespace drtk_amd {
@@ -1468,6 +1492,18 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #ifndef DRTK_MIP_T3_OCC
 #define DRTK_MIP_T3_OCC 4
 #endif
+#ifndef DRTK_MIP_ROUND_BY_TAP
+#define DRTK_MIP_ROUND_BY_TAP 1
+#endif
+#ifndef DRTK_MIP_LEAN_ROUNDS
+#define DRTK_MIP_LEAN_ROUNDS 24
+#endif
+#ifndef DRTK_MIP_LEAN_HOPELESS_PAIRS
+#define DRTK_MIP_LEAN_HOPELESS_PAIRS 24 // a round that catches fewer (tap, level) pairs than this is the tile's last but one
+#endif
+#ifndef DRTK_MIP_LEAN_FLUSH_PAIR
+#define DRTK_MIP_LEAN_FLUSH_PAIR 0
+#endif
 // window accumulators per channel and slot (two slots; one slot of twice the size where a tile has one live level).  1024 =
 // the square windows' memory (48 KB for RGB: 3 tiles per CU); 768 -> 36 KB: 4 tiles; 640 -> 30 KB: 5 tiles = 5 waves per
 // SIMD, which the lean loop's 94-98 VGPRs allow.
@@ -1497,6 +1533,9 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   __shared__ int s_h[kMaxLevels], s_w[kMaxLevels];
   __shared__ long long s_sn[kMaxLevels];
   __shared__ int s_ref, s_npend, s_ox[kWinLevels], s_oy[kWinLevels], s_hx[kWinLevels], s_hy[kWinLevels];
+  // rounds: the lowest pending (tap, level) bit of the tile (two cells, by round parity), and the placement by THAT tap alone
+  __shared__ int s_bit[2], s_refb, s_bx[kWinLevels], s_by[kWinLevels], s_bhx[kWinLevels], s_bhy[kWinLevels];
+  __shared__ unsigned long long s_seed[kWinLevels];
   // first-round placement per ABSOLUTE level (so that the reference level and the origins come out of ONE phase):
   // bounding box of the north-west texels of the tile's taps on level d
   __shared__ int s_lox[kMaxLevels + 1], s_loy[kMaxLevels + 1], s_hix[kMaxLevels + 1], s_hiy[kMaxLevels + 1];
@@ -1505,6 +1544,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   const int tid = threadIdx.x;
   const int n = blockIdx.y;
   const int tile = tile_index(strip);
+  DRTK_MIP_TILE_T0();
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileH + tid / kTileW;
   const bool valid = px < W && py < H;
@@ -1530,7 +1570,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     s_ptr[tid] = lv.ptr[i], s_grad[tid] = lv.grad[i], s_sn[tid] = lv.sn[i], s_h[tid] = lv.h[i], s_w[tid] = lv.w[i];
   }
   if (tid <= kMaxLevels) s_lox[tid] = s_loy[tid] = INT32_MAX, s_hix[tid] = s_hiy[tid] = INT32_MIN;
-  if (tid == 0) s_ref = kMaxLevels;
+  if (tid == 0) s_ref = kMaxLevels, s_bit[0] = s_bit[1] = 32;
   {
     double2* w2 = reinterpret_cast<double2*>(s_win);
     const double2 z = {0.0, 0.0};
@@ -1652,8 +1692,9 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   auto slot_cell = [&](int l, int ix_nw, int iy_nw) -> int {
     if (l < 0 || l >= kWinLevels) return -1;
     const int wx = ix_nw - (l == 0 ? wox[0] : wox[1]), wy = iy_nw - (l == 0 ? woy[0] : woy[1]);
-    const int sx = l == 0 ? wsx[0] : wsx[1], ny = l == 0 ? wny[0] : wny[1];
-    return (static_cast<unsigned>(wx) < (1u << sx) - 1u && static_cast<unsigned>(wy) < static_cast<unsigned>(ny - 1)) ? (wy << sx) + wx : -1;
+    // (rows: those the flush walks -- the bounding box the slot was shaped for, where that is less than the slot)
+    const int sx = l == 0 ? wsx[0] : wsx[1], ny = l == 0 ? win_rows[0] : win_rows[1];
+    return (static_cast<unsigned>(wx) < (1u << sx) - 1u && wy >= 0 && wy < ny - 1) ? (wy << sx) + wx : -1;
   };
   auto slot_stride = [&](int l) -> int { return 1 << (l == 0 ? wsx[0] : wsx[1]); };
   auto slot_chan = [&](int l) -> int { return l == 0 ? wcells[0] : wcells[1]; };  // cells per channel
@@ -1882,8 +1923,9 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
       const int64_t plane = int64_t(h) * w;
       const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C_total + c0) * plane);
       for (int c = 0; c < C; ++c) {
-        // two cells per lane and step (one 16-byte LDS read); a window row = consecutive lanes
         const int stride = 1 << wsx[l], chan = wcells[l];
+#if DRTK_MIP_LEAN_FLUSH_PAIR
+        // two cells per lane and step (one 16-byte LDS read); a window row = consecutive lanes
         double2* win2 = reinterpret_cast<double2*>(s_win + (l == 0 ? 0 : C * wcells[0]) + c * chan);
         for (int i2 = tid; i2 < win_rows[l] * stride / 2; i2 += kMipBlock) { // rows beyond win_rows were never written
           const double2 q = win2[i2];
@@ -1896,6 +1938,21 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
             if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
           }
         }
+#else
+        // ONE cell per lane: the lanes of an atomic instruction are consecutive texels of a row, so a row's adds travel as
+        // one request per 64-byte line -- with two cells per lane (one 16-byte LDS read, round 4) every line was asked for
+        // twice, by the even and by the odd texels' instruction: 10.2 M of the kernel's 16.4 M atomic requests on the
+        // textured benchmark were this flush (TCP_TCC_ATOMIC_WITHOUT_RET_REQ), at what a request costs at the memory side.
+        double* win1 = s_win + (l == 0 ? 0 : C * wcells[0]) + c * chan;
+        for (int i = tid; i < win_rows[l] * stride; i += kMipBlock) { // rows beyond win_rows were never written
+          const double q = win1[i];
+          if (q != 0.0) {
+            if (rearm) win1[i] = 0.0;
+            const int gx = wox[l] + (i & (stride - 1)), gy = woy[l] + (i >> wsx[l]);
+            atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx, static_cast<T>(q));
+          }
+        }
+#endif
       }
     }
   };
@@ -1918,38 +1975,92 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   // Same-box A/B of the threshold (textured benchmark / kernel_bench at 1 and 4 texels per pixel, ms): off 1.565 / 2.755 /
   // 7.74; 32 pairs 1.565 / 2.80 / 7.94; 96 1.56 / 2.98 / 8.23; 256 1.538 / 3.03 / 8.50 -- what the pole tiles save, the
   // tiles of a minified texture lose several times over: the switch stays off.
+  // the lean form of a tap's cell and axis weights on a level of (h, w) texels -- the operations of the first pass's straight
+  // line; returns whether the tap is interior (all four corners inside the level: nearly every pending tap; the others go
+  // through bilinear_quad below)
+  auto lean_tap = [&](T x, T y, int w, int h, int& ix_nw, int& iy_nw, T& wx0, T& wx1, T& wy0, T& wy1) -> bool {
+    const T wm1 = static_cast<T>(w - 1), hm1 = static_cast<T>(h - 1);
+    T ixu, iyu;
+    if (align_corners) {
+      ixu = ((x + 1.f) / 2) * wm1, iyu = ((y + 1.f) / 2) * hm1;
+    } else {
+      ixu = ((x + 1.f) * static_cast<T>(w) - 1) / 2, iyu = ((y + 1.f) * static_cast<T>(h) - 1) / 2;
+    }
+    T ix, iy;
+    if (padding == 1) {
+      ix = fminf(fmaxf(ixu, T(0)), wm1), iy = fminf(fmaxf(iyu, T(0)), hm1);
+    } else {
+      ix = fminf(fmaxf(ixu, T(-4)), T(2e9f)), iy = fminf(fmaxf(iyu, T(-4)), T(2e9f));
+    }
+    const T fx_floor = floor(ix), fy_floor = floor(iy);
+    ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
+    wx1 = (fx_floor + T(1)) - ix, wx0 = ix - fx_floor, wy1 = (fy_floor + T(1)) - iy, wy0 = iy - fy_floor;
+    return ((x == x) & (y == y)) & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(w - 1)) & (static_cast<unsigned>(iy_nw) < static_cast<unsigned>(h - 1));
+  };
+  // how many taps away from one of its taps a pixel can have another one inside the same window (<= 128 cells wide and
+  // high): the taps are equally spaced, 2 / (n + 1) of (du, dv) apart -- on the coarser of the pixel's levels half as many
+  // texels as on the finer.  A filter for the rounds below, not a decision: a tap it wrongly leaves out stays pending.
+  int k_span;
+  {
+    const T step = T(2) / static_cast<T>(t.n + 1);
+    const T sp = fmaxf(fabsf(static_cast<T>(t.du)) * static_cast<T>(s_w[t.d1]), fabsf(static_cast<T>(t.dv)) * static_cast<T>(s_h[t.d1])) * step * T(0.5);
+    k_span = static_cast<int>(fminf(T(16), T(258) / fmaxf(sp, T(1)))) + 1;
+  }
   int ref_now = ref, npend_before = 0;
   for (int round = 1;; ++round) {
+    {
+      const int wb = wave_min_i32(pending ? __builtin_ctz(pending) : 32);
+      if ((tid & (kWave - 1)) == 0 && wb < 32) atomicMin(&s_bit[round & 1], wb);
+    }
     const bool again = __syncthreads_or(pending != 0) && !DRTK_DBG(dbg, 8);
     flush(ref_now, again);
-    if (!again) return;
+    if (!again) {
+      DRTK_MIP_TILE_DONE(round - 1);
+      return;
+    }
     if (tid == 0) DRTK_MIP_STAT(round < 7 ? round : 7, 1);
-    bool last = round >= DRTK_MIP_ROUNDS - 1; // (or hopeless, below)
+    bool last = round >= DRTK_MIP_LEAN_ROUNDS - 1; // (or hopeless, below)
+    const int i_star = s_bit[round & 1] >> 1; // the tile's first pending tap
     __syncthreads(); // everybody has finished its flush (it reads the origins)
-    if (tid == 0) s_ref = kMaxLevels, s_npend = 0;
-    if (tid < kWinLevels) s_ox[tid] = s_oy[tid] = INT32_MAX, s_hx[tid] = s_hy[tid] = INT32_MIN;
-    // where this pixel's pending taps are: bounding box of their north-west texels per level
-    bool miss[2] = {false, false};
+    if (tid == 0) s_ref = s_refb = kMaxLevels, s_npend = 0, s_bit[(round + 1) & 1] = 32;
+    if (tid < kWinLevels) {
+      s_ox[tid] = s_oy[tid] = s_bx[tid] = s_by[tid] = INT32_MAX, s_hx[tid] = s_hy[tid] = s_bhx[tid] = s_bhy[tid] = INT32_MIN;
+      s_seed[tid] = ~0ull;
+    }
+    // where this pixel's pending taps are: bounding box of their north-west texels per level (A: all of them), and
+    // where its tap i_star is, if pending (B)
+    bool miss[2] = {false, false}, star[2] = {false, false};
     int miss_x[2] = {INT32_MAX, INT32_MAX}, miss_y[2] = {INT32_MAX, INT32_MAX}, miss_hx[2] = {INT32_MIN, INT32_MIN}, miss_hy[2] = {INT32_MIN, INT32_MIN};
-    for (uint32_t todo = pending; todo;) {
-      const int bit = __builtin_ctz(todo);
-      todo &= todo - 1;
-      const int i = bit >> 1, s2 = bit & 1;
-      T x, y;
-      tap_xy(i, x, y);
+    int star_x[2] = {0, 0}, star_y[2] = {0, 0};
+    // (the taps of a pixel are collinear and ordered: the extremes of its pending taps on a level are the first and the last)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const uint32_t m = pending & (0x55555555u << s2);
+      if (m == 0) continue;
+      const int i_lo = __builtin_ctz(m) >> 1, i_hi = (31 - __builtin_clz(m)) >> 1;
+      const bool star_pending = ((m >> (2 * i_star + s2)) & 1u) != 0;
       const int d = t.d1 + s2;
-      const Quad<T> q = bilinear_quad<T>(x, y, s_h[d], s_w[d], padding, align_corners);
-      if (s2 == 0) {
-        miss[0] = true, miss_x[0] = min(miss_x[0], q.ix_nw), miss_y[0] = min(miss_y[0], q.iy_nw);
-        miss_hx[0] = max(miss_hx[0], q.ix_nw), miss_hy[0] = max(miss_hy[0], q.iy_nw);
-      } else {
-        miss[1] = true, miss_x[1] = min(miss_x[1], q.ix_nw), miss_y[1] = min(miss_y[1], q.iy_nw);
-        miss_hx[1] = max(miss_hx[1], q.ix_nw), miss_hy[1] = max(miss_hy[1], q.iy_nw);
+      const int w = s_w[d], h = s_h[d];
+      miss[s2] = true;
+      for (int e = 0; e < 3; ++e) {
+        const int i = e == 0 ? i_lo : e == 1 ? i_hi : i_star;
+        if ((e == 1 && i_hi == i_lo) || (e == 2 && (!star_pending || i_star == i_lo || i_star == i_hi))) continue;
+        T x, y;
+        tap_xy(i, x, y);
+        int qx, qy; // (of a tap on the border of its level: its clamped position -- any origin is correct)
+        T u0, u1, u2, u3;
+        lean_tap(x, y, w, h, qx, qy, u0, u1, u2, u3);
+        if (e < 2) {
+          miss_x[s2] = min(miss_x[s2], qx), miss_y[s2] = min(miss_y[s2], qy);
+          miss_hx[s2] = max(miss_hx[s2], qx), miss_hy[s2] = max(miss_hy[s2], qy);
+        }
+        if (i == i_star) star[s2] = true, star_x[s2] = qx, star_y[s2] = qy;
       }
     }
     __syncthreads();
     {
       const int d_min = wave_min_i32(miss[0] ? t.d1 : miss[1] ? t.d1 + 1 : kMaxLevels);
+      const int d_minb = wave_min_i32(star[0] ? t.d1 : star[1] ? t.d1 + 1 : kMaxLevels);
       // the tile's pending (tap, level) pairs: a wave's count from five ballots over the bits of its lanes' counts (<= 32)
       const int pc = __popc(pending);
       int wave_pc = 0;
@@ -1957,31 +2068,38 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
       for (int b = 0; b < 6; ++b) wave_pc += __popcll(__ballot((pc >> b) & 1)) << b;
       if ((tid & (kWave - 1)) == 0) {
         atomicMin(&s_ref, d_min);
+        atomicMin(&s_refb, d_minb);
         atomicAdd(&s_npend, wave_pc);
       }
     }
     __syncthreads();
-    ref_now = s_ref;
+    const int ref_a = s_ref, ref_b = s_refb;
     {
       // HOPELESS: the round before this one caught fewer than kHopelessPairs pairs -- scattered taps; this round is the last
       const int npend = s_npend;
-      const bool hopeless = DRTK_MIP_HOPELESS && round >= 2 && npend_before - npend < DRTK_MIP_HOPELESS_PAIRS;
+      const bool hopeless = DRTK_MIP_LEAN_HOPELESS_PAIRS > 0 && round >= 2 && npend_before - npend < DRTK_MIP_LEAN_HOPELESS_PAIRS;
       if (tid == 0 && hopeless) DRTK_MIP_STAT(11, 1);
       npend_before = npend;
       last = last || hopeless;
     }
     {
       int lo_x[kWinLevels], lo_y[kWinLevels], hi_x[kWinLevels], hi_y[kWinLevels];
+      int b_x[kWinLevels], b_y[kWinLevels], b_hx[kWinLevels], b_hy[kWinLevels];
+      unsigned long long seed[kWinLevels];
 #pragma unroll
-      for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = INT32_MAX, hi_x[l] = hi_y[l] = INT32_MIN;
+      for (int l = 0; l < kWinLevels; ++l) lo_x[l] = lo_y[l] = b_x[l] = b_y[l] = INT32_MAX, hi_x[l] = hi_y[l] = b_hx[l] = b_hy[l] = INT32_MIN, seed[l] = ~0ull;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int l = t.d1 + s2 - ref_now;
+        const int la = t.d1 + s2 - ref_a, lb = t.d1 + s2 - ref_b;
 #pragma unroll
         for (int k = 0; k < kWinLevels; ++k) {
-          if (miss[s2] && k == l) {
+          if (miss[s2] && k == la) {
             lo_x[k] = min(lo_x[k], miss_x[s2]), lo_y[k] = min(lo_y[k], miss_y[s2]);
             hi_x[k] = max(hi_x[k], miss_hx[s2]), hi_y[k] = max(hi_y[k], miss_hy[s2]);
+          }
+          if (star[s2] && k == lb) {
+            b_x[k] = b_hx[k] = star_x[s2], b_y[k] = b_hy[k] = star_y[s2];
+            seed[k] = static_cast<unsigned long long>(static_cast<unsigned>(star_y[s2] + 1)) << 32 | static_cast<unsigned>(star_x[s2] + 1);
           }
         }
       }
@@ -1995,9 +2113,23 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
           atomicMax(&s_hx[l], g);
           atomicMax(&s_hy[l], e);
         }
+        if (__ballot(b_x[l] != INT32_MAX) != 0) { // (wave-uniform)
+          const int ba = wave_min_i32(b_x[l]), bb = wave_min_i32(b_y[l]);
+          const int bg = wave_max_i32(b_hx[l]), be = wave_max_i32(b_hy[l]);
+          if ((tid & (kWave - 1)) == 0) {
+            atomicMin(&s_bx[l], ba);
+            atomicMin(&s_by[l], bb);
+            atomicMax(&s_bhx[l], bg);
+            atomicMax(&s_bhy[l], be);
+          }
+          // the seed: the topmost (then leftmost) of the candidates -- a window that starts on its row and is centred on its
+          // column holds at least this tap, whatever the shape of the rest
+          if (b_y[l] == bb && b_x[l] != INT32_MAX) atomicMin(&s_seed[l], seed[l]);
+        }
       }
     }
     __syncthreads();
+    bool fits;
     {
       int lox[kWinLevels], loy[kWinLevels], hix[kWinLevels], hiy[kWinLevels];
 #pragma unroll
@@ -2005,11 +2137,61 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
         lox[l] = __builtin_amdgcn_readfirstlane(s_ox[l]), loy[l] = __builtin_amdgcn_readfirstlane(s_oy[l]);
         hix[l] = __builtin_amdgcn_readfirstlane(s_hx[l]), hiy[l] = __builtin_amdgcn_readfirstlane(s_hy[l]);
       }
+      // A: do ALL pending taps of the two finest pending levels fit the slots?  Then the windows take them (the usual case:
+      // a tile whose taps overflowed the first windows a little).  Otherwise B: the windows go onto ONE tap of the tile's
+      // pixels, the first that is pending anywhere (and its two finest levels).  The pixels of a tile are neighbours, so their
+      // taps number i are too, however far the taps of one pixel lie apart -- the limb of the textured benchmark: 600 tiles
+      // whose pixels spread eight taps on two levels over thousands of texels; the bounding box of everything pending
+      // is then the whole texture, a window in its corner holds nothing, and 0.8 M pairs x 12 scattered atomics (0.2 ms
+      // of 1.55) went to global memory after five empty rounds.
+      fits = true;
+      {
+        const bool two = lox[1] != INT32_MAX;
+#pragma unroll
+        for (int l = 0; l < kWinLevels; ++l) {
+          if (lox[l] == INT32_MAX) continue;
+          const int cells = two ? kWinSlotCells : kWinLevels * kWinSlotCells;
+          const long long need_w = static_cast<long long>(hix[l]) - lox[l] + 2, need_h = static_cast<long long>(hiy[l]) - loy[l] + 2;
+          const int sx = need_w <= 16 ? 4 : need_w <= 32 ? 5 : need_w <= 64 ? 6 : 7;
+          fits = fits && need_w <= 128 && need_h <= (cells >> sx);
+        }
+      }
+      ref_now = ref_a;
+      if (!fits && DRTK_MIP_ROUND_BY_TAP) {
+        ref_now = ref_b;
+#pragma unroll
+        for (int l = 0; l < kWinLevels; ++l) {
+          lox[l] = __builtin_amdgcn_readfirstlane(s_bx[l]), loy[l] = __builtin_amdgcn_readfirstlane(s_by[l]);
+          hix[l] = __builtin_amdgcn_readfirstlane(s_bhx[l]), hiy[l] = __builtin_amdgcn_readfirstlane(s_bhy[l]);
+        }
+      }
       // a window whose slot has no pending tap on level ref_now must still exist as slot 0: ref_now IS a level with pending taps
-      shape_slots(lox, loy, hix, hiy, true);
+      shape_slots(lox, loy, hix, hiy, false); // (rows: the bounding box's -- slot_cell() admits no others -- so the flush walks no more)
+      if (!fits && DRTK_MIP_ROUND_BY_TAP) {
+#pragma unroll
+        for (int l = 0; l < kWinLevels; ++l) {
+          if (lox[l] == INT32_MAX) continue;
+          const int width = 1 << wsx[l];
+          if (static_cast<long long>(hix[l]) - lox[l] + 2 > width) { // wider than the slot: centred on the seed's column
+            const unsigned long long sd = s_seed[l];
+            const int seed_x = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(sd))) - 1;
+            wox[l] = max(lox[l], seed_x - (width / 2 - 1));
+          }
+        }
+      }
     }
     if (pending != 0) {
       uint32_t todo = pending;
+      if (!fits && DRTK_MIP_ROUND_BY_TAP && !last) {
+        // windows placed by tap i_star: a pixel whose own tap i_star is inside them walks its taps within k_span of it only
+        bool star_in = false;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) star_in = star_in || (star[s2] && slot_cell(t.d1 + s2 - ref_now, star_x[s2], star_y[s2]) >= 0);
+        if (star_in) {
+          const int b_lo = 2 * max(i_star - k_span, 0), b_hi = 2 * min(i_star + k_span, 15) + 1;
+          todo &= (0xFFFFFFFFu << b_lo) & (0xFFFFFFFFu >> (31 - b_hi));
+        }
+      }
       while (todo) {
         const int bit = __builtin_ctz(todo);
         todo &= todo - 1;
@@ -2020,14 +2202,54 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
         const int h = s_h[d], w = s_w[d];
         const int64_t plane = int64_t(h) * w;
         const T alpha = s2 == 0 ? alpha_2 : alpha_1;
-        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
         const int l = d - ref_now;
+        {
+          int ix_nw, iy_nw;
+          T wx0, wx1, wy0, wy1;
+          if (lean_tap(x, y, w, h, ix_nw, iy_nw, wx0, wx1, wy0, wy1)) {
+            const int cell = slot_cell(l, ix_nw, iy_nw);
+            if (cell < 0 && !last) continue; // stays pending: the next round's windows
+            pending &= ~(1u << bit);
+            if (cell < 0) DRTK_MIP_STAT(10, 1);
+            if (cell < 0) DRTK_MIP_STAT(12 + min(max(d - ref, 0), 3), 1);
+            if (cell < 0) DRTK_MIP_DUMP(static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), static_cast<unsigned>(tid) << 16 | static_cast<unsigned>(d), static_cast<unsigned>(ix_nw), static_cast<unsigned>(iy_nw));
+            if (cell < 0 && DRTK_DBG(dbg, 256)) continue; // (ablation: what the left-over global atomics cost)
+            const T q_nw = wx1 * wy1, q_ne = wx0 * wy1, q_sw = wx1 * wy0, q_se = wx0 * wy0;
+            if (cell >= 0) {
+              double* wp = s_win + slot_base(l) + cell;
+              const int stride = slot_stride(l), chan = slot_chan(l);
+#pragma unroll
+              for (int c = 0; c < CN; ++c) {
+                const T gc = go[c] * alpha;
+                lds_add(wp + c * chan, static_cast<double>(q_nw * gc));
+                lds_add(wp + c * chan + 1, static_cast<double>(q_ne * gc));
+                lds_add(wp + c * chan + stride, static_cast<double>(q_sw * gc));
+                lds_add(wp + c * chan + stride + 1, static_cast<double>(q_se * gc));
+              }
+            } else {
+              const GlobalPtr<T> gp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C_total + c0) * plane) + (int64_t(iy_nw) * w + ix_nw);
+#pragma unroll
+              for (int c = 0; c < CN; ++c) {
+                const T gc = go[c] * alpha;
+                if (gc == T(0)) continue;
+                atomic_add_g1(gp + c * plane, q_nw * gc);
+                atomic_add_g1(gp + c * plane + 1, q_ne * gc);
+                atomic_add_g1(gp + c * plane + w, q_sw * gc);
+                atomic_add_g1(gp + c * plane + w + 1, q_se * gc);
+              }
+            }
+            continue;
+          }
+        }
+        const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners); // (a deferred tap on the border of its level: rare)
         const int cell = slot_cell(l, q.ix_nw, q.iy_nw);
         const int stride = slot_stride(l), chan = slot_chan(l);
         if (cell < 0 && !last) continue; // stays pending: the next round's windows
         pending &= ~(1u << bit);
         if (cell < 0) DRTK_MIP_STAT(10, 1);
         if (cell < 0) DRTK_MIP_STAT(12 + min(max(d - ref, 0), 3), 1);
+        if (cell < 0) DRTK_MIP_DUMP(static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), static_cast<unsigned>(tid) << 16 | static_cast<unsigned>(d), static_cast<unsigned>(q.ix_nw), static_cast<unsigned>(q.iy_nw));
+        if (cell < 0 && DRTK_DBG(dbg, 256)) continue; // (ablation: what the left-over global atomics cost)
         const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C_total + c0) * plane);
 #pragma unroll
         for (int c = 0; c < CN; ++c) {

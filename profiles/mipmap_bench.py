@@ -25,6 +25,8 @@ ap.add_argument("--flags", default="0")
 ap.add_argument("--lib", default="")
 ap.add_argument("--stats", action="store_true")
 ap.add_argument("--rounds-stats", action="store_true", help="ablation build: how many tiles of the tiled backward enter each further round, how many taps stay pending")
+ap.add_argument("--leftover-dump", default="", help="ablation build: save {view, tile, thread, level, x, y} of the (tap, level) pairs that end in global memory after the last round (npz)")
+ap.add_argument("--tile-times", default="", help="ablation build: save {view, tile, further rounds, start, end (10 ns ticks)} of every tile of the lean backward that had upstream gradient (npz)")
 ap.add_argument("--dump", default="", help="save the backward's outputs (compare two libraries with --compare A B)")
 ap.add_argument("--compare", nargs=2, default=None)
 a = ap.parse_args()
@@ -33,7 +35,7 @@ if a.compare:
     worst = max((x.double() - y.double()).abs().max().item() / y.abs().max().item() for x, y in zip(A, B))
     print(f"compare {a.compare[0]} {a.compare[1]}: worst difference / max magnitude = {worst:.2e}")
     sys.exit(0 if worst < 2e-5 else 1)
-ABLATE = a.flags != "0" or a.rounds_stats
+ABLATE = a.flags != "0" or a.rounds_stats or bool(a.leftover_dump) or bool(a.tile_times)
 if a.lib:
     capi.use_profiling_library(os.path.abspath(a.lib))
 elif ABLATE:
@@ -143,3 +145,40 @@ if a.dump:
     gl, gg = capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0)
     fw = capi.mipmap_grid_sampler_2d(tex, grid, jac, 8, 1, 0)
     th.save([t[:1].cpu() for t in gl[:3]] + [gg[:1].cpu(), fw[:1].cpu()], a.dump)
+
+if a.leftover_dump:
+    import ctypes
+
+    import numpy as np
+
+    L = capi.lib()
+    buf = (ctypes.c_uint * (4 << 20))()
+    cnt = ctypes.c_uint(0)
+    L.drtk_amd_debug_read_mip_dump(buf, ctypes.byref(cnt))  # clear
+    L.drtk_amd_debug_set_flags(64)
+    capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0)
+    th.cuda.synchronize()
+    L.drtk_amd_debug_read_mip_dump(buf, ctypes.byref(cnt))
+    L.drtk_amd_debug_set_flags(0)
+    d = np.frombuffer(buf, dtype=np.uint32, count=4 * cnt.value).reshape(-1, 4).copy()
+    np.savez_compressed(a.leftover_dump, view=d[:, 0] >> 24, tile=d[:, 0] & 0xFFFFFF, thread=d[:, 1] >> 16, level=d[:, 1] & 0xFFFF,
+                        x=d[:, 2].astype(np.int32), y=d[:, 3].astype(np.int32), H=a.res, W=a.res)
+    print(f"leftover dump: {cnt.value} pairs -> {a.leftover_dump}")
+
+if a.tile_times:
+    import ctypes
+
+    import numpy as np
+
+    L = capi.lib()
+    buf = (ctypes.c_uint * (4 << 20))()
+    cnt = ctypes.c_uint(0)
+    L.drtk_amd_debug_read_mip_dump(buf, ctypes.byref(cnt))  # clear
+    L.drtk_amd_debug_set_flags(1024)
+    capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0)
+    th.cuda.synchronize()
+    L.drtk_amd_debug_read_mip_dump(buf, ctypes.byref(cnt))
+    L.drtk_amd_debug_set_flags(0)
+    d = np.frombuffer(buf, dtype=np.uint32, count=4 * cnt.value).reshape(-1, 4).copy()
+    np.savez_compressed(a.tile_times, view=d[:, 0] >> 24, tile=d[:, 0] & 0xFFFFFF, rounds=d[:, 1], t0=d[:, 2], t1=d[:, 3], H=a.res, W=a.res)
+    print(f"tile times: {cnt.value} tiles -> {a.tile_times}")
