@@ -57,12 +57,17 @@ extern "C" __attribute__((visibility("default"))) int drtk_amd_debug_read_mip_du
   if (k_ < ::drtk_amd::kMipDumpMax) ::drtk_amd::g_mip_dump[k_] = make_uint4(a, b, c, d); } } while (0)
 #define DRTK_MIP_DUMP(a, b, c, d) DRTK_MIP_DUMP_IF(64, a, b, c, d)
 // flag 1024: a tile's timeline instead -- {view << 24 | tile, further rounds, start, end} in 10 ns ticks (--tile-times)
-#define DRTK_MIP_TILE_T0() const unsigned int tile_t0_ = static_cast<unsigned int>(wall_clock64())
-#define DRTK_MIP_TILE_DONE(rounds) do { if (tid == 0) DRTK_MIP_DUMP_IF(1024, static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), rounds, tile_t0_, static_cast<unsigned int>(wall_clock64())); } while (0)
+#define DRTK_MIP_TILE_T0() const unsigned int tile_t0_ = static_cast<unsigned int>(wall_clock64()); unsigned int tile_ph_[3] = {0u, 0u, 0u}
+#define DRTK_MIP_TILE_PHASE(k) tile_ph_[k] = static_cast<unsigned int>(wall_clock64()) - tile_t0_
+// flag 2048: the phases of a tile instead -- {.., rounds | inputs there << 16, windows placed | taps done << 16, end}, ticks since the start
+#define DRTK_MIP_TILE_DONE(rounds) do { if (tid == 0) { \
+  DRTK_MIP_DUMP_IF(1024, static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), rounds, tile_t0_, static_cast<unsigned int>(wall_clock64())); \
+  DRTK_MIP_DUMP_IF(2048, static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), static_cast<unsigned>(rounds) | tile_ph_[0] << 16, tile_ph_[1] | tile_ph_[2] << 16, static_cast<unsigned int>(wall_clock64()) - tile_t0_); } } while (0)
 #else
 #define DRTK_MIP_STAT(i, v) do { } while (0)
 #define DRTK_MIP_DUMP(a, b, c, d) do { } while (0)
 #define DRTK_MIP_TILE_T0() do { } while (0)
+#define DRTK_MIP_TILE_PHASE(k) do { } while (0)
 #define DRTK_MIP_TILE_DONE(rounds) do { } while (0)
 #endif
 
@@ -1309,18 +1314,16 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
       const int64_t plane = int64_t(h) * w;
       const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + int64_t(n) * C * plane);
       for (int c = 0; c < C; ++c) {
-        // two cells per lane and step (one 16-byte LDS read); a window row = consecutive lanes
+        // ONE cell per lane: an atomic instruction's lanes are consecutive texels of a row, one request per 64-byte line
+        // (two cells per lane asked for every line twice -- see mipmap_backward_lean_kernel's flush)
         const int stride = 1 << wsx[l], chan = wcells[l];
-        double2* win2 = reinterpret_cast<double2*>(s_win + (l == 0 ? 0 : C * wcells[0]) + c * chan);
-        for (int i2 = tid; i2 < win_rows[l] * stride / 2; i2 += kMipBlock) { // rows beyond win_rows were never written
-          const double2 q = win2[i2];
-          if (rearm && (q.x != 0.0 || q.y != 0.0)) win2[i2] = double2{0.0, 0.0};
-          const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
-          const int i = i2 * 2;
-          const int gx = wox[l] + (i & (stride - 1)), gy = woy[l] + (i >> wsx[l]);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
+        double* win1 = s_win + (l == 0 ? 0 : C * wcells[0]) + c * chan;
+        for (int i = tid; i < win_rows[l] * stride; i += kMipBlock) { // rows beyond win_rows were never written
+          const double q = win1[i];
+          if (q != 0.0) {
+            if (rearm) win1[i] = 0.0;
+            const int gx = wox[l] + (i & (stride - 1)), gy = woy[l] + (i >> wsx[l]);
+            atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx, static_cast<T>(q));
           }
         }
       }
@@ -1583,6 +1586,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     if (valid && c0 == 0) store_grid_grad<T>(grad_grid, ggl, n, pix, T(0), T(0)); // (a later channel block adds nothing)
     return;
   }
+  DRTK_MIP_TILE_PHASE(0);
 
   Taps<T> t = {};
   if (has_go) t = setup_taps<T>(uv, lv.h[0], lv.w[0], mipmaps, max_aniso, force_max_aniso, clip_grad);
@@ -1653,6 +1657,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     if ((tid & (kWave - 1)) == 0 && d_lo < kMaxLevels) atomicMin(&s_ref, d_lo);
   }
   __syncthreads();
+  DRTK_MIP_TILE_PHASE(1);
   const int ref = s_ref;
   // ---- the two window SLOTS (round 5: shaped, not square).  Slot l holds level ref + l.  The windows' memory is
   // kWinLevels x kWinSlotCells accumulators per channel; a tile with no live tap on level ref + 1 -- every tile of a magnified
@@ -1911,6 +1916,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   }
   if (tid == 0) DRTK_MIP_STAT(0, 1);
   __syncthreads();
+  DRTK_MIP_TILE_PHASE(2);
   // flush the windows: consecutive threads = consecutive texels of a row; cells that stayed 0 cost nothing,
   // cells outside the level were never written (only in-bounds corners are accumulated).  With `rearm` the cells are
   // zeroed as they are read: the windows serve a second round.

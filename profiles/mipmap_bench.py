@@ -26,6 +26,7 @@ ap.add_argument("--lib", default="")
 ap.add_argument("--stats", action="store_true")
 ap.add_argument("--rounds-stats", action="store_true", help="ablation build: how many tiles of the tiled backward enter each further round, how many taps stay pending")
 ap.add_argument("--leftover-dump", default="", help="ablation build: save {view, tile, thread, level, x, y} of the (tap, level) pairs that end in global memory after the last round (npz)")
+ap.add_argument("--tile-phases", action="store_true", help="with --tile-times: the phases of a tile (inputs there / windows placed / taps done / end) instead of its start and end")
 ap.add_argument("--tile-times", default="", help="ablation build: save {view, tile, further rounds, start, end (10 ns ticks)} of every tile of the lean backward that had upstream gradient (npz)")
 ap.add_argument("--dump", default="", help="save the backward's outputs (compare two libraries with --compare A B)")
 ap.add_argument("--compare", nargs=2, default=None)
@@ -174,7 +175,7 @@ if a.tile_times:
     buf = (ctypes.c_uint * (4 << 20))()
     cnt = ctypes.c_uint(0)
     L.drtk_amd_debug_read_mip_dump(buf, ctypes.byref(cnt))  # clear
-    L.drtk_amd_debug_set_flags(1024)
+    L.drtk_amd_debug_set_flags(2048 if a.tile_phases else 1024)
     capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0)
     th.cuda.synchronize()
     L.drtk_amd_debug_read_mip_dump(buf, ctypes.byref(cnt))
