@@ -1498,11 +1498,14 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #ifndef DRTK_MIP_ROUND_BY_TAP
 #define DRTK_MIP_ROUND_BY_TAP 1
 #endif
+// Same-box A/B (textured benchmark incl. the pyramid's zero-fill / kernel_bench at 1 and 4 texels per pixel, ms): placement by
+// everything pending, 6 rounds (the first half of round 5) 1.53 / 2.30 / 5.90; by tap: 24 rounds, hopeless below 24 pairs
+// 1.44 / 2.18 / 4.48; 32 rounds, 16 pairs 1.44 / 2.16 / 4.35; 24 rounds, no cut-off 1.70 / 2.43 / 4.71; 12 rounds 1.58 / 2.32 / 4.59
 #ifndef DRTK_MIP_LEAN_ROUNDS
-#define DRTK_MIP_LEAN_ROUNDS 24
+#define DRTK_MIP_LEAN_ROUNDS 32
 #endif
 #ifndef DRTK_MIP_LEAN_HOPELESS_PAIRS
-#define DRTK_MIP_LEAN_HOPELESS_PAIRS 24 // a round that catches fewer (tap, level) pairs than this is the tile's last but one
+#define DRTK_MIP_LEAN_HOPELESS_PAIRS 16 // a round that catches fewer (tap, level) pairs than this is the tile's last but one
 #endif
 #ifndef DRTK_MIP_LEAN_FLUSH_PAIR
 #define DRTK_MIP_LEAN_FLUSH_PAIR 0
@@ -1963,24 +1966,20 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     }
   };
   // Does any pixel of the tile have taps the windows did not hold?  (16 % of the tiles of the minified benchmark scenes;
-  // on the textured benchmark the atlas seam -- neighbouring pixels sample opposite ends of the texture -- and the limb,
-  // where eight anisotropic taps spread over more texels than a window is wide.)  `pending` says which.
-#ifndef DRTK_MIP_ROUNDS
-#define DRTK_MIP_ROUNDS 6 // same-box A/B (textured benchmark / kernel_bench at 1 texel per pixel / at 4): 1 round (all misses to
-#endif                    // global memory, rounds 1-2) 2.15 / 4.58 / 11.7 ms; 2: 2.00 / 3.80 / 9.85; 3: 1.95 / 3.41 / 9.10; 4: 1.94 / 3.11 / 8.63; 6: 1.97 / 2.97 / 8.09
-  // ---- further rounds: the windows are moved onto the taps that are still pending and those taps alone are accumulated
-  // (texture gradient only: the grid gradient is complete).  What is still pending after the last round -- a region of
-  // the texture or a level too many -- goes to global memory corner by corner, as all misses did before.
-  // HOPELESS tiles (round 5): where a round catches only a handful of (tap, level) pairs, the taps are scattered beyond what
-  // windows can hold -- the poles of an atlas, where neighbouring pixels sample texels thousands of columns apart: on the
-  // textured benchmark 1.7 % of the tiles ran all five further rounds and still sent nearly all of their taps to global
-  // memory afterwards (profiles/mipmap_bench.py --rounds-stats), 39 % of all tile-rounds.  The round after such a round is
-  // the tile's last (what is pending goes to global memory at once).  The test is on PAIRS caught, not on a share: a tile
-  // of a minified texture needs many windows and every one of its rounds catches hundreds of pairs -- cutting those short
-  // (a first version tested the share of pixels that still had pending taps) cost 11 % on the minified scenes.
-  // Same-box A/B of the threshold (textured benchmark / kernel_bench at 1 and 4 texels per pixel, ms): off 1.565 / 2.755 /
-  // 7.74; 32 pairs 1.565 / 2.80 / 7.94; 96 1.56 / 2.98 / 8.23; 256 1.538 / 3.03 / 8.50 -- what the pole tiles save, the
-  // tiles of a minified texture lose several times over: the switch stays off.
+  // on the textured benchmark the atlas seam and the limb of the sphere, where a pixel spreads eight anisotropic taps on
+  // two levels over thousands of texels.)  `pending` says which.
+  // ---- further rounds: the windows are moved onto taps that are still pending and those taps alone are accumulated
+  // (texture gradient only: the grid gradient is complete).  Where the windows go: onto everything pending if that fits
+  // (A), else onto ONE tap of the tile's pixels (B) -- see the placement below.  What is still pending after the last
+  // round goes to global memory corner by corner, as all misses did before round 3.
+  // A round that catches fewer than DRTK_MIP_LEAN_HOPELESS_PAIRS pairs makes the next one the tile's last: its taps are
+  // scattered beyond what windows hold (random uv), and a round costs what some tens of pairs' atomics do.  (With the
+  // windows in the corner of everything pending -- the first half of round 5 -- this cut-off cost the minified scenes
+  // 3-10 %: their rounds' windows then often held little although the tile had plenty to give; by tap they do not.)
+  // What a round costs (profiles/mipmap_bench.py --tile-times / --tile-phases, 10 ns clock per tile): a tile of the textured
+  // benchmark without further rounds lives 11.6 us (inputs 2.4, tap setup + placement 2.1, taps 5.2, flush 1.9) with three
+  // others on its CU; every further round adds 8-12 us -- ~1500 instructions per wave at the ~16 cycles per instruction a
+  // wave gets when four share a SIMD.
   // the lean form of a tap's cell and axis weights on a level of (h, w) texels -- the operations of the first pass's straight
   // line; returns whether the tap is interior (all four corners inside the level: nearly every pending tap; the others go
   // through bilinear_quad below)

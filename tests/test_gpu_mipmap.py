@@ -143,6 +143,57 @@ def test_masked_upstream_gradients_magnified_pixels_and_tap_counts_beyond_the_ta
             close(a, b, f"grad level {i}")
 
 
+@pytest.mark.parametrize("levels", [2, 6])
+@pytest.mark.parametrize("padding", [0, 1])
+@pytest.mark.parametrize("C", [1, 3, 4, 6])
+def test_taps_of_a_pixel_far_apart_on_a_smooth_uv_field(padding, C, levels):
+    """The further rounds of the tiled backward place the windows on ONE tap of a tile's pixels when everything pending
+    does not fit (the limb of a sphere: a pixel's eight taps spread over hundreds of texels, while tap i of neighbouring
+    pixels stay neighbours).  Smooth uv fields that produce exactly that, checked against the oracle:
+    * taps along a diagonal (the corner of the bounding box of everything pending holds nothing),
+    * a seam through the tiles (one half samples one end of the texture, the other half the other end),
+    * a footprint that grows 30x across the image (a tile's pixels on three or four levels, one to eight taps),
+    * a cluster of one tap wider than the widest window slot (the window is centred on the seed tap).
+    With a pyramid of two levels the level of detail is clipped and the eight taps of a pixel lie 30-60 texels apart
+    (spread over 230-460 texels: more than any window); with six levels they are 1-2 texels apart on the pixel's own level
+    while the tiles' pixels sit on three different ones."""
+    import oracle as O
+    from drtk_amd import capi
+
+    H, W, size = 48, 80, 512
+    g = th.Generator().manual_seed(77 + 3 * padding + C)
+    tex = [th.rand(2, C, size, size, generator=g)]
+    for _ in range(levels - 1):
+        tex.append(th.nn.functional.avg_pool2d(tex[-1], 2))
+    yy, xx = th.meshgrid(th.arange(H, dtype=th.float32), th.arange(W, dtype=th.float32), indexing="ij")
+    u = -0.55 + 1.1 * xx / W + 0.02 * yy / H
+    v = -0.5 + 1.0 * yy / H + 0.03 * xx / W
+    grid = th.stack([th.stack([u, v], -1), th.stack([v * 0.9, -u * 0.8], -1)])  # [2, H, W, 2]
+    grid[0, :, W // 2:, 0] -= 1.0                                             # a seam: the right half wraps to the other end
+    grid[0, :, W // 2:, 0] += 2.0 * (grid[0, :, W // 2:, 0] < -1).float()
+    jac = th.zeros(2, H, W, 2, 2)
+    grow = 0.01 * (1.0 + 29.0 * xx / W)                                        # footprint grows 30x from left to right
+    jac[0, ..., 0, 0] = 0.55 * grow / grow.max() + 0.05                        # view 0: long along +u +v (diagonal taps)
+    jac[0, ..., 0, 1] = 0.45 * grow / grow.max() + 0.04
+    jac[0, ..., 1, 0] = -0.004
+    jac[0, ..., 1, 1] = 0.005
+    jac[1, ..., 1, 0] = 0.9                                                    # view 1: along u, clusters 40+ texels wide
+    jac[1, ..., 1, 1] = 0.002
+    jac[1, ..., 0, 0] = 0.003 + 0.1 * yy / H                                   # (and a second axis that makes one tap's cluster wide)
+    jac[1, ..., 0, 1] = 0.02
+    gout = th.rand(2, C, H, W, generator=g) * 2 - 1
+    gout[:, :, 8:20, 30:50] = 0                                                # part of the tiles masked
+    for force, clip in [(False, False), (True, False), (False, True)]:
+        want = O.mipmap_grid_sampler_2d(tex, grid, jac, 8, padding, 0, False, force, clip)
+        got = capi.mipmap_grid_sampler_2d(dev(tex), dev(grid), dev(jac), 8, padding, 0, False, force, clip)
+        close(got, want, "forward")
+        wl, wg = O.mipmap_grid_sampler_2d_backward(gout, tex, grid, jac, 8, padding, 0, False, force, clip)
+        gl, gg = capi.mipmap_grid_sampler_2d_backward(dev(gout), dev(tex), dev(grid), dev(jac), 8, padding, 0, False, force, clip)
+        close(gg, wg, "grad grid", atol=2e-5)
+        for i, (a, b) in enumerate(zip(gl, wl)):
+            close(a, b, f"grad level {i}")
+
+
 def test_non_finite_texels_under_a_zero_weight_stay_out_of_the_result():
     """include/drtk_amd.h, "FINITE TEXELS ASSUMED": a magnified pixel (footprint below one texel) blends level 0 with
     weight 1 and level 1 with weight EXACTLY 0.  The reference evaluates 0 * texel, the oracle restatement with it, so a
