@@ -113,9 +113,9 @@ constexpr int debug_flags() { return 0; }
 #endif
 // Strip length for tile_index(): the tiles of 16 consecutive image rows (128 KB of every float plane at
 // W = 2048 -- strips of 64 to 256 KB measured best for every planar kernel, profiles/kernel_bench.py
-// --flags).  Diagnostics: debug flags >> 10 override it (1 = linear order).
+// --flags).  Diagnostics: bits 10 ... 19 of the debug flags override it (1 = linear order).
 inline int xcd_strip(int64_t tiles_per_16_rows) {
-  const int forced = debug_flags() >> 10;
+  const int forced = (debug_flags() >> 10) & 1023;
   if (forced) return forced;
   return tiles_per_16_rows < 2 ? 2 : static_cast<int>(tiles_per_16_rows);
 }

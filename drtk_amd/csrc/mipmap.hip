@@ -56,13 +56,13 @@ extern "C" __attribute__((visibility("default"))) int drtk_amd_debug_read_mip_du
 #define DRTK_MIP_DUMP_IF(flag, a, b, c, d) do { if (DRTK_DBG(dbg, flag)) { const unsigned int k_ = atomicAdd(&::drtk_amd::g_mip_dump_n, 1u); \
   if (k_ < ::drtk_amd::kMipDumpMax) ::drtk_amd::g_mip_dump[k_] = make_uint4(a, b, c, d); } } while (0)
 #define DRTK_MIP_DUMP(a, b, c, d) DRTK_MIP_DUMP_IF(64, a, b, c, d)
-// flag 1024: a tile's timeline instead -- {view << 24 | tile, further rounds, start, end} in 10 ns ticks (--tile-times)
+// flag 1 << 20: a tile's timeline instead -- {view << 24 | tile, further rounds, start, end} in 10 ns ticks (--tile-times)
 #define DRTK_MIP_TILE_T0() const unsigned int tile_t0_ = static_cast<unsigned int>(wall_clock64()); unsigned int tile_ph_[3] = {0u, 0u, 0u}
 #define DRTK_MIP_TILE_PHASE(k) tile_ph_[k] = static_cast<unsigned int>(wall_clock64()) - tile_t0_
-// flag 2048: the phases of a tile instead -- {.., rounds | inputs there << 16, windows placed | taps done << 16, end}, ticks since the start
+// flag 1 << 21: the phases of a tile instead -- {.., rounds | inputs there << 16, windows placed | taps done << 16, end}, ticks since the start
 #define DRTK_MIP_TILE_DONE(rounds) do { if (tid == 0) { \
-  DRTK_MIP_DUMP_IF(1024, static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), rounds, tile_t0_, static_cast<unsigned int>(wall_clock64())); \
-  DRTK_MIP_DUMP_IF(2048, static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), static_cast<unsigned>(rounds) | tile_ph_[0] << 16, tile_ph_[1] | tile_ph_[2] << 16, static_cast<unsigned int>(wall_clock64()) - tile_t0_); } } while (0)
+  DRTK_MIP_DUMP_IF(1 << 20, static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), rounds, tile_t0_, static_cast<unsigned int>(wall_clock64())); \
+  DRTK_MIP_DUMP_IF(1 << 21, static_cast<unsigned>(n) << 24 | static_cast<unsigned>(tile), static_cast<unsigned>(rounds) | tile_ph_[0] << 16, tile_ph_[1] | tile_ph_[2] << 16, static_cast<unsigned int>(wall_clock64()) - tile_t0_); } } while (0)
 #else
 #define DRTK_MIP_STAT(i, v) do { } while (0)
 #define DRTK_MIP_DUMP(a, b, c, d) do { } while (0)
@@ -1495,6 +1495,9 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #ifndef DRTK_MIP_T3_OCC
 #define DRTK_MIP_T3_OCC 4
 #endif
+#ifndef DRTK_MIP_ROWS_OUTSIDE_IN
+#define DRTK_MIP_ROWS_OUTSIDE_IN 0
+#endif
 #ifndef DRTK_MIP_ROUND_BY_TAP
 #define DRTK_MIP_ROUND_BY_TAP 1
 #endif
@@ -1549,9 +1552,19 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   double* const s_win = reinterpret_cast<double*>(s_win_raw);
   const int tid = threadIdx.x;
   const int n = blockIdx.y;
-  const int tile = tile_index(strip);
+  // (DRTK_MIP_ROWS_OUTSIDE_IN, measured and left off: tile rows from the outside in -- 0, last, 1, last - 1, ... -- so that the
+  // expensive limb tiles of the LAST view are not dispatched at the very end.  A tile's life varies 20x (11 us; 140+ with nine
+  // further rounds) and the per-tile timeline shows the tail: the last 1 % of the tiles of 2 x 4096^2 views finish 0.17 ms
+  // after the others.  Outside-in: 1.476 -> 1.38 ms there, but 8 x 2048^2 (BASELINE configs[4]) 1.99 -> 1.99 and
+  // kernel_bench's minified scene at 4 texels per pixel 4.35 -> 4.64: two bands of tiles in flight halve the reuse of texels
+  // and gradient lines between neighbouring tile rows.)
+  const int tile_disp = tile_index(strip);
   DRTK_MIP_TILE_T0();
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int ty_disp = tile_disp / tiles_x, tx = tile_disp - ty_disp * tiles_x;
+  const int tiles_y = (H + kTileH - 1) / kTileH;
+  const int ty = DRTK_MIP_ROWS_OUTSIDE_IN ? ((ty_disp & 1) ? tiles_y - 1 - (ty_disp >> 1) : (ty_disp >> 1)) : ty_disp;
+  const int tile = ty * tiles_x + tx;
+  (void)tile;
   const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileH + tid / kTileW;
   const bool valid = px < W && py < H;
   const int64_t HW = int64_t(H) * W;

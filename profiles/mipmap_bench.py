@@ -175,7 +175,7 @@ if a.tile_times:
     buf = (ctypes.c_uint * (4 << 20))()
     cnt = ctypes.c_uint(0)
     L.drtk_amd_debug_read_mip_dump(buf, ctypes.byref(cnt))  # clear
-    L.drtk_amd_debug_set_flags(2048 if a.tile_phases else 1024)
+    L.drtk_amd_debug_set_flags((1 << 21) if a.tile_phases else (1 << 20))
     capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, 0)
     th.cuda.synchronize()
     L.drtk_amd_debug_read_mip_dump(buf, ctypes.byref(cnt))
