@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #define DRTK_MIP_T3_OCC 4
 #endif
 #ifndef DRTK_MIP_ROWS_OUTSIDE_IN
-#define DRTK_MIP_ROWS_OUTSIDE_IN 0
+#define DRTK_MIP_ROWS_OUTSIDE_IN 3
 #endif
 #ifndef DRTK_MIP_ROUND_BY_TAP
 #define DRTK_MIP_ROUND_BY_TAP 1
@@ -1552,17 +1552,26 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   double* const s_win = reinterpret_cast<double*>(s_win_raw);
   const int tid = threadIdx.x;
   const int n = blockIdx.y;
-  // (DRTK_MIP_ROWS_OUTSIDE_IN, measured and left off: tile rows from the outside in -- 0, last, 1, last - 1, ... -- so that the
-  // expensive limb tiles of the LAST view are not dispatched at the very end.  A tile's life varies 20x (11 us; 140+ with nine
-  // further rounds) and the per-tile timeline shows the tail: the last 1 % of the tiles of 2 x 4096^2 views finish 0.17 ms
-  // after the others.  Outside-in: 1.476 -> 1.38 ms there, but 8 x 2048^2 (BASELINE configs[4]) 1.99 -> 1.99 and
-  // kernel_bench's minified scene at 4 texels per pixel 4.35 -> 4.64: two bands of tiles in flight halve the reuse of texels
-  // and gradient lines between neighbouring tile rows.)
+  // The tile rows of the launch's LAST view are dispatched from the outside in (0, last, 1, last - 1, ...).  A tile's life varies
+  // 20x (11 us; 140+ where a limb tile needs nine further rounds), and tiles that are dispatched last and live longest are a
+  // tail every other CU waits for: on BASELINE configs[4]'s shape (2 x 4096^2) the last 1 % of the tiles -- the bottom limb of
+  // the last view -- finished 0.17 ms after the others (per-tile timeline, profiles/r05/mipmap_tile_times.txt).  Silhouettes
+  // and grazing angles, the expensive tiles, lie around an object; background and the magnified interior are cheap: the
+  // interior goes last.  Same-box A/B, ms (2 x 4096^2 / 8 x 2048^2 / kernel_bench's minified scenes at 1 and 4 texels per
+  // pixel): in order 1.46 / 1.98 / 2.14 / 4.35; every view outside-in 1.35 / 2.00 / 2.18 / 4.53 (two bands of tiles in
+  // flight: less reuse between neighbouring tile rows); groups of eight rows outside-in 1.41 / 2.03 / 2.21 / 4.45; the last
+  // view only 1.37 / 1.98 / 2.12 / 4.33.
   const int tile_disp = tile_index(strip);
   DRTK_MIP_TILE_T0();
   const int ty_disp = tile_disp / tiles_x, tx = tile_disp - ty_disp * tiles_x;
   const int tiles_y = (H + kTileH - 1) / kTileH;
-  const int ty = DRTK_MIP_ROWS_OUTSIDE_IN ? ((ty_disp & 1) ? tiles_y - 1 - (ty_disp >> 1) : (ty_disp >> 1)) : ty_disp;
+  int ty = ty_disp;
+  if (DRTK_MIP_ROWS_OUTSIDE_IN == 1 || (DRTK_MIP_ROWS_OUTSIDE_IN == 3 && blockIdx.y + 1 == gridDim.y)) { // 3: the launch's last view only
+    ty = (ty_disp & 1) ? tiles_y - 1 - (ty_disp >> 1) : (ty_disp >> 1);
+  } else if (DRTK_MIP_ROWS_OUTSIDE_IN == 2) { // groups of eight tile rows (one per XCD strip) from the outside in; rows beyond the last whole group in order
+    const int groups = tiles_y >> 3, g = ty_disp >> 3;
+    if (g < groups) ty = (((g & 1) ? groups - 1 - (g >> 1) : (g >> 1)) << 3) + (ty_disp & 7);
+  }
   const int tile = ty * tiles_x + tx;
   (void)tile;
   const int px = tx * kTileW + (tid & (kTileW - 1)), py = ty * kTileH + tid / kTileW;
