@@ -1510,9 +1510,6 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #ifndef DRTK_MIP_LEAN_HOPELESS_PAIRS
 #define DRTK_MIP_LEAN_HOPELESS_PAIRS 16 // a round that catches fewer (tap, level) pairs than this is the tile's last but one
 #endif
-#ifndef DRTK_MIP_LEAN_FLUSH_PAIR
-#define DRTK_MIP_LEAN_FLUSH_PAIR 0
-#endif
 // window accumulators per channel and slot (two slots; one slot of twice the size where a tile has one live level).  1024 =
 // the square windows' memory (48 KB for RGB: 3 tiles per CU); 768 -> 36 KB: 4 tiles; 640 -> 30 KB: 5 tiles = 5 waves per
 // SIMD, which the lean loop's 94-98 VGPRs allow.
@@ -1568,9 +1565,6 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   int ty = ty_disp;
   if (DRTK_MIP_ROWS_OUTSIDE_IN == 1 || (DRTK_MIP_ROWS_OUTSIDE_IN == 3 && blockIdx.y + 1 == gridDim.y)) { // 3: the launch's last view only
     ty = (ty_disp & 1) ? tiles_y - 1 - (ty_disp >> 1) : (ty_disp >> 1);
-  } else if (DRTK_MIP_ROWS_OUTSIDE_IN == 2) { // groups of eight tile rows (one per XCD strip) from the outside in; rows beyond the last whole group in order
-    const int groups = tiles_y >> 3, g = ty_disp >> 3;
-    if (g < groups) ty = (((g & 1) ? groups - 1 - (g >> 1) : (g >> 1)) << 3) + (ty_disp & 7);
   }
   const int tile = ty * tiles_x + tx;
   (void)tile;
@@ -1955,21 +1949,6 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
       const GlobalPtr<T> ginp = (GlobalPtr<T>)(static_cast<T*>(s_grad[d]) + (int64_t(n) * C_total + c0) * plane);
       for (int c = 0; c < C; ++c) {
         const int stride = 1 << wsx[l], chan = wcells[l];
-#if DRTK_MIP_LEAN_FLUSH_PAIR
-        // two cells per lane and step (one 16-byte LDS read); a window row = consecutive lanes
-        double2* win2 = reinterpret_cast<double2*>(s_win + (l == 0 ? 0 : C * wcells[0]) + c * chan);
-        for (int i2 = tid; i2 < win_rows[l] * stride / 2; i2 += kMipBlock) { // rows beyond win_rows were never written
-          const double2 q = win2[i2];
-          if (rearm && (q.x != 0.0 || q.y != 0.0)) win2[i2] = double2{0.0, 0.0};
-          const T vals[2] = {static_cast<T>(q.x), static_cast<T>(q.y)};
-          const int i = i2 * 2;
-          const int gx = wox[l] + (i & (stride - 1)), gy = woy[l] + (i >> wsx[l]);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (vals[j] != T(0)) atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx + j, vals[j]);
-          }
-        }
-#else
         // ONE cell per lane: the lanes of an atomic instruction are consecutive texels of a row, so a row's adds travel as
         // one request per 64-byte line -- with two cells per lane (one 16-byte LDS read, round 4) every line was asked for
         // twice, by the even and by the odd texels' instruction: 10.2 M of the kernel's 16.4 M atomic requests on the
@@ -1983,7 +1962,6 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
             atomic_add_g1(ginp + c * plane + int64_t(gy) * w + gx, static_cast<T>(q));
           }
         }
-#endif
       }
     }
   };
