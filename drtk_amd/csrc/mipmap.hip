@@ -600,8 +600,17 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 //     exec-mask regions in the loop; the border taps themselves (rare) are added by a branch the wave only takes if it has one;
 //   * 32-bit texel offsets from per-pixel level bases.
 // Reflection padding, double and bicubic stay with the kernels above.
+// Waves per SIMD (late round 5).  The kernel is a chain of gathers per tap and lives on waves in flight, like the backward on
+// tiles in flight: the compiler's own choice was 100 registers = FOUR waves per SIMD (the allocation granule puts five at
+// <= 96).  Asked for five it fits 84-94 without a spill: 0.70 -> 0.65 ms on the textured benchmark.  With the per-level sizes
+// and the view's base pointers re-read from the LDS table inside the tap loop (three LDS reads per (tap, level)) instead of
+// living in twelve registers per lane: 62-64 registers = EIGHT waves, 0.59 ms (kernel_bench's minified scenes 0.97 -> 0.80 and
+// 1.23 -> 1.10); four channels per sweep: 70-72 = seven.
+#ifndef DRTK_MIP_FWD_OCC
+#define DRTK_MIP_FWD_OCC 8
+#endif
 template <int PAD, int CB>
-__global__ __launch_bounds__(kBlock) void mipmap_forward_lean_kernel(
+__global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap_forward_lean_kernel(
     LevelTable lv, int mipmaps, const float* __restrict__ grid, GridLayout gl, const float* __restrict__ vt, int C,
     int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, float* __restrict__ out, int strip) {
   using T = float;
@@ -633,16 +642,11 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_lean_kernel(
   // level slot s = 0: level d1 with weight alpha_2; s = 1: level d1 + 1 with alpha_1.  A slot whose weight is exactly
   // zero -- the coarser level of every magnified pixel -- is dead (as in the kernels above).
   const bool live[2] = {bool(valid & (alpha_2 != T(0))), bool(valid & (n_lv == 2) & (alpha_1 != T(0)))};
-  int lw[2], lh[2];
-  T lwf[2], lhf[2];
-  GlobalPtr<const T> lbase[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int d = live[s] ? t.d1 + s : 0;
-    lw[s] = s_w[d], lh[s] = s_h[d];
-    lwf[s] = static_cast<T>(lw[s]), lhf[s] = static_cast<T>(lh[s]);
-    lbase[s] = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + n * s_sn[d]);
-  }
+  // (per-level sizes and the view's base pointer are re-read from the LDS table inside the tap loop instead of living in
+  // twelve registers per lane)
+  if (threadIdx.x < kMaxLevels) s_ptr[threadIdx.x] = static_cast<const T*>(s_ptr[threadIdx.x]) + n * s_sn[threadIdx.x];
+  __syncthreads();
+  const int ld[2] = {live[0] ? t.d1 : 0, live[1] ? t.d1 + 1 : 0};
   const double du_d = t.du, dv_d = t.dv;
   const int n_max = wave_max_i32(valid ? t.n : 0);
   const bool table = max_aniso <= kTapTab; // kernel-uniform: the taps' positions come from the LDS table
@@ -665,6 +669,12 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_lean_kernel(
       for (int s = 0; s < 2; ++s) {
         const bool on = has_tap & live[s];
         if (__ballot(on) == 0) continue; // wave-uniform
+        int lw[2], lh[2];
+        T lwf[2], lhf[2];
+        GlobalPtr<const T> lbase[2];
+        lw[s] = s_w[ld[s]], lh[s] = s_h[ld[s]];
+        lwf[s] = static_cast<T>(lw[s]), lhf[s] = static_cast<T>(lh[s]);
+        lbase[s] = (GlobalPtr<const T>)static_cast<const T*>(s_ptr[ld[s]]);
         // the reference's coordinate pipeline for an INTERIOR tap: unnormalize, clip (border padding), floor.  Values are
         // made finite first (a clamp that cannot move a tap whose cell lies inside the level), so that the weights of the
         // lanes that do not count -- no tap, a tap on or beyond the border, a NaN -- are finite and their products with
