@@ -22,7 +22,7 @@ bash profiles/scripts/collect_round.sh > $F/collect_round.log 2>&1
 cp gpurun_out/round/bench_n1.json gpurun_out/round/bench_step_kernel_stats.txt gpurun_out/round/traffic.json gpurun_out/round/kernel_bench_pmc_*.txt $F/ 2>/dev/null
 bash profiles/scripts/other_configs.sh > $F/other_configs.log 2>&1
 mkdir -p $F/other_configs; cp gpurun_out/configs/*.json $F/other_configs/
-python3 profiles/shape_bench.py --what interp_c --reps 10 --channels 4,5,6,7,8,9,10,11,12,13,14,15,16,20,24,32,40,64 --dtypes f32,f64 --out $F/interp_bwd_by_C.json > /dev/null 2> $F/interp_bwd_by_C.log
+python3 profiles/shape_bench.py --what interp_c --reps 10 --channels 4,5,6,7,8,9,10,11,12,13,14,15,16,17,20,21,24,32,37,40,64 --dtypes f32,f64 --out $F/interp_bwd_by_C.json > /dev/null 2> $F/interp_bwd_by_C.log
 python3 profiles/shape_bench.py --what raster,f64 --reps 10 --split-dir $F > $F/shape_bench.json 2> $F/shape_bench.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $F/tex_stats -- python3 bench.py --workload textured --no-graph --steps 10 --warmup 2 --cpu-sample-views 0 > $F/tex_stats.log 2>&1
 python3 profiles/summarize_stats.py $F/tex_stats $F/textured_step_kernel_stats.txt > /dev/null 2>&1
