@@ -545,8 +545,11 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
 #ifndef DRTK_INTERP_ANYC_QA
 #define DRTK_INTERP_ANYC_QA 1
 #endif
+#ifndef DRTK_INTERP_ANYC_SPLIT
+#define DRTK_INTERP_ANYC_SPLIT 1
+#endif
 #ifndef DRTK_INTERP_ANYC_WAVES
-#define DRTK_INTERP_ANYC_WAVES 3
+#define DRTK_INTERP_ANYC_WAVES 4
 #endif
 #ifndef DRTK_INTERP_CH8
 #define DRTK_INTERP_CH8 1
@@ -768,8 +771,10 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : C
 #ifndef DRTK_INTERP_QA
 #define DRTK_INTERP_QA 1
 #endif
-    // float4 per corner requested before / after phase 2 (ANYC + bary gradient: compiled for 3 waves per SIMD -- the window arithmetic
-    // of the partial group spills 4-10 registers at 4, and 2-4 with every request moved behind phase 2)
+    // float4 per corner requested before / after phase 2 (ANYC + bary gradient: the window arithmetic of the partial group spills
+    // 4-10 registers at 4 waves per SIMD, and 2-4 with every request moved behind phase 2; rounds 5a-b ran it at 3 waves, 138
+    // registers.  With the LAST group of a 16-channel chunk requested after the products of the others -- DRTK_INTERP_ANYC_SPLIT,
+    // below -- it is 124 registers and runs at 4: C = 13 ... 15 0.855 -> 0.745 ms, 17 1.19 -> 1.05, 21 1.27 -> 1.12, 37 1.90 -> 1.65)
     constexpr int QA = ANYC ? DRTK_INTERP_ANYC_QA : DRTK_INTERP_QA, QD = CH / 4 - QA;
     // group q of a row's chunk: channels 4q .. 4q+3, or (ANYC, the chunk's partial last group) the four that end the row
     typedef T TQuadU __attribute__((ext_vector_type(4), aligned(sizeof(T))));
@@ -837,8 +842,11 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : C
         const T* d0 = attrs_n + int64_t(w0) * C + c0;
         const T* d1 = attrs_n + int64_t(w1) * C + c0;
         const T* d2 = attrs_n + int64_t(w2) * C + c0;
+        // (ANYC at four waves per SIMD: the last group is requested only after the products of the others -- twelve registers
+        // less in flight, one more round trip per chunk)
+        constexpr int QD1 = (ANYC && CH == 16 && DRTK_INTERP_ANYC_SPLIT && QD > 1) ? QD - 1 : QD; // (12-channel chunks fit without: 0.69 vs 0.71 ms at C = 11)
 #pragma unroll
-        for (int q = 0; q < QD; ++q) {
+        for (int q = 0; q < QD1; ++q) {
           if (4 * (QA + q) < cc) {
             D0[q] = attr4(d0, QA + q);
             D1[q] = attr4(d1, QA + q);
@@ -875,8 +883,15 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : C
           if (4 * q < cc) dot4(q, A0[q], A1[q], A2[q]);
         }
 #pragma unroll
-        for (int q = 0; q < QD; ++q) {
+        for (int q = 0; q < QD1; ++q) {
           if (4 * (QA + q) < cc) dot4(QA + q, D0[q], D1[q], D2[q]);
+        }
+        if constexpr (QD1 < QD) {
+          if (4 * (QA + QD1) < cc) {
+            asm volatile("" ::: "memory"); // (keeps the request behind the products above)
+            const V4 e0 = attr4(d0, QA + QD1), e1 = attr4(d1, QA + QD1), e2 = attr4(d2, QA + QD1);
+            dot4(QA + QD1, e0, e1, e2);
+          }
         }
       }
     }
