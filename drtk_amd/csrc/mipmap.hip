@@ -1502,8 +1502,15 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 // flush) exposed; at <= 128 a CU holds four tiles instead of three.
 // Wider textures (C > 4: neural textures) run it once per block of four channels (`C_total`, `c0`; the grid gradient
 // accumulates over the blocks, the tap geometry is recomputed per block) instead of the wave-private kernel below.
+// Tiles per CU (= waves per SIMD), up to three channels: FIVE since late round 5 -- 94-96 registers (the pixel's index is
+// rebuilt where it is needed instead of being carried: it was what spilled) and windows of 2 x 512 accumulators per channel
+// (24.5 KB for RGB).  Same-box A/B, ms (textured benchmark 2 x 4096^2 / 8 x 2048^2 / kernel_bench's minified scenes at 1 and 4
+// texels per pixel): four tiles with 2 x 768 cells 1.383 / 1.99 / 2.13 / 4.35; four with 2 x 512 1.42 / 2.12 / 2.27 / 4.85; FIVE
+// with 2 x 512 1.28 / 1.95 / 2.11 / 4.53 -- the fifth tile is worth more than the larger windows except where a tile's taps
+// cover four texels per pixel.  (2 x 640 cells = 32 144 B per tile is five tiles by the occupancy query, profiles/micro/
+// lds_occupancy.hip, and runs like four: 1.41 / - / 2.23 / 4.74.)  Four channels per pass: 100-110 registers, four tiles.
 #ifndef DRTK_MIP_T3_OCC
-#define DRTK_MIP_T3_OCC 4
+#define DRTK_MIP_T3_OCC 5
 #endif
 #ifndef DRTK_MIP_ROWS_OUTSIDE_IN
 #define DRTK_MIP_ROWS_OUTSIDE_IN 3
@@ -1521,19 +1528,22 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #define DRTK_MIP_LEAN_HOPELESS_PAIRS 16 // a round that catches fewer (tap, level) pairs than this is the tile's last but one
 #endif
 // window accumulators per channel and slot (two slots; one slot of twice the size where a tile has one live level).  1024 =
-// the square windows' memory (48 KB for RGB: 3 tiles per CU); 768 -> 36 KB: 4 tiles; 640 -> 30 KB: 5 tiles = 5 waves per
-// SIMD, which the lean loop's 94-98 VGPRs allow.
+// the square windows' memory of round 4 (48 KB for RGB: 3 tiles per CU); 768 -> 36 KB: 4 tiles (the first half of round 5);
+// 512 -> 24.5 KB: 5 tiles, with the registers that go with them (DRTK_MIP_T3_OCC above).
 #ifndef DRTK_MIP_T3_SLOT_CELLS
-#define DRTK_MIP_T3_SLOT_CELLS 768
+#define DRTK_MIP_T3_SLOT_CELLS 512 // (768 until late round 5: see DRTK_MIP_T3_OCC)
+#endif
+#ifndef DRTK_MIP_T3_SLOT_CELLS12
+#define DRTK_MIP_T3_SLOT_CELLS12 768 // one or two channels: 12-24 KB, five tiles either way (C = 1 / 2: 0.91 / 1.08 ms; with 512: 0.94 / 1.09)
 #endif
 #ifndef DRTK_MIP_T3_SLOT_CELLS4
 #define DRTK_MIP_T3_SLOT_CELLS4 512 // four channels: 2 x 512 x 4 x 8 B = 32 KB keeps four tiles per CU (768: 48 KB, three)
 #endif
 template <int CN>
-constexpr int lean_slot_cells() { return CN == 4 ? DRTK_MIP_T3_SLOT_CELLS4 : DRTK_MIP_T3_SLOT_CELLS; }
-static_assert(DRTK_MIP_T3_SLOT_CELLS % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS4 % 128 == 0, "whole rows at every slot width (16 ... 128 cells), cells in pairs");
+constexpr int lean_slot_cells() { return CN == 4 ? DRTK_MIP_T3_SLOT_CELLS4 : CN == 3 ? DRTK_MIP_T3_SLOT_CELLS : DRTK_MIP_T3_SLOT_CELLS12; }
+static_assert(DRTK_MIP_T3_SLOT_CELLS % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS4 % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS12 % 128 == 0, "whole rows at every slot width (16 ... 128 cells), cells in pairs");
 template <int PAD, bool ALIGN, int CN>
-__global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_lean_kernel(
+__global__ __launch_bounds__(kMipBlock, CN <= 3 ? DRTK_MIP_T3_OCC : 4) void mipmap_backward_lean_kernel(
     LevelTable lv, int mipmaps, const float* __restrict__ grad_out, const float* __restrict__ grid, GridLayout gl,
     const float* __restrict__ vt, int H, int W, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, float* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg, int C_total, int c0) {
@@ -1592,8 +1602,14 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     for (int c = 0; c < CN; ++c) go[c] = gout_px[int64_t(c) * HW];
   }
   PixelUV<T> uv = {};
-  const int64_t pix = int64_t(py) * W + px;
-  if (valid) uv = load_pixel_uv<T>(grid, gl, vt, n, pix, index);
+  // (the pixel's index is rebuilt where it is needed -- here, at an early exit, after the tap loop -- from a laundered thread id:
+  // carried through the kernel its two registers are the ones that spill at five waves per SIMD)
+  auto pixel_index = [&]() -> int64_t {
+    int tid_l = tid;
+    asm volatile("" : "+v"(tid_l));
+    return int64_t(ty * kTileH + tid_l / kTileW) * W + (tx * kTileW + (tid_l & (kTileW - 1)));
+  };
+  if (valid) uv = load_pixel_uv<T>(grid, gl, vt, n, int64_t(py) * W + px, index);
   // ... and under them everything that needs no data: the tables, the placement cells, the windows' zero-fill (a tile
   // that turns out to have no upstream gradient has zeroed its windows for nothing; the stores wait for nobody)
   stage_tap_table(s_f);
@@ -1612,7 +1628,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
 #pragma unroll
   for (int c = 0; c < CN; ++c) has_go = has_go | (go[c] != T(0));
   if (!__syncthreads_or(has_go)) { // (also publishes the tables and the zero-fill)
-    if (valid && c0 == 0) store_grid_grad<T>(grad_grid, ggl, n, pix, T(0), T(0)); // (a later channel block adds nothing)
+    if (valid && c0 == 0) store_grid_grad<T>(grad_grid, ggl, n, pixel_index(), T(0), T(0)); // (a later channel block adds nothing)
     return;
   }
   DRTK_MIP_TILE_PHASE(0);
@@ -1935,6 +1951,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
     }
   }
   if (valid) {
+    const int64_t pix = pixel_index();
     if (c0 != 0) { // a further block of channels of a wide texture: the grid gradient accumulates (one thread per pixel, launches in stream order)
       const T* gq = grad_grid + int64_t(n) * ggl.sN + pix * ggl.sP;
       acc_x += gq[0], acc_y += gq[ggl.sC];
@@ -2015,12 +2032,12 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
   // how many taps away from one of its taps a pixel can have another one inside the same window (<= 128 cells wide and
   // high): the taps are equally spaced, 2 / (n + 1) of (du, dv) apart -- on the coarser of the pixel's levels half as many
   // texels as on the finer.  A filter for the rounds below, not a decision: a tap it wrongly leaves out stays pending.
-  int k_span;
-  {
+  // (evaluated where a round needs it: a register less across the tap loop)
+  auto tap_span = [&]() -> int {
     const T step = T(2) / static_cast<T>(t.n + 1);
     const T sp = fmaxf(fabsf(static_cast<T>(t.du)) * static_cast<T>(s_w[t.d1]), fabsf(static_cast<T>(t.dv)) * static_cast<T>(s_h[t.d1])) * step * T(0.5);
-    k_span = static_cast<int>(fminf(T(16), T(258) / fmaxf(sp, T(1)))) + 1;
-  }
+    return static_cast<int>(fminf(T(16), T(258) / fmaxf(sp, T(1)))) + 1;
+  };
   int ref_now = ref, npend_before = 0;
   for (int round = 1;; ++round) {
     {
@@ -2203,6 +2220,7 @@ __global__ __launch_bounds__(kMipBlock, DRTK_MIP_T3_OCC) void mipmap_backward_le
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) star_in = star_in || (star[s2] && slot_cell(t.d1 + s2 - ref_now, star_x[s2], star_y[s2]) >= 0);
         if (star_in) {
+          const int k_span = tap_span();
           const int b_lo = 2 * max(i_star - k_span, 0), b_hi = 2 * min(i_star + k_span, 15) + 1;
           todo &= (0xFFFFFFFFu << b_lo) & (0xFFFFFFFFu >> (31 - b_hi));
         }
