@@ -1508,9 +1508,12 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 // texels per pixel): four tiles with 2 x 768 cells 1.383 / 1.99 / 2.13 / 4.35; four with 2 x 512 1.42 / 2.12 / 2.27 / 4.85; FIVE
 // with 2 x 512 1.28 / 1.95 / 2.11 / 4.53 -- the fifth tile is worth more than the larger windows except where a tile's taps
 // cover four texels per pixel.  (2 x 640 cells = 32 144 B per tile is five tiles by the occupancy query, profiles/micro/
-// lds_occupancy.hip, and runs like four: 1.41 / - / 2.23 / 4.74.)  Four channels per pass: 100-110 registers, four tiles.
+// lds_occupancy.hip, and runs like four: 1.41 / - / 2.23 / 4.74.)  Four channels per pass: DRTK_MIP_T3_OCC4.
 #ifndef DRTK_MIP_T3_OCC
 #define DRTK_MIP_T3_OCC 5
+#endif
+#ifndef DRTK_MIP_T3_OCC4
+#define DRTK_MIP_T3_OCC4 5 // four channels per pass: 96 registers, windows of 2 x 384 accumulators (24.6 KB): C = 4 / 8 / 16 1.62 / 3.17 / 6.33 -> 1.51 / 2.92 / 5.90 ms
 #endif
 #ifndef DRTK_MIP_ROWS_OUTSIDE_IN
 #define DRTK_MIP_ROWS_OUTSIDE_IN 3
@@ -1537,13 +1540,13 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #define DRTK_MIP_T3_SLOT_CELLS12 768 // one or two channels: 12-24 KB, five tiles either way (C = 1 / 2: 0.91 / 1.08 ms; with 512: 0.94 / 1.09)
 #endif
 #ifndef DRTK_MIP_T3_SLOT_CELLS4
-#define DRTK_MIP_T3_SLOT_CELLS4 512 // four channels: 2 x 512 x 4 x 8 B = 32 KB keeps four tiles per CU (768: 48 KB, three)
+#define DRTK_MIP_T3_SLOT_CELLS4 384 // four channels: 2 x 384 x 4 x 8 B = 24.6 KB: five tiles per CU (512: 32 KB, four)
 #endif
 template <int CN>
 constexpr int lean_slot_cells() { return CN == 4 ? DRTK_MIP_T3_SLOT_CELLS4 : CN == 3 ? DRTK_MIP_T3_SLOT_CELLS : DRTK_MIP_T3_SLOT_CELLS12; }
 static_assert(DRTK_MIP_T3_SLOT_CELLS % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS4 % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS12 % 128 == 0, "whole rows at every slot width (16 ... 128 cells), cells in pairs");
 template <int PAD, bool ALIGN, int CN>
-__global__ __launch_bounds__(kMipBlock, CN <= 3 ? DRTK_MIP_T3_OCC : 4) void mipmap_backward_lean_kernel(
+__global__ __launch_bounds__(kMipBlock, CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_OCC4) void mipmap_backward_lean_kernel(
     LevelTable lv, int mipmaps, const float* __restrict__ grad_out, const float* __restrict__ grid, GridLayout gl,
     const float* __restrict__ vt, int H, int W, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, float* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg, int C_total, int c0) {
