@@ -11,7 +11,7 @@ from drtk_amd.interpolate import (  # noqa: F401
     interpolation_normal_matrix,
 )
 from drtk_amd.mipmap_grid_sample import mipmap_grid_sample  # noqa: F401
-from drtk_amd.rasterize import rasterize, rasterize_with_depth  # noqa: F401
+from drtk_amd.rasterize import get_depth_order, rasterize, rasterize_with_depth, set_depth_order  # noqa: F401
 from drtk_amd.render import render  # noqa: F401
 from drtk_amd.screen_space_uv_derivative import screen_space_uv_derivative  # noqa: F401
 from drtk_amd.transform import transform, transform_with_v_cam  # noqa: F401
@@ -19,8 +19,9 @@ from drtk_amd.transform import transform, transform_with_v_cam  # noqa: F401
 __version__ = "0.1.0"
 
 # The public surface.  Same names, arguments and defaults as `drtk.*` for everything on the hot path and its "next"
-# rows; `interpolate_masked` (interpolate with the background written as 0) and `capture_step` (a whole step as a
-# HIP graph) are this package's additions.  Not
+# rows; `interpolate_masked` (interpolate with the background written as 0), `capture_step` (a whole step as a
+# HIP graph) and `set_depth_order` / `get_depth_order` (the rasterizer's depth order: the reference's source, or the
+# reference as its setup.py builds it) are this package's additions.  Not
 # provided: grid_scatter, msi, filter2d and the pure-PyTorch `*_ref` models (out of scope).
 __all__ = [
     "rasterize",
@@ -36,4 +37,6 @@ __all__ = [
     "transform",
     "transform_with_v_cam",
     "capture_step",
+    "set_depth_order",
+    "get_depth_order",
 ]

@@ -166,41 +166,6 @@ def build_variant(out, defines, verbose=True):
     return out
 
 
-FASTMATH_DEPTH_LIB = os.path.join(PKG, "libdrtk_amd_depth_fastmath.so")
-
-
-def build_depth_fastmath(force=False, verbose=True):
-    """drtk_amd/libdrtk_amd_depth_fastmath.so -- the whole C ABI with the rasterizer's depth evaluated in the order the
-    reference's host path has when built with its own flags (-O3 --fast-math: csrc/rasterize.hip,
-    DRTK_DEPTH_FASTMATH_ORDER).  An OFFERED variant for callers who need index_img bit-equal to the reference as
-    setup.py builds it; the default library keeps the source order (strict IEEE), the torch-operator shim links the
-    default, and nothing loads this one unless asked (drtk_amd.capi.use_depth_order("fastmath") before the first call,
-    or DRTK_AMD_DEPTH_ORDER=fastmath in the environment).  Pinned by tests/test_gpu_parity.py::
-    test_depth_fastmath_variant_reproduces_the_reference_as_built."""
-    deps = _kernel_deps()
-    extra = " ".join(HIP_FLAGS) + " -DDRTK_DEPTH_FASTMATH_ORDER"
-    if not force and _newer(FASTMATH_DEPTH_LIB, deps, extra):
-        return FASTMATH_DEPTH_LIB
-    # only rasterize.hip differs: the other objects are compiled once more all the same (a library is ONE consistent set
-    # of flags; ~1 min side by side)
-    objs, cmds = [], []
-    for s in KERNEL_SRCS:
-        o = os.path.join(CSRC, s + ".fastmath.o")
-        objs.append(o)
-        cmds.append([HIPCC, *HIP_FLAGS, "-DDRTK_DEPTH_FASTMATH_ORDER", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, s), "-o", o])
-    with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
-        outs = list(ex.map(_run, cmds))
-    for s, out in zip(KERNEL_SRCS, outs):
-        check_no_vgpr_spills(out, s + " (depth-order variant)")
-    _run([HIPCC, *LINK_FLAGS, "-o", FASTMATH_DEPTH_LIB, *objs])
-    for o in objs:
-        os.remove(o)
-    _stamp(FASTMATH_DEPTH_LIB, deps, extra)
-    if verbose:
-        print(f"[drtk_amd] built {FASTMATH_DEPTH_LIB}")
-    return FASTMATH_DEPTH_LIB
-
-
 OPS_DIR = os.path.join(CSRC, "torch_ops")
 OPS_SRCS = ["rasterize.cpp", "render.cpp", "interpolate.cpp", "interp_matrix.cpp", "mipmap.cpp", "edge_grad.cpp", "transform.cpp"]
 
@@ -269,18 +234,15 @@ def build_ext_modules(force=False, verbose=True):
     return outs
 
 
-def build_all(force=False, verbose=True, depth_fastmath=None):
-    """The product: kernels + C ABI, torch-operator shim, `import drtk` modules.  The depth-order variant is an OFFERED
-    extra nothing loads by default: it is built when asked for (`--with-depth-fastmath`, DRTK_AMD_BUILD_DEPTH_FASTMATH=1,
-    __graft_entry__.build() asks: a GPU test pins it), and a failure there never fails the product build."""
+def build_all(force=False, verbose=True):
+    """The product: kernels + C ABI, torch-operator shim, `import drtk` modules.  (Until round 5 a second copy of the
+    library carried the rasterizer's other depth order; it is a run-time setting of the one library now:
+    include/drtk_amd.h drtk_amd_set_depth_order.)"""
     build_kernels(force=force, verbose=verbose)
-    if depth_fastmath is None:
-        depth_fastmath = os.environ.get("DRTK_AMD_BUILD_DEPTH_FASTMATH", "0") == "1"
-    if depth_fastmath:
-        try:
-            build_depth_fastmath(force=force, verbose=verbose)
-        except RuntimeError as e:  # optional variant: report, keep going
-            print(f"[drtk_amd] WARNING: the optional depth-order variant did not build:\n{e}", file=sys.stderr)
+    stale = os.path.join(PKG, "libdrtk_amd_depth_fastmath.so")  # a leftover of such a build would only mislead
+    for f in (stale, stale + ".src"):
+        if os.path.isfile(f):
+            os.remove(f)
     build_torch_ops(force=force, verbose=verbose)
     build_ext_modules(force=force, verbose=verbose)
     return LIB, OPS
@@ -306,10 +268,7 @@ if __name__ == "__main__":
     elif "--variant" in sys.argv:  # python drtk_amd/build.py --variant out.so DEFINE[=value] ...
         i = sys.argv.index("--variant")
         build_variant(sys.argv[i + 1], sys.argv[i + 2:])
-    elif "--depth-order" in sys.argv:  # python drtk_amd/build.py --depth-order fastmath
-        assert sys.argv[sys.argv.index("--depth-order") + 1] == "fastmath", "--depth-order fastmath (the default library IS the strict order)"
-        build_depth_fastmath(force="--force" in sys.argv)
     elif "--ablation" in sys.argv:
         build_ablation(force="--force" in sys.argv)
     else:
-        build_all(force="--force" in sys.argv, depth_fastmath=True if "--with-depth-fastmath" in sys.argv else None)
+        build_all(force="--force" in sys.argv)

@@ -84,27 +84,30 @@ def use_profiling_library(path: str) -> None:
     _lib_path = path
 
 
+DEPTH_ORDERS = {"strict": 0, "fastmath": 1}  # drtk_depth_order_t
+
+
 def use_depth_order(order: str) -> None:
-    """Bind this module to the build variant whose rasterizer evaluates depth in the order of the reference AS BUILT by its
-    setup.py (`-O3 --fast-math`): `order="fastmath"` -> drtk_amd/libdrtk_amd_depth_fastmath.so (drtk_amd/build.py
-    build_depth_fastmath); `"strict"` is the default library.  Must be called before the first C-ABI call of the
-    process; DRTK_AMD_DEPTH_ORDER=fastmath in the environment does the same.  The torch operators always use the default."""
-    global _lib_path
-    assert order in ("strict", "fastmath"), order
-    assert _lib is None, "the C-ABI library is already loaded"
-    _lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdrtk_amd_depth_fastmath.so") if order == "fastmath" else None
+    """The rasterizer's depth-order setting (include/drtk_amd.h: drtk_amd_set_depth_order): `"fastmath"` evaluates the
+    depth sum in the order of the reference AS BUILT by its setup.py (`-O3 --fast-math`), `"strict"` (the default) in the
+    order its source spells.  One setting per process and library -- the torch operators call the same library and
+    follow it; DRTK_AMD_DEPTH_ORDER=fastmath in the environment sets the initial value.  Affects later launches."""
+    assert order in DEPTH_ORDERS, order
+    _check(lib().drtk_amd_set_depth_order(DEPTH_ORDERS[order]), "set_depth_order")
+
+
+def depth_order() -> str:
+    o = lib().drtk_amd_get_depth_order()
+    return next(k for k, v in DEPTH_ORDERS.items() if v == o)
 
 
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if _lib_path is None and os.environ.get("DRTK_AMD_DEPTH_ORDER", "") == "fastmath":
-            use_depth_order("fastmath")
         path = _lib_path or native_library_paths()[0]
         if not os.path.isfile(path):
             build_py = os.path.join(os.path.dirname(os.path.abspath(__file__)), "build.py")
-            how = f"python {build_py} --depth-order fastmath" if path.endswith("libdrtk_amd_depth_fastmath.so") else f"python {build_py}"
-            raise ImportError(f"{path} is missing: run `{how}`")
+            raise ImportError(f"{path} is missing: run `python {build_py}`")
         L = ctypes.CDLL(path)
         L.drtk_amd_status_string.restype = ctypes.c_char_p
         L.drtk_amd_status_string.argtypes = [ctypes.c_int]
@@ -119,6 +122,8 @@ def lib() -> ctypes.CDLL:
 EXPORTS = [
     "drtk_amd_status_string",
     "drtk_amd_version",
+    "drtk_amd_set_depth_order",
+    "drtk_amd_get_depth_order",
     "drtk_amd_rasterize_workspace_bytes",
     "drtk_amd_rasterize_lines_workspace_bytes",
     "drtk_amd_rasterize",

@@ -2,6 +2,7 @@
 #include "common.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -30,6 +31,31 @@ extern "C" const char* drtk_amd_status_string(int status) {
 #define DRTK_STR(x) DRTK_STR2(x)
 extern "C" const char* drtk_amd_version(void) {
   return DRTK_STR(DRTK_AMD_VERSION_MAJOR) "." DRTK_STR(DRTK_AMD_VERSION_MINOR) " (gfx950)";
+}
+
+namespace drtk_amd {
+// The rasterizer's depth-order setting (include/drtk_amd.h): -1 = not read yet.
+static std::atomic<int> g_depth_order{-1};
+int depth_order_setting() {
+  int o = g_depth_order.load(std::memory_order_relaxed);
+  if (o < 0) {
+    const char* e = std::getenv("DRTK_AMD_DEPTH_ORDER");
+    const int from_env = (e && std::strcmp(e, "fastmath") == 0) ? DRTK_DEPTH_ORDER_FASTMATH : DRTK_DEPTH_ORDER_STRICT;
+    int expected = -1;
+    g_depth_order.compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
+    o = g_depth_order.load(std::memory_order_relaxed);
+  }
+  return o;
+}
+} // namespace drtk_amd
+
+extern "C" int drtk_amd_set_depth_order(int order) {
+  if (order != DRTK_DEPTH_ORDER_STRICT && order != DRTK_DEPTH_ORDER_FASTMATH) return DRTK_ERR_INVALID_ARGUMENT;
+  drtk_amd::g_depth_order.store(order, std::memory_order_relaxed);
+  return DRTK_OK;
+}
+extern "C" int drtk_amd_get_depth_order(void) {
+  return drtk_amd::depth_order_setting();
 }
 
 namespace drtk_amd {

@@ -123,6 +123,9 @@ inline int xcd_strip(int64_t tiles_per_16_rows) {
 // Compute units of the current device (cached per device id).
 int num_compute_units();
 
+// The rasterizer's depth-order setting (drtk_depth_order_t; include/drtk_amd.h: drtk_amd_set_depth_order, DRTK_AMD_DEPTH_ORDER).
+int depth_order_setting();
+
 // memset(p, value, bytes) in stream order, as an ordinary KERNEL launch (any alignment, any size; DRTK_OK or
 // DRTK_ERR_LAUNCH).  The library does not use hipMemsetAsync: captured into a graph (torch.cuda.graph around a
 // training step) its memset node stops doing its job on replays that follow other work on the device -- measured

@@ -691,26 +691,32 @@ __global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap
             (static_cast<unsigned>(iy_nw) < static_cast<unsigned>(lh[s] - 1));
         // corner weights (bilinear_quad: (ix_se - ix) with ix_se = ix_nw + 1, an exact float) times the level's weight
         const T wx1 = (fx_floor + T(1)) - ix, wx0 = ix - fx_floor;
-        const T al = interior ? (s == 0 ? alpha_2 : alpha_1) : T(0);
-        const T wy1 = ((fy_floor + T(1)) - iy) * al, wy0 = (iy - fy_floor) * al;
-        const T w_nw = wx1 * wy1, w_ne = wx0 * wy1, w_sw = wx1 * wy0, w_se = wx0 * wy0;
-        const int o_nw = iy_nw * lw[s] + ix_nw;
-        const int o_top = interior ? o_nw : 0;
-        const int o_bot = interior ? o_nw + lw[s] : 0;
-        const int plane = lw[s] * lh[s]; // < 2^31 (fill_table)
+        const int plane = lw[s] * lh[s]; // <= kLeanMaxPlane (the dispatch): cc * plane + offset fits 32 bits
         const GlobalPtr<const T> b = lbase[s] + int64_t(c0) * plane;
-        Pair<T> top[CB], bot[CB];
+        // Round 6: the tap's loads and fmas run under `interior` -- ONE exec-mask region per (tap, level).  Round 5 let the
+        // other lanes (no tap i, a border tap, a NaN coordinate, a dead level) run the same loads at offset 0 with weight 0:
+        // that read texels (0,0) / (1,0) of the level for pixels that never sample them -- a NaN or Inf there turned
+        // `texel * 0` into NaN where the reference stays finite -- and on a 1 x 1 level the pair at offset 0 of the last
+        // channel of the last view ended one element beyond the tensor.  The lanes that are switched off touch nothing now.
+        if (interior) {
+          const T al = s == 0 ? alpha_2 : alpha_1;
+          const T wy1 = ((fy_floor + T(1)) - iy) * al, wy0 = (iy - fy_floor) * al;
+          const T w_nw = wx1 * wy1, w_ne = wx0 * wy1, w_sw = wx1 * wy0, w_se = wx0 * wy0;
+          const int o_top = iy_nw * lw[s] + ix_nw;
+          const int o_bot = o_top + lw[s];
+          Pair<T> top[CB], bot[CB];
 #pragma unroll
-        for (int cc = 0; cc < CB; ++cc) {
-          top[cc] = *(GlobalPtr<const Pair<T>>)(b + (cc * plane + o_top));
-          bot[cc] = *(GlobalPtr<const Pair<T>>)(b + (cc * plane + o_bot));
-        }
+          for (int cc = 0; cc < CB; ++cc) {
+            top[cc] = *(GlobalPtr<const Pair<T>>)(b + (cc * plane + o_top));
+            bot[cc] = *(GlobalPtr<const Pair<T>>)(b + (cc * plane + o_bot));
+          }
 #pragma unroll
-        for (int cc = 0; cc < CB; ++cc) {
-          acc[cc] = __builtin_fmaf(top[cc].x, w_nw, acc[cc]);
-          acc[cc] = __builtin_fmaf(top[cc].y, w_ne, acc[cc]);
-          acc[cc] = __builtin_fmaf(bot[cc].x, w_sw, acc[cc]);
-          acc[cc] = __builtin_fmaf(bot[cc].y, w_se, acc[cc]);
+          for (int cc = 0; cc < CB; ++cc) {
+            acc[cc] = __builtin_fmaf(top[cc].x, w_nw, acc[cc]);
+            acc[cc] = __builtin_fmaf(top[cc].y, w_ne, acc[cc]);
+            acc[cc] = __builtin_fmaf(bot[cc].x, w_sw, acc[cc]);
+            acc[cc] = __builtin_fmaf(bot[cc].y, w_se, acc[cc]);
+          }
         }
         if (__ballot(on & !interior) != 0) {
           // a tap on the border of its level (or a non-finite coordinate) somewhere in the wave: those lanes alone, corner by
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap
             const T aq = s == 0 ? alpha_2 : alpha_1;
 #pragma unroll
             for (int cc = 0; cc < CB; ++cc) {
-              const GlobalPtr<const T> pch = b + cc * plane;
+              const GlobalPtr<const T> pch = b + cc * plane; // (cc <= 3, plane <= kLeanMaxPlane)
               if (q.o_nw >= 0) acc[cc] += pch[q.o_nw] * q.nw * aq;
               if (q.o_ne >= 0) acc[cc] += pch[q.o_ne] * q.ne * aq;
               if (q.o_sw >= 0) acc[cc] += pch[q.o_sw] * q.sw * aq;
@@ -1856,15 +1862,22 @@ __global__ __launch_bounds__(kMipBlock, CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_
           }
         }
         // ---- grid gradient: texels of the (interior) tap; d/dx of the bilinear form = differences of texels
-        const int plane = w * h; // < 2^31 (fill_table)
-        const int o_top = interior ? iy_nw * w + ix_nw : 0;
-        const int o_bot = interior ? o_top + w : 0;
+        const int plane = w * h; // <= kLeanMaxPlane (the dispatch): c * plane + offset fits 32 bits
         const GlobalPtr<const T> inp = (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d]) + int64_t(n) * s_sn[d]) + int64_t(c0) * plane;
+        // (round 6: the loads run under `interior`, one exec-mask region -- the lanes without an interior tap used to load the
+        // pair at offset 0 of their level: on a 1 x 1 level, one element beyond the last channel of the last view.  What
+        // their registers hold instead is never used: g[c] is zero on those lanes)
+        const int o_top = iy_nw * w + ix_nw;
+        const int o_bot = o_top + w;
         Pair<T> top[CN], bot[CN];
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
-          top[c] = bot[c] = Pair<T>{T(0), T(0)};
-          if (!DRTK_DBG(dbg, 2)) {
+          top[c] = __builtin_nondeterministic_value(top[c]);
+          bot[c] = __builtin_nondeterministic_value(bot[c]);
+        }
+        if (interior && !DRTK_DBG(dbg, 2)) {
+#pragma unroll
+          for (int c = 0; c < CN; ++c) {
             top[c] = *(GlobalPtr<const Pair<T>>)(inp + (c * plane + o_top));
             bot[c] = *(GlobalPtr<const Pair<T>>)(inp + (c * plane + o_bot));
           }
@@ -1914,7 +1927,7 @@ __global__ __launch_bounds__(kMipBlock, CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_
                 }
               }
               if (interior) continue; // (its grid gradient is in the straight line above)
-              const GlobalPtr<const T> pch = inp + c * plane;
+              const GlobalPtr<const T> pch = inp + c * plane; // (c <= 3, plane <= kLeanMaxPlane)
               T v_nw = T(0), v_ne = T(0), v_sw = T(0), v_se = T(0);
               if (!DRTK_DBG(dbg, 2)) {
                 if (q.o_nw >= 0) v_nw = pch[q.o_nw];
@@ -2790,6 +2803,16 @@ int fill_table(
   return DRTK_OK;
 }
 
+// The lean kernels address a texel as `channel_in_block * plane + offset` in 32 bits (at most three planes + one): levels
+// beyond this size (a 23 170^2 level) take the general kernels, whose plane offsets are 64-bit.
+constexpr int64_t kLeanMaxPlane = ((int64_t(1) << 31) - 1) / 4;
+bool lean_planes_ok(const LevelTable& lv, int mipmaps) {
+  for (int i = 0; i < mipmaps; ++i) {
+    if (int64_t(lv.h[i]) * lv.w[i] > kLeanMaxPlane) return false;
+  }
+  return true;
+}
+
 // grid_layout = {sN, sP, sC} in elements (NULL: contiguous [N,H,W,2]); the pair access needs sC = 1, even strides and a
 // base aligned to two elements
 int make_grid_layout(GridLayout& gl, const int64_t* layout, const void* base, int64_t H, int64_t W, size_t elem) {
@@ -2842,7 +2865,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
       H * W, max_aniso, force_max_aniso != 0, clip_grad != 0, static_cast<float*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
 #define LAUNCH_LC(PAD)                                                                    \
   if (C % 4 == 0) LAUNCH_L(PAD, 4); else if (C % 3 == 0) LAUNCH_L(PAD, 3); else if (C % 2 == 0) LAUNCH_L(PAD, 2); else LAUNCH_L(PAD, 1)
-  if (dtype == DRTK_F32 && interpolation_mode == 0 && padding_mode != 2 && N <= kMaxViewsPerLaunch && DRTK_MIP_FWD_LEAN) {
+  if (dtype == DRTK_F32 && interpolation_mode == 0 && padding_mode != 2 && N <= kMaxViewsPerLaunch && DRTK_MIP_FWD_LEAN && lean_planes_ok(lv, mipmaps)) {
     if (padding_mode == 0) { LAUNCH_LC(0); } else { LAUNCH_LC(1); }
   } else if (dtype == DRTK_F32) {
     if (interpolation_mode == 0) { LAUNCH(float, 0); } else { LAUNCH(float, 2); }
@@ -2904,7 +2927,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
 #endif
     if constexpr (sizeof(T) == 4 && DRTK_MIP_BWD_LEAN) {
       if (interpolation_mode == 0 && padding_mode != 2 && C >= 1 && N <= 65535 && !DRTK_DBG(debug_flags(), 512) &&
-          (C <= 4 || DRTK_MIP_BWD_LEAN_WIDE)) { // float, bilinear, zeros / border padding: the lean tap loop, four channels a launch
+          (C <= 4 || DRTK_MIP_BWD_LEAN_WIDE) && lean_planes_ok(lv, mipmaps)) { // float, bilinear, zeros / border padding: the lean tap loop, four channels a launch
         const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
 #define LEANK(PAD, ALIGN, CN)                                                                                           \
   DRTK_LAUNCH(                                                                                                          \

@@ -816,7 +816,9 @@ using TriOwn = TriRow<T>;
 // reference's (rasterize_kernel.cu:117-161), evaluated per lane = per pixel.
 // STRIDE = lanes that share the triangle: 16 (one DPP row per triangle, `lane16_half` = lane % 16 + 1/2) or the whole
 // workgroup (cooperative pass over a large triangle, `lane16_half` = thread id + 1/2).
-template <typename T, int TILE_SHIFT, bool EARLY_Z, int STRIDE = 16>
+// FM (round 6; before: a second library built with -DDRTK_DEPTH_FASTMATH_ORDER): the order of the depth sum, chosen per
+// LAUNCH from the library's depth-order setting (drtk_amd_set_depth_order / DRTK_AMD_DEPTH_ORDER, include/drtk_amd.h).
+template <typename T, int TILE_SHIFT, bool EARLY_Z, bool FM, int STRIDE = 16>
 __device__ __forceinline__ void shade_rows(
     const TriRow<T>& u, float lane16_half, float x0f, float y0f, unsigned long long* __restrict__ zbuf, int dbg) {
   constexpr float kTileF = static_cast<float>(1 << TILE_SHIFT);
@@ -881,28 +883,25 @@ __device__ __forceinline__ void shade_rows(
     // unconditionally; whether any lane needs the IEEE fallback (operands outside the guarded range: denormal
     // quotients, an all-ones significand) is ONE wave-uniform test per pass instead of a divergent branch per
     // division -- the fallback itself is exact_div / exact_rcp
-    const T q0 = b0 * u.rdenom, q1 = b1 * u.rdenom, q2 = b2 * u.rdenom;
-    const bool fast_ok = div_ok & (min3(b0, b1, b2) >= b_min);
-    T d0 = markstein2(b0, u.abs_denom, u.rdenom, q0);
-    T d1 = markstein2(b1, u.abs_denom, u.rdenom, q1);
-    T d2 = markstein2(b2, u.abs_denom, u.rdenom, q2);
-    if (__ballot(!fast_ok) != 0) {
-      d0 = exact_div(b0, u.abs_denom, u.rdenom, div_ok);
-      d1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
-      d2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
+    T d0 = T(0), d1 = T(0), d2 = T(0);
+    if constexpr (!FM) {
+      const T q0 = b0 * u.rdenom, q1 = b1 * u.rdenom, q2 = b2 * u.rdenom;
+      const bool fast_ok = div_ok & (min3(b0, b1, b2) >= b_min);
+      d0 = markstein2(b0, u.abs_denom, u.rdenom, q0);
+      d1 = markstein2(b1, u.abs_denom, u.rdenom, q1);
+      d2 = markstein2(b2, u.abs_denom, u.rdenom, q2);
+      if (__ballot(!fast_ok) != 0) {
+        d0 = exact_div(b0, u.abs_denom, u.rdenom, div_ok);
+        d1 = exact_div(b1, u.abs_denom, u.rdenom, div_ok);
+        d2 = exact_div(b2, u.abs_denom, u.rdenom, div_ok);
+      }
     }
-#ifdef DRTK_DEPTH_FASTMATH_ORDER
-    // Build variant (python drtk_amd/build.py --depth-order fastmath; never the default): the depth as the reference's
-    // host path evaluates it WHEN BUILT WITH ITS OWN FLAGS (setup.py:22-24: -O3 --fast-math, GCC 11.4 on x86-64; SURVEY
-    // App. A.1 step 8, from the disassembly): one IEEE reciprocal r = 1 / |den| per triangle and
-    // s = ((e1 dinv1 + e0 dinv0) + e2 dinv2) r  instead of three quotients e_k / |den| -- the last bits of 40 % of the
-    // depths move, and with them the owner of a handful of near-tie pixels per view
-    // (tests/golden/fastmath_owner_changes_*.npz).  No FMA there either.
-    (void)d0, (void)d1, (void)d2;
-    const T depth_inverse = ((b1 * u.dinv1 + b0 * u.dinv0) + b2 * u.dinv2) * u.rdenom;
-#else
-    const T depth_inverse = u.dinv0 * d0 + u.dinv1 * d1 + u.dinv2 * d2;
-#endif
+    // FM: the depth as the reference's host path evaluates it WHEN BUILT WITH ITS OWN FLAGS (setup.py:22-24: -O3
+    // --fast-math, GCC 11.4 on x86-64; SURVEY App. A.1 step 8, from the disassembly): one IEEE reciprocal r = 1 / |den|
+    // per triangle and  s = ((e1 dinv1 + e0 dinv0) + e2 dinv2) r  instead of three quotients e_k / |den| -- the last bits
+    // of 40 % of the depths move, and with them the owner of a handful of near-tie pixels per view
+    // (tests/golden/fastmath_owner_changes_*.npz).  No FMA there either.  !FM (the default): the source order, strict.
+    const T depth_inverse = FM ? ((b1 * u.dinv1 + b0 * u.dinv0) + b2 * u.dinv2) * u.rdenom : u.dinv0 * d0 + u.dinv1 * d1 + u.dinv2 * d2;
     // epsclamp (:153) of a value that cannot be negative: every d_k is a quotient of b_k >= 0 (the fragment passed the
     // coverage test) and abs_denom > 0, every dinv_k is 1 / z_k with z_k > 1e-8 (the near-plane cull, :96) -- so only the
     // `v > eps ? v : eps` branch of the clamp exists here (a NaN sum takes eps there as well)
@@ -916,7 +915,7 @@ __device__ __forceinline__ void shade_rows(
 }
 
 // Rasterize the triangles held one per lane (own-lane state `o`): `nsteps` steps, step k = lane k of every row.
-template <typename T, int TILE_SHIFT, bool EARLY_Z>
+template <typename T, int TILE_SHIFT, bool EARLY_Z, bool FM>
 __device__ __forceinline__ void raster_rows(
     const TriOwn<T>& o, int nsteps, int x0, int y0, unsigned long long* __restrict__ zbuf, int dbg) {
   const float x0f = static_cast<float>(x0), y0f = static_cast<float>(y0);
@@ -931,7 +930,7 @@ __device__ __forceinline__ void raster_rows(
       default: u = row_bcast_tri<15>(o); break;
 #undef DRTK_ROW_STEP
     }
-    shade_rows<T, TILE_SHIFT, EARLY_Z>(u, lane16_half, x0f, y0f, zbuf, dbg);
+    shade_rows<T, TILE_SHIFT, EARLY_Z, FM>(u, lane16_half, x0f, y0f, zbuf, dbg);
   }
 }
 
@@ -975,7 +974,7 @@ constexpr int kCoopMin = DRTK_RASTER_COOP_MIN, kCoopMinDense = DRTK_RASTER_COOP_
 constexpr int kCoopBatch = 64; // triangles set up together, one per lane of the waves' first lanes, and parked in LDS
 constexpr int kCoopMax = 256; // entries per item and phase; what does not fit takes the ordinary path
 
-template <typename T, int TILE_SHIFT>
+template <typename T, int TILE_SHIFT, bool FM>
 __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile_raster_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, int F, int64_t V, int64_t vi_sN,
     int H, int W, int tiles_x, int tiles_per_view, const int32_t* __restrict__ tile_offset,
@@ -1242,9 +1241,9 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
           const TriOwn<T> own = make_row_state<T>(valid, s, f, z_lo, x0, y0, x1, y1);
           if (!DRTK_DBG(dbg, 1)) {
             if (phase == 0) {
-              raster_rows<T, TILE_SHIFT, false>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
+              raster_rows<T, TILE_SHIFT, false, FM>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
             } else {
-              raster_rows<T, TILE_SHIFT, true>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
+              raster_rows<T, TILE_SHIFT, true, FM>(own, (cnt + 3) >> 2, x0, y0, zbuf, dbg);
             }
           }
         }
@@ -1283,9 +1282,9 @@ __global__ __launch_bounds__(kRasterBlock, raster_waves_per_simd<T>()) void tile
               __builtin_memcpy(&u, w, sizeof(u));
               if (!DRTK_DBG(dbg, 1)) {
                 if (phase == 0) {
-                  shade_rows<T, TILE_SHIFT, false, kRasterBlock>(u, first, x0f, y0f, zbuf, dbg);
+                  shade_rows<T, TILE_SHIFT, false, FM, kRasterBlock>(u, first, x0f, y0f, zbuf, dbg);
                 } else {
-                  shade_rows<T, TILE_SHIFT, true, kRasterBlock>(u, first, x0f, y0f, zbuf, dbg);
+                  shade_rows<T, TILE_SHIFT, true, FM, kRasterBlock>(u, first, x0f, y0f, zbuf, dbg);
                 }
               }
             }
@@ -1456,17 +1455,18 @@ int rasterize_impl(
   const int64_t resident = int64_t(num_compute_units()) * (raster_waves_per_simd<T>() / 2);
 #endif
   const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(L.max_items, resident));
+#define DRTK_RASTER_LAUNCH(SHIFT, FM)                                                                              \
+  DRTK_LAUNCH(                                                                                                    \
+      (tile_raster_kernel<T, SHIFT, FM>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,   \
+      (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,    \
+      big_list, tri_range, tri_pre, items, queue, depth_img, index_img, debug_flags())
+  const bool fm = depth_order_setting() == DRTK_DEPTH_ORDER_FASTMATH;
   if (L.tile_shift == 6) {
-    DRTK_LAUNCH(
-        (tile_raster_kernel<T, 6>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
-        (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,
-        big_list, tri_range, tri_pre, items, queue, depth_img, index_img, debug_flags());
+    if (fm) DRTK_RASTER_LAUNCH(6, true); else DRTK_RASTER_LAUNCH(6, false);
   } else {
-    DRTK_LAUNCH(
-        (tile_raster_kernel<T, 5>), dim3(blocks), dim3(kRasterBlock), 0, stream, v, vi, (int)F, V, vi_sN,
-        (int)H, (int)W, L.tiles_x, (int)L.tiles_per_view, tile_offset, tile_count, view_stats, pairs, big_count,
-        big_list, tri_range, tri_pre, items, queue, depth_img, index_img, debug_flags());
+    if (fm) DRTK_RASTER_LAUNCH(5, true); else DRTK_RASTER_LAUNCH(5, false);
   }
+#undef DRTK_RASTER_LAUNCH
   DRTK_RETURN_IF_LAUNCH_FAILED();
   return DRTK_OK;
 }

@@ -47,7 +47,7 @@
  *     sqrt (cuda_math_helper.h:173-176).  Expect differences of 2 * max_dp_dr at a few such silhouette pixels when
  *     comparing against those (about 1 in 150 of the small two-object float32 test scenes has one); against the
  *     strict evaluation there are none (profiles/NOTES.md section 3).
- *   - thread-safety: re-entrant; no global mutable state.
+ *   - thread-safety: re-entrant; no global mutable state except the rasterizer's depth-order setting (one atomic int).
  */
 #ifndef DRTK_AMD_H
 #define DRTK_AMD_H
@@ -92,14 +92,26 @@ const char* drtk_amd_version(void);
  * wins depth ties) and depth_img (ALWAYS float32, 0 where empty, rasterize_kernel.cu:481) --
  * bit-exact with the reference's arithmetic (rasterize_kernel.cu:69-166).
  * The depth's summation order is the one the reference's source spells, evaluated strictly.  A reference
- * build compiled with -ffast-math may associate that sum differently; libdrtk_amd_depth_fastmath.so
- * (same ABI, `python drtk_amd/build.py --depth-order fastmath`) evaluates it in the order such a build
- * was observed to use, for deployments that must match one bit for bit.
+ * build compiled with -ffast-math (its setup.py:22-24) associates that sum differently: the library's DEPTH-ORDER
+ * SETTING (drtk_amd_set_depth_order below, or DRTK_AMD_DEPTH_ORDER=fastmath in the environment) makes every later
+ * rasterize call evaluate it in the order such a build was observed to use, for deployments that must match one bit
+ * for bit.
  * `workspace` holds the tile bins; query its size first.
  * `wireframe != 0` selects the line mode (rasterize_kernel.cu:170-400: edges whose bit is set in the top
  * nibble of vi[...,0] are drawn by the diamond rule, the triangles themselves only occlude); it needs the
  * workspace of drtk_amd_rasterize_lines_workspace_bytes (a packed [N,H,W] 64-bit buffer) instead.
  */
+typedef enum {
+  DRTK_DEPTH_ORDER_STRICT = 0,  /* s = dinv0 (e0/|den|) + dinv1 (e1/|den|) + dinv2 (e2/|den|): rasterize_kernel.cu:148-153 as written */
+  DRTK_DEPTH_ORDER_FASTMATH = 1 /* s = ((e1 dinv1 + e0 dinv0) + e2 dinv2) (1/|den|): the host build of setup.py:22-24 (-O3 --fast-math) */
+} drtk_depth_order_t;
+/* The one library-level setting (everything else is re-entrant and stateless): which of the two orders
+ * drtk_amd_rasterize launches from now on.  Initial value: DRTK_DEPTH_ORDER_FASTMATH if the environment holds
+ * DRTK_AMD_DEPTH_ORDER=fastmath when the setting is first read or written, else DRTK_DEPTH_ORDER_STRICT.  The torch
+ * operators (torch.ops.rasterize_ext.rasterize, drtk.rasterize) call the same entry point and follow it.
+ * Set it before the first rasterize call of a deployment; a change is atomic and affects later launches only. */
+int drtk_amd_set_depth_order(int order); /* DRTK_OK, or DRTK_ERR_INVALID_ARGUMENT for anything but the two values */
+int drtk_amd_get_depth_order(void);      /* a drtk_depth_order_t */
 int drtk_amd_rasterize_workspace_bytes(int64_t N, int64_t F, int64_t H, int64_t W, size_t* bytes);
 int drtk_amd_rasterize_lines_workspace_bytes(int64_t N, int64_t H, int64_t W, size_t* bytes);
 int drtk_amd_rasterize(

@@ -429,36 +429,53 @@ def test_full_size_index_img_and_the_committed_fast_math_owner_changes(mesh):
     assert float(rel.max()) <= 4 * 2.0 ** -23 and float(z["max_rel_depth_difference"]) <= 4e-7
 
 
+@pytest.mark.parametrize("route", ["capi", "drtk", "torch_ops_env"])
 @pytest.mark.parametrize("mesh", ["100k", "250k"])
-def test_depth_fastmath_variant_reproduces_the_reference_as_built(mesh):
-    """The offered build variant (drtk_amd/libdrtk_amd_depth_fastmath.so, capi.use_depth_order("fastmath")): index_img of a
-    full benchmark view equals the image of the reference compiled with its own `-O3 --fast-math` at ZERO differing
-    pixels (SHA-256 of the committed fixture; the listed owner changes are reproduced one by one), where the default
-    library is the strict image.  Runs in a child process: a process binds one library."""
+def test_depth_fastmath_variant_reproduces_the_reference_as_built(mesh, route):
+    """The rasterizer's depth-order setting (include/drtk_amd.h drtk_amd_set_depth_order; DRTK_AMD_DEPTH_ORDER): with
+    "fastmath" the index_img of a full benchmark view equals the image of the reference compiled with its own `-O3
+    --fast-math` at ZERO differing pixels (SHA-256 of the committed fixture; the listed owner changes are reproduced one
+    by one); the default is the strict image.  Three routes to the same library: the C ABI (ctypes), the drop-in
+    `import drtk` + `drtk_amd.set_depth_order`, and `torch.ops.rasterize_ext.rasterize` with nothing but the environment
+    variable.  The drop-in route also switches back and finds the strict image again.  Child process: the setting is per process."""
     import subprocess
 
+    call = {
+        "capi": 'from drtk_amd import capi\ncapi.use_depth_order("fastmath")\nrast = lambda v, vi, r: capi.rasterize(v, vi, r, r)',
+        "drtk": 'import drtk, drtk_amd\nassert drtk_amd.get_depth_order() == "strict"\ndrtk_amd.set_depth_order("fastmath")\nrast = lambda v, vi, r: drtk.rasterize_with_depth(v, vi, r, r)',
+        "torch_ops_env": 'import drtk_amd\nassert drtk_amd.get_depth_order() == "fastmath"\nrast = lambda v, vi, r: th.ops.rasterize_ext.rasterize(v, vi[None].expand(1, -1, -1), r, r, False)',
+    }[route]
     code = f"""
 import hashlib, sys
 import numpy as np, torch as th
 sys.path.insert(0, {ROOT!r})
-from drtk_amd import capi, synthetic as S
-capi.use_depth_order("fastmath")
+from drtk_amd import synthetic as S
+{call}
 z = np.load({GOLDEN_DIR!r} + "/fastmath_owner_changes_{mesh}.npz")
 res = int(z["res"])
 nl, no = S.MESH_SIZES[{mesh!r}]
 _, vi = S.uv_sphere(nl, no, lobes=0.05)
 v = th.from_numpy(z["v"])[None].cuda()
-d, i = capi.rasterize(v, vi.cuda(), res, res)
+d, i = rast(v, vi.cuda(), res)
 i, d = i.cpu(), d.cpu()
 sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
 px = th.from_numpy(z["pixels"])
 diff = int((i.flatten()[px] != th.from_numpy(z["index_fast"])).sum())
-print("RESULT", sha(i) == str(z["sha256_index_fast"]), diff, bool(th.equal(d.flatten()[px], th.from_numpy(z["depth_fast"]))), int((i >= 0).sum()) == int(z["covered"]))
+back = True
+if {route!r} == "drtk":
+    drtk_amd.set_depth_order("strict")
+    i2 = drtk.rasterize(v, vi.cuda(), res, res).cpu()
+    back = bool(th.equal(i2.flatten()[px], th.from_numpy(z["index_strict"]))) and sha(i2) == str(z["sha256_index_strict"])
+print("RESULT", sha(i) == str(z["sha256_index_fast"]), diff, bool(th.equal(d.flatten()[px], th.from_numpy(z["depth_fast"]))), int((i >= 0).sum()) == int(z["covered"]), back)
 """
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    env.pop("DRTK_AMD_DEPTH_ORDER", None)
+    if route == "torch_ops_env":
+        env["DRTK_AMD_DEPTH_ORDER"] = "fastmath"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
-    assert line[1:] == ["True", "0", "True", "True"], f"index hash equal / differing listed pixels / depths at them equal / coverage equal: {line[1:]}"
+    assert line[1:] == ["True", "0", "True", "True", "True"], f"index hash equal / differing listed pixels / depths at them equal / coverage equal / strict again after switching back: {line[1:]}"
 
 
 def rel_at(mask, a, b):

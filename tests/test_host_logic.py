@@ -86,6 +86,47 @@ def test_c_abi_argument_validation_without_gpu():
         assert call(4096 + 4, big) == -1
 
 
+def test_depth_order_setting_is_one_library_level_switch_shared_by_every_route():
+    """include/drtk_amd.h drtk_amd_set_depth_order / drtk_amd_get_depth_order: no GPU needed for the setting itself.  The C
+    ABI handle, drtk_amd.set_depth_order and the library the torch-operator shim links are ONE library object per process;
+    the initial value follows DRTK_AMD_DEPTH_ORDER; invalid values are rejected.  (Child processes: the setting is global.)"""
+    import subprocess
+
+    code = f"""
+import ctypes, os, sys
+sys.path.insert(0, {ROOT!r})
+import drtk_amd
+from drtk_amd import capi
+L = ctypes.CDLL(os.path.join({ROOT!r}, "drtk_amd", "libdrtk_amd.so"))
+first = drtk_amd.get_depth_order()
+assert capi.depth_order() == first and L.drtk_amd_get_depth_order() == {{"strict": 0, "fastmath": 1}}[first]
+assert L.drtk_amd_set_depth_order(2) == -1 and L.drtk_amd_set_depth_order(-1) == -1 and drtk_amd.get_depth_order() == first
+other = "strict" if first == "fastmath" else "fastmath"
+drtk_amd.set_depth_order(other)
+assert capi.depth_order() == other and L.drtk_amd_get_depth_order() == {{"strict": 0, "fastmath": 1}}[other]
+capi.use_depth_order(first)
+assert drtk_amd.get_depth_order() == first
+try:
+    drtk_amd.set_depth_order("fast")
+    raise SystemExit("accepted an unknown order")
+except ValueError:
+    pass
+# the operator shim resolves its C-ABI calls in the same library object (one mapping of libdrtk_amd.so in the process)
+maps = [l.split()[-1] for l in open("/proc/self/maps") if "libdrtk_amd" in l]
+assert len(set(maps)) == 1, set(maps)
+print("FIRST", first)
+"""
+    for env_value, want in ((None, "strict"), ("fastmath", "fastmath"), ("strict", "strict"), ("nonsense", "strict")):
+        env = dict(os.environ)
+        env.pop("DRTK_AMD_DEPTH_ORDER", None)
+        if env_value is not None:
+            env["DRTK_AMD_DEPTH_ORDER"] = env_value
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split()[-2:] == ["FIRST", want], (env_value, r.stdout)
+    assert not os.path.exists(os.path.join(ROOT, "drtk_amd", "libdrtk_amd_depth_fastmath.so")), "the second library of rounds 4-5 is gone: one library, one setting"
+
+
 def test_torch_operator_schemas_match_reference():
     import drtk_amd  # noqa: F401  (loads the library)
 
