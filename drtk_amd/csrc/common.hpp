@@ -73,6 +73,51 @@ __device__ __forceinline__ void atomic_add_global(T* p, T v) {
   unsafeAtomicAdd(p, v);
 }
 
+// Wave-aggregated "+1" on counters[key] for the lanes with `on` set: lanes of a wave that hit the same
+// counter (consecutive triangles of a mesh mostly land in the same few tiles) are merged into ONE
+// atomic by their first lane.  With FETCH each lane gets its own slot (old value + rank).
+template <bool FETCH>
+__device__ __forceinline__ int wave_agg_inc(int32_t* __restrict__ counters, int key, bool on) {
+  const int lane = lane_id();
+  unsigned long long todo = __ballot(on);
+  int pos = 0;
+  while (todo) {
+    const int leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+    const int k = __builtin_amdgcn_readlane(key, leader);
+    const bool mine = on && key == k;
+    const unsigned long long same = __ballot(mine);
+    int base = 0;
+    if (lane == leader) {
+      const int cnt = __popcll(same);
+      if (FETCH) {
+        base = atomicAdd(counters + k, cnt);
+      } else {
+        atomicAdd(counters + k, cnt);
+      }
+    }
+    if (FETCH) {
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (mine) pos = base + __popcll(same & ((1ull << lane) - 1ull));
+    }
+    todo &= ~same;
+  }
+  return pos;
+}
+
+
+// Four consecutive elements as ONE non-temporal 16 / 32-byte load or store (`nt`: data this launch touches once).
+// (__builtin_nontemporal_* take clang vector types, not HIP's struct wrappers.)
+template <typename T>
+using NtQuad = T __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ NtQuad<T> nt_load4(const T* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const NtQuad<T>*>(p));
+}
+template <typename T>
+__device__ __forceinline__ void nt_store4(T* p, T a, T b, T c, T d) {
+  __builtin_nontemporal_store(NtQuad<T>{a, b, c, d}, reinterpret_cast<NtQuad<T>*>(p));
+}
+
 // XCD-aware workgroup -> tile order.  The dispatcher deals workgroups round-robin to the 8 XCDs (block b
 // runs on XCD b % 8), each with its own L2.  If block b simply takes tile b of an image whose channel
 // planes are a power of two apart, every XCD only ever sees one residue class of 4 KB pieces, and all C

@@ -75,47 +75,79 @@ __global__ __launch_bounds__(kBlock) void interpolation_matrix_backward_kernel(
   for (int k = 0; k < 3; ++k) gp[int64_t(order[k]) * HW] = grad_values[row * 3 + k];
 }
 
-// values[pair[n,tri,3i+j]] += b_i * b_j : wave = 64 pixels of one view, runs of equal triangle are
-// summed in registers (segscatter, 9 "pairs" per pixel) and flushed with one atomic per run and entry.
+// values[pair[n,tri,3i+j]] += b_i * b_j.  Round 6 (rounds 2-5: the products staged in LDS, summed per run of equal triangle
+// along a row and flushed with nine single-float atomics PER RUN -- 24 M scattered atomic requests on the bench views, which
+// is what the kernel cost: 1.10 ms, 0.07 of the HBM peak on its 19 B/px): render backward's scheme.  A workgroup owns a
+// 64 x 16 pixel tile, each wave 4 adjacent rows; lane = pixel; the SIX distinct products of a pixel (b_i b_j == b_j b_i
+// exactly) stay in registers, a segmented scan over the 16-lane rows leaves each run's sums in its last lane, which adds
+// them to a wave-private table keyed by TRIANGLE (double accumulators); the table is flushed once per 64 x 4 pixels with
+// the nine atomics of each triangle it holds -- a triangle costs nine requests per wave tile instead of nine per run.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void normal_matrix_values_kernel(
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) void normal_matrix_values_kernel(
     const int32_t* __restrict__ pair_indices, const int32_t* __restrict__ index_img,
-    const T* __restrict__ bary_img, int64_t pair_sN, int64_t HW, T* __restrict__ values) {
-  using V4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
+    const T* __restrict__ bary_img, int64_t pair_sN, int H, int W, int tiles_x, T* __restrict__ values, int strip) {
   constexpr int kWaves = kBlock / kWave;
-  __shared__ __attribute__((aligned(16))) T s_val[kWaves][9 * kRunPad];
-  __shared__ int32_t s_dst[kWaves][9 * kRunPad];
+  __shared__ int32_t t_keys[kWaves][kTableSlots];
+  __shared__ TableAcc t_vals[kWaves][kTableSlots * 6];
+  const int64_t HW = int64_t(H) * W;
   const int n = blockIdx.y;
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-  const int64_t pix = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-  const int32_t tr = pix < HW ? index_img[int64_t(n) * HW + pix] : -1;
-  T b[3] = {T(0), T(0), T(0)};
-  int32_t dst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (tr != -1) {
-    const T* bp = bary_img + int64_t(n) * 3 * HW + pix;
-    b[0] = bp[0], b[1] = bp[HW], b[2] = bp[2 * HW];
-    const int32_t* pr = pair_indices + int64_t(n) * pair_sN + int64_t(tr) * 9;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) dst[j] = pr[j];
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      s_val[wave][(i * 3 + j) * kRunPad + lane] = b[i] * b[j];
-      s_dst[wave][(i * 3 + j) * kRunPad + lane] = dst[i * 3 + j];
-    }
-  unsigned long long heads, cov;
-  run_masks(tr, heads, cov);
+  const int tile = tile_index(strip);
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int x = txi * kWave + lane;
+  const int32_t* pr_n = pair_indices + int64_t(n) * pair_sN;
+  table_init(t_keys[wave]);
+  for (int i = lane; i < kTableSlots * 6; i += kWave) t_vals[wave][i] = 0;
   wave_lds_sync();
-  if (cov == 0) return;
-  const T* sv = s_val[wave];
-  scatter_runs<T>(
-      heads, cov, nullptr, s_dst[wave], 9, 1, static_cast<TableAcc*>(nullptr), 0, values, 1, 0,
-      [sv](int k, int, int g4, T* x) {
-        const V4 q = *reinterpret_cast<const V4*>(sv + k * kRunPad + 4 * g4);
-        x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
-      });
+  auto load_tr = [&](int pass) -> int32_t {
+    const int yy = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
+    return (x < W && yy < H) ? index_img[int64_t(n) * HW + int64_t(yy) * W + x] : -1;
+  };
+  int32_t tr_next = load_tr(0);
+#pragma unroll 1
+  for (int pass = 0; pass < kTileRows / kWaves; ++pass) {
+    const int y = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
+    const int32_t tr = tr_next;
+    if (pass + 1 < kTileRows / kWaves) tr_next = load_tr(pass + 1);
+    if (__ballot(tr != -1) == 0) continue;
+    T g[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) g[j] = T(0);
+    if (tr != -1) {
+      const T* bp = bary_img + int64_t(n) * 3 * HW + int64_t(y) * W + x;
+      const T b0 = bp[0], b1 = bp[HW], b2 = bp[2 * HW];
+      g[0] = b0 * b0, g[1] = b0 * b1, g[2] = b0 * b2, g[3] = b1 * b1, g[4] = b1 * b2, g[5] = b2 * b2;
+    }
+    int dist;
+    bool tail;
+    run_rows16(tr, dist, tail);
+    run_sums_rows16<T, 6>(g, dist);
+    if (tail && tr != -1) {
+      const int slot = table_slot(t_keys[wave], tr);
+      if (slot >= 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) lds_atomic_add(t_vals[wave] + slot * 6 + j, static_cast<TableAcc>(g[j]));
+      } else { // the table has no room for this triangle: its nine entries directly
+        const int32_t* pr = pr_n + int64_t(tr) * 9;
+        constexpr int kSym[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+#pragma unroll
+        for (int j = 0; j < 9; ++j) atomic_add_global(values + pr[j], g[kSym[j]]);
+      }
+    }
+  }
+  wave_lds_sync();
+  for (int e = lane; e < kTableSlots * 9; e += kWave) {
+    const int s = e / 9, j = e - s * 9;
+    const int32_t key = t_keys[wave][s];
+    if (key >= 0) {
+      const int i3 = j / 3, j3 = j - i3 * 3;
+      const int lo = i3 < j3 ? i3 : j3, hi = i3 < j3 ? j3 : i3;
+      const int sym = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5); // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2) -> 0 .. 5
+      const T xv = static_cast<T>(t_vals[wave][s * 6 + sym]);
+      if (xv != T(0)) atomic_add_global(values + pr_n[int64_t(key) * 9 + j], xv);
+    }
+  }
 }
 
 template <typename T>
@@ -221,8 +253,9 @@ extern "C" int drtk_amd_interpolation_normal_matrix_values(
   }
   if (N * H * W == 0 || nnz == 0) return DRTK_OK;
   if (!pair_indices || !index_img || !bary_img) return DRTK_ERR_INVALID_ARGUMENT;
-  const dim3 grid(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N));
-#define CALL DRTK_LAUNCH((normal_matrix_values_kernel<T>), grid, dim3(kBlock), 0, s, pair_indices, index_img, static_cast<const T*>(bary_img), pair_sN, H * W, static_cast<T*>(values))
+  const int tiles_x = static_cast<int>(ceil_div(W, kWave)), tiles_y = static_cast<int>(ceil_div(H, kTileRows));
+  const dim3 grid(static_cast<unsigned>(int64_t(tiles_x) * tiles_y), static_cast<unsigned>(N));
+#define CALL DRTK_LAUNCH((normal_matrix_values_kernel<T>), grid, dim3(kBlock), 0, s, pair_indices, index_img, static_cast<const T*>(bary_img), pair_sN, (int)H, (int)W, tiles_x, static_cast<T*>(values), xcd_strip(int64_t(tiles_x) * (16 / kTileRows)))
   DRTK_DISPATCH(dtype, CALL, CALL)
 #undef CALL
   DRTK_RETURN_IF_LAUNCH_FAILED();

@@ -38,6 +38,10 @@ struct Vec4<double> {
 // pixels may run over the end of a row (each gets its own coordinates for the background sweep), the accesses need the
 // element's alignment only, and the last lane of a view whose pixel count is not a multiple of four goes pixel by pixel
 // (round 4; before, such images took one pixel per lane: 1.2x the time at 2048 x 2046).
+// (round 6: bounded to 4 waves per SIMD -- 128 registers -- the prefetching instantiation spills 30-38 of its 158)
+#ifndef DRTK_INTERP_FWD_NT
+#define DRTK_INTERP_FWD_NT 0 // 1: index / barycentric quads as non-temporal loads (A/B switch, round 6)
+#endif
 template <typename T, int VEC, int CV, bool PREFETCH = false, bool ANYW = false>
 __global__ __launch_bounds__(kBlock) void interpolate_kernel(
     const T* __restrict__ attrs, const int32_t* __restrict__ vi,
@@ -79,11 +83,17 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
       }
     }
   } else if constexpr (VEC == 4) {
+#if DRTK_INTERP_FWD_NT
+    const NtQuad<int32_t> t4 = nt_load4(idx_p);
+    tr[0] = t4.x, tr[1] = t4.y, tr[2] = t4.z, tr[3] = t4.w;
+    const NtQuad<T> a = nt_load4(bary_p), b = nt_load4(bary_p + HW), c = nt_load4(bary_p + 2 * HW);
+#else
     const int4 t4 = *reinterpret_cast<const int4*>(idx_p);
     tr[0] = t4.x, tr[1] = t4.y, tr[2] = t4.z, tr[3] = t4.w;
     const V4 a = *reinterpret_cast<const V4*>(bary_p);
     const V4 b = *reinterpret_cast<const V4*>(bary_p + HW);
     const V4 c = *reinterpret_cast<const V4*>(bary_p + 2 * HW);
+#endif
     B0[0] = a.x, B0[1] = a.y, B0[2] = a.z, B0[3] = a.w;
     B1[0] = b.x, B1[1] = b.y, B1[2] = b.z, B1[3] = b.w;
     B2[0] = c.x, B2[1] = c.y, B2[2] = c.z, B2[3] = c.w;
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
           if (pix0 + j < HW) o[j] = r[j];
       }
     } else {
-      *reinterpret_cast<V4*>(o) = V4{r0, r1, r2, r3};
+      *reinterpret_cast<V4*>(o) = V4{r0, r1, r2, r3}; // (non-temporal stores: 0.534 vs 0.538 ms, round 6 -- nothing)
     }
   };
 
@@ -577,6 +587,10 @@ __global__ __launch_bounds__(kBlock) void interpolate_backward_small_kernel(
 //     channels the previous group already took; phase 2 is channel-count agnostic (J = 3 cc lanes).  Rows of such a C
 //     are never whole 64-byte segments, so the run sums go through the workgroup's vertex table.
 //   * double (round 5): the same pipeline in chunks of CH = 8 channels (the registers of 16 floats), 8-byte buffer loads.
+#ifndef DRTK_INTERP_BWD_AUX
+#define DRTK_INTERP_BWD_AUX 2 // cache policy of the grad_out / bary plane loads: 2 = nt (each plane is read once per launch: 0.600 -> 0.581 ms
+                               // at C = 16, same box, round 6; 0 = default policy)
+#endif
 template <typename T, bool HAS_BARY, bool TABLE, int CH, bool ANYC>
 __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : CH == 8 || CH == 12 ? DRTK_INTERP_CH8_WAVES : ANYC && HAS_BARY ? DRTK_INTERP_ANYC_WAVES : 4)) void interpolate_backward_wide_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
@@ -673,9 +687,9 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : C
   auto plane_load = [&](const T* plane, uint32_t byte_offset, bool exists) -> T { // `exists`: wave-uniform (ANYC: a plane < C)
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(plane), 0, exists ? static_cast<int>(plane_bytes) : 0, 0x00020000);
     if constexpr (sizeof(T) == 4) {
-      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, byte_offset, 0, 0));
+      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, byte_offset, 0, DRTK_INTERP_BWD_AUX));
     } else {
-      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, byte_offset, 0, 0));
+      return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, byte_offset, 0, DRTK_INTERP_BWD_AUX));
     }
   };
   auto row_offset = [&](int ps) -> uint32_t { // beyond the plane for a lane off the canvas

@@ -146,6 +146,35 @@ __device__ __forceinline__ T reflect_coord(T in, int twice_low, int twice_high, 
   *grad_in = static_cast<T>(-mult);
   return span - extra + mn;
 }
+// reflect_coord for the lean kernels: the same value and multiplier, the long form only when a lane of the wave needs it.
+// With a = |in - low| < span no flip occurs: fmod(a, span) == a exactly and floor(a / span) == 0, so the reference's
+// `extra + low` is `a + low` -- two additions instead of an fmod, a division and a floor.  (Taps further than one texture
+// width beyond the border, or non-finite: the wave takes reflect_coord itself.)
+template <typename T>
+__device__ __forceinline__ T reflect_coord_lean(T in, int twice_low, int twice_high, T* grad_in) {
+  if (twice_low == twice_high) {
+    *grad_in = T(0);
+    return T(0);
+  }
+  const T mn = static_cast<T>(twice_low) / 2;
+  const T span = static_cast<T>(twice_high - twice_low) / 2;
+  T a = in - mn;
+  T m = T(1);
+  if (a < T(0)) m = T(-1), a = -a;
+  if (__ballot(!(a < span)) != 0) return reflect_coord(in, twice_low, twice_high, grad_in);
+  *grad_in = m;
+  return a + mn;
+}
+// ... followed by the clamp to the level (clip_coord: a clamped coordinate has a zero gradient), both axes of a tap
+template <typename T>
+__device__ __forceinline__ void reflect_clip_lean(T ixu, T iyu, int w, int h, bool align_corners, T& ix, T& iy, T& mx, T& my) {
+  T gx, gy;
+  const T rx = align_corners ? reflect_coord_lean(ixu, 0, 2 * (w - 1), &gx) : reflect_coord_lean(ixu, -1, 2 * w - 1, &gx);
+  const T ry = align_corners ? reflect_coord_lean(iyu, 0, 2 * (h - 1), &gy) : reflect_coord_lean(iyu, -1, 2 * h - 1, &gy);
+  const T wm1 = static_cast<T>(w - 1), hm1 = static_cast<T>(h - 1);
+  mx = ((rx > T(0)) & (rx < wm1)) ? mx * gx : T(0), my = ((ry > T(0)) & (ry < hm1)) ? my * gy : T(0);
+  ix = fminf(fmaxf(rx, T(0)), wm1), iy = fminf(fmaxf(ry, T(0)), hm1);
+}
 template <typename T>
 __device__ __forceinline__ T safe_int_range(T x) {
   if (x > static_cast<T>(INT32_MAX - 1) || x < static_cast<T>(INT32_MIN) || !isfinite(static_cast<double>(x)))
@@ -614,7 +643,7 @@ __global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap
     LevelTable lv, int mipmaps, const float* __restrict__ grid, GridLayout gl, const float* __restrict__ vt, int C,
     int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, float* __restrict__ out, int strip) {
   using T = float;
-  static_assert(PAD == 0 || PAD == 1, "zeros or border padding");
+  static_assert(PAD >= 0 && PAD <= 2, "zeros, border or reflection padding");
   static_assert(CB >= 1 && CB <= 4, "channels per sweep over the taps (C is a multiple of CB)");
   constexpr int padding = PAD;
   constexpr bool align_corners = false; // mipmap_grid_sampler_kernel.cu:423
@@ -680,14 +709,19 @@ __global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap
         // lanes that do not count -- no tap, a tap on or beyond the border, a NaN -- are finite and their products with
         // alpha = 0 vanish; those lanes' real contribution, if any, comes from the branch below.
         T ix = ((x + 1.f) * lwf[s] - 1) / 2, iy = ((y + 1.f) * lhf[s] - 1) / 2;
+        bool sane = true; // (reflection: a coordinate the short pipeline must not touch goes to the corner-by-corner branch)
         if (padding == 1) {
           ix = fminf(fmaxf(ix, T(0)), lwf[s] - T(1)), iy = fminf(fmaxf(iy, T(0)), lhf[s] - T(1)); // == clip_coord but NaN -> 0
+        } else if (padding == 2) {
+          sane = (fabsf(ix) < T(1e9f)) & (fabsf(iy) < T(1e9f)); // (false for NaN)
+          T unused_x = T(1), unused_y = T(1);
+          reflect_clip_lean<T>(sane ? ix : T(0), sane ? iy : T(0), lw[s], lh[s], align_corners, ix, iy, unused_x, unused_y);
         } else {
           ix = fminf(fmaxf(ix, T(-4)), T(2e9f)), iy = fminf(fmaxf(iy, T(-4)), T(2e9f));
         }
         const T fx_floor = floor(ix), fy_floor = floor(iy);
         const int ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
-        const bool interior = on & ordered & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(lw[s] - 1)) &
+        const bool interior = on & ordered & sane & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(lw[s] - 1)) &
             (static_cast<unsigned>(iy_nw) < static_cast<unsigned>(lh[s] - 1));
         // corner weights (bilinear_quad: (ix_se - ix) with ix_se = ix_nw + 1, an exact float) times the level's weight
         const T wx1 = (fx_floor + T(1)) - ix, wx0 = ix - fx_floor;
@@ -1552,12 +1586,14 @@ template <int CN>
 constexpr int lean_slot_cells() { return CN == 4 ? DRTK_MIP_T3_SLOT_CELLS4 : CN == 3 ? DRTK_MIP_T3_SLOT_CELLS : DRTK_MIP_T3_SLOT_CELLS12; }
 static_assert(DRTK_MIP_T3_SLOT_CELLS % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS4 % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS12 % 128 == 0, "whole rows at every slot width (16 ... 128 cells), cells in pairs");
 template <int PAD, bool ALIGN, int CN>
-__global__ __launch_bounds__(kMipBlock, CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_OCC4) void mipmap_backward_lean_kernel(
+// (reflection padding, round 6: the reflect + clip of both axes takes the kernel 2-4 registers over the 96 of five tiles per CU;
+// compiled for four -- 128 registers, no spill; the windows keep the five-tile size)
+__global__ __launch_bounds__(kMipBlock, PAD == 2 ? 4 : (CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_OCC4)) void mipmap_backward_lean_kernel(
     LevelTable lv, int mipmaps, const float* __restrict__ grad_out, const float* __restrict__ grid, GridLayout gl,
     const float* __restrict__ vt, int H, int W, int tiles_x, int max_aniso,
     bool force_max_aniso, bool clip_grad, float* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg, int C_total, int c0) {
   using T = float;
-  static_assert(PAD == 0 || PAD == 1, "zeros or border padding");
+  static_assert(PAD >= 0 && PAD <= 2, "zeros, border or reflection padding");
   static_assert(CN >= 1 && CN <= 4, "texture channels");
   constexpr int C = CN;
   constexpr int padding = PAD;
@@ -1819,15 +1855,19 @@ __global__ __launch_bounds__(kMipBlock, CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_
           mx = static_cast<T>(w) / 2, my = static_cast<T>(h) / 2;
         }
         T ix, iy;
+        bool sane = true; // (reflection: a coordinate the short pipeline must not touch goes to the corner-by-corner branch)
         if (padding == 1) { // clip_coord: clamped coordinates have a zero gradient
           mx = ((ixu > T(0)) & (ixu < wm1)) ? mx : T(0), my = ((iyu > T(0)) & (iyu < hm1)) ? my : T(0);
           ix = fminf(fmaxf(ixu, T(0)), wm1), iy = fminf(fmaxf(iyu, T(0)), hm1);
+        } else if (padding == 2) { // reflect_coord, then clip_coord (source_index's order)
+          sane = (fabsf(ixu) < T(1e9f)) & (fabsf(iyu) < T(1e9f));
+          reflect_clip_lean<T>(sane ? ixu : T(0), sane ? iyu : T(0), w, h, align_corners, ix, iy, mx, my);
         } else { // (made finite; a tap whose cell lies inside the level is not moved)
           ix = fminf(fmaxf(ixu, T(-4)), T(2e9f)), iy = fminf(fmaxf(iyu, T(-4)), T(2e9f));
         }
         const T fx_floor = floor(ix), fy_floor = floor(iy);
         const int ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
-        const bool interior = on & ordered & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(w - 1)) &
+        const bool interior = on & ordered & sane & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(w - 1)) &
             (static_cast<unsigned>(iy_nw) < static_cast<unsigned>(h - 1));
         const T wx1 = (fx_floor + T(1)) - ix, wx0 = ix - fx_floor, wy1 = (fy_floor + T(1)) - iy, wy0 = iy - fy_floor;
         const int l = d - ref;
@@ -2035,15 +2075,20 @@ __global__ __launch_bounds__(kMipBlock, CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_
       ixu = ((x + 1.f) * static_cast<T>(w) - 1) / 2, iyu = ((y + 1.f) * static_cast<T>(h) - 1) / 2;
     }
     T ix, iy;
+    bool sane = true;
     if (padding == 1) {
       ix = fminf(fmaxf(ixu, T(0)), wm1), iy = fminf(fmaxf(iyu, T(0)), hm1);
+    } else if (padding == 2) {
+      sane = (fabsf(ixu) < T(1e9f)) & (fabsf(iyu) < T(1e9f));
+      T unused_x = T(1), unused_y = T(1);
+      reflect_clip_lean<T>(sane ? ixu : T(0), sane ? iyu : T(0), w, h, align_corners, ix, iy, unused_x, unused_y);
     } else {
       ix = fminf(fmaxf(ixu, T(-4)), T(2e9f)), iy = fminf(fmaxf(iyu, T(-4)), T(2e9f));
     }
     const T fx_floor = floor(ix), fy_floor = floor(iy);
     ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
     wx1 = (fx_floor + T(1)) - ix, wx0 = ix - fx_floor, wy1 = (fy_floor + T(1)) - iy, wy0 = iy - fy_floor;
-    return ((x == x) & (y == y)) & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(w - 1)) & (static_cast<unsigned>(iy_nw) < static_cast<unsigned>(h - 1));
+    return sane & ((x == x) & (y == y)) & (static_cast<unsigned>(ix_nw) < static_cast<unsigned>(w - 1)) & (static_cast<unsigned>(iy_nw) < static_cast<unsigned>(h - 1));
   };
   // how many taps away from one of its taps a pixel can have another one inside the same window (<= 128 cells wide and
   // high): the taps are equally spaced, 2 / (n + 1) of (du, dv) apart -- on the coarser of the pixel's levels half as many
@@ -2865,8 +2910,8 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
       H * W, max_aniso, force_max_aniso != 0, clip_grad != 0, static_cast<float*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
 #define LAUNCH_LC(PAD)                                                                    \
   if (C % 4 == 0) LAUNCH_L(PAD, 4); else if (C % 3 == 0) LAUNCH_L(PAD, 3); else if (C % 2 == 0) LAUNCH_L(PAD, 2); else LAUNCH_L(PAD, 1)
-  if (dtype == DRTK_F32 && interpolation_mode == 0 && padding_mode != 2 && N <= kMaxViewsPerLaunch && DRTK_MIP_FWD_LEAN && lean_planes_ok(lv, mipmaps)) {
-    if (padding_mode == 0) { LAUNCH_LC(0); } else { LAUNCH_LC(1); }
+  if (dtype == DRTK_F32 && interpolation_mode == 0 && N <= kMaxViewsPerLaunch && DRTK_MIP_FWD_LEAN && lean_planes_ok(lv, mipmaps)) {
+    if (padding_mode == 0) { LAUNCH_LC(0); } else if (padding_mode == 1) { LAUNCH_LC(1); } else { LAUNCH_LC(2); }
   } else if (dtype == DRTK_F32) {
     if (interpolation_mode == 0) { LAUNCH(float, 0); } else { LAUNCH(float, 2); }
   } else {
@@ -2926,7 +2971,7 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
 #define DRTK_MIP_BWD_LEAN_WIDE 1 // C > 4: the lean tile kernel once per block of four channels instead of the wave-private kernel
 #endif
     if constexpr (sizeof(T) == 4 && DRTK_MIP_BWD_LEAN) {
-      if (interpolation_mode == 0 && padding_mode != 2 && C >= 1 && N <= 65535 && !DRTK_DBG(debug_flags(), 512) &&
+      if (interpolation_mode == 0 && C >= 1 && N <= 65535 && !DRTK_DBG(debug_flags(), 512) &&
           (C <= 4 || DRTK_MIP_BWD_LEAN_WIDE) && lean_planes_ok(lv, mipmaps)) { // float, bilinear, zeros / border padding: the lean tap loop, four channels a launch
         const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
 #define LEANK(PAD, ALIGN, CN)                                                                                           \
@@ -2945,9 +2990,9 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
         for (int c0 = 0; c0 < C; c0 += 4) {
           const int cn = static_cast<int>(C - c0 < 4 ? C - c0 : 4);
           if (align_corners) {
-            if (padding_mode == 0) { LEANC(0, true) } else { LEANC(1, true) }
+            if (padding_mode == 0) { LEANC(0, true) } else if (padding_mode == 1) { LEANC(1, true) } else { LEANC(2, true) }
           } else {
-            if (padding_mode == 0) { LEANC(0, false) } else { LEANC(1, false) }
+            if (padding_mode == 0) { LEANC(0, false) } else if (padding_mode == 1) { LEANC(1, false) } else { LEANC(2, false) }
           }
           DRTK_RETURN_IF_LAUNCH_FAILED();
         }

@@ -391,37 +391,7 @@ inline BinLayout make_layout(int64_t N, int64_t F, int64_t H, int64_t W) {
   return L;
 }
 
-// Wave-aggregated "+1" on counters[key] for the lanes with `on` set: lanes of a wave that hit the same
-// counter (consecutive triangles of a mesh mostly land in the same few tiles) are merged into ONE
-// atomic by their first lane.  With FETCH each lane gets its own slot (old value + rank).
-template <bool FETCH>
-__device__ __forceinline__ int wave_agg_inc(int32_t* __restrict__ counters, int key, bool on) {
-  const int lane = lane_id();
-  unsigned long long todo = __ballot(on);
-  int pos = 0;
-  while (todo) {
-    const int leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
-    const int k = __builtin_amdgcn_readlane(key, leader);
-    const bool mine = on && key == k;
-    const unsigned long long same = __ballot(mine);
-    int base = 0;
-    if (lane == leader) {
-      const int cnt = __popcll(same);
-      if (FETCH) {
-        base = atomicAdd(counters + k, cnt);
-      } else {
-        atomicAdd(counters + k, cnt);
-      }
-    }
-    if (FETCH) {
-      base = __builtin_amdgcn_readlane(base, leader);
-      if (mine) pos = base + __popcll(same & ((1ull << lane) - 1ull));
-    }
-    todo &= ~same;
-  }
-  return pos;
-}
-
+// (wave_agg_inc -- the wave-aggregated "+1" on counters[key] -- lives in common.hpp: the wireframe binner uses it too)
 // Same aggregation on a pair of 32-bit counters packed in one 64-bit word: lanes with `hi` set bump the
 // high word, the others (or, with BOTH, every lane) the low word -- one atomic per distinct key and wave.
 //   count pass (BOTH):  low += lanes, high += lanes with hi        -> {entries, positive entries}

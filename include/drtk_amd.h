@@ -66,7 +66,7 @@ extern "C" {
 #endif
 
 #define DRTK_AMD_VERSION_MAJOR 0
-#define DRTK_AMD_VERSION_MINOR 3
+#define DRTK_AMD_VERSION_MINOR 4
 
 typedef enum { DRTK_F32 = 0, DRTK_F64 = 1 } drtk_dtype_t;
 
@@ -99,7 +99,7 @@ const char* drtk_amd_version(void);
  * `workspace` holds the tile bins; query its size first.
  * `wireframe != 0` selects the line mode (rasterize_kernel.cu:170-400: edges whose bit is set in the top
  * nibble of vi[...,0] are drawn by the diamond rule, the triangles themselves only occlude); it needs the
- * workspace of drtk_amd_rasterize_lines_workspace_bytes (a packed [N,H,W] 64-bit buffer) instead.
+ * workspace of drtk_amd_rasterize_lines_workspace_bytes (tile bins of the padded bounding boxes) instead.
  */
 typedef enum {
   DRTK_DEPTH_ORDER_STRICT = 0,  /* s = dinv0 (e0/|den|) + dinv1 (e1/|den|) + dinv2 (e2/|den|): rasterize_kernel.cu:148-153 as written */
@@ -113,7 +113,7 @@ typedef enum {
 int drtk_amd_set_depth_order(int order); /* DRTK_OK, or DRTK_ERR_INVALID_ARGUMENT for anything but the two values */
 int drtk_amd_get_depth_order(void);      /* a drtk_depth_order_t */
 int drtk_amd_rasterize_workspace_bytes(int64_t N, int64_t F, int64_t H, int64_t W, size_t* bytes);
-int drtk_amd_rasterize_lines_workspace_bytes(int64_t N, int64_t H, int64_t W, size_t* bytes);
+int drtk_amd_rasterize_lines_workspace_bytes(int64_t N, int64_t F, int64_t H, int64_t W, size_t* bytes);
 int drtk_amd_rasterize(
     drtk_dtype_t dtype, const void* v, const int32_t* vi, int64_t N, int64_t V, int64_t F,
     int64_t vi_sN, int64_t H, int64_t W, int wireframe, float* depth_img, int32_t* index_img,

@@ -26,6 +26,10 @@ static int drtk_oracle_resolve_threads(int nthreads) {
   return nthreads < mx ? nthreads : mx;
 }
 
+/* tests/f64_distance.py: accumulate |term| instead of term in the backward functions (see DRTK_MAG in the body). */
+static int drtk_oracle_abs_accumulate = 0;
+void drtk_oracle_set_abs_accumulate(int on) { drtk_oracle_abs_accumulate = on != 0; }
+
 #define REAL float
 #define SFX f32
 #define REAL_EPS 1e-8f /* cuda_math_helper.h:62-64 */

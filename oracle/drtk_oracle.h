@@ -97,6 +97,9 @@ DRTK_ORACLE_DECL(f64, double)
 
 /* Number of OpenMP threads the library would use for nthreads = 0 ("all"). */
 int drtk_oracle_max_threads(void);
+/* Test helper: while on, every backward function accumulates |term| instead of term -- its outputs are the magnitudes
+ * summed into each element (the per-element scale of float32 rounding error).  Process-wide; off by default. */
+void drtk_oracle_set_abs_accumulate(int on);
 
 #ifdef __cplusplus
 }

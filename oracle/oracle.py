@@ -37,6 +37,21 @@ def max_threads() -> int:
     return int(lib().drtk_oracle_max_threads())
 
 
+class accumulated_magnitudes:
+    """`with accumulated_magnitudes(): A = render_backward(...)`: inside the block the backward functions (render,
+    interpolate, edge_grad) sum |term| instead of term, so each output element is the MAGNITUDE accumulated into it --
+    the per-element scale of a float32 evaluation's rounding error (tests/f64_distance.py).  Process-wide switch of the
+    oracle library; restored on exit."""
+
+    def __enter__(self):
+        lib().drtk_oracle_set_abs_accumulate(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().drtk_oracle_set_abs_accumulate(0)
+        return False
+
+
 def _sfx(t: torch.Tensor) -> str:
     if t.dtype == torch.float32:
         return "f32"

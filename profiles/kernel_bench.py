@@ -67,6 +67,50 @@ kernels = {
     "interpolate_backward": lambda: capi.interpolate_backward(go, attr, vi, index, bary, True, True),
     "render_backward": lambda: capi.render_backward(v, vi, index, gd, gb),
 }
+# algorithmic bytes per launch for the kernels that have a figure (SURVEY 8d per-pixel tensors; the sparse operators: DESIGN 3)
+NPX = a.views * H * W
+ALG_BYTES = {
+    "rasterize": 8 * NPX, "render": 20 * NPX, "interpolate": (16 + 4 * a.channels) * NPX,
+    "interpolate_backward": (4 * a.channels + 28) * NPX, "render_backward": 20 * NPX,
+}
+if any(k in a.only for k in ("interpolation_matrix", "normal_matrix", "wireframe", "sparse")):
+    # SURVEY 8f rows 1 and 4 on the same views: the sparse interpolation operators and wireframe rasterization
+    import drtk_amd  # noqa: F401  (registers the operators: the A^T A pattern is built by the shim's device-side builder)
+
+    row_pixels = th.nonzero(index.reshape(-1).ne(-1)).reshape(-1)
+    R = row_pixels.numel()
+    crow, col, vals, _ = capi.interpolation_matrix(vi, index, bary)
+    gvals = th.rand(vals.shape, device=dev, generator=g)
+    V = v.shape[1]
+    ncrow, ncol, pair = th.ops.drtk_amd_ext.normal_matrix_structure(vi[None].expand(a.views, -1, -1) if vi.dim() == 2 else vi, V)
+    nnz = ncol.numel()
+    gnv = th.rand(nnz, device=dev, generator=g)
+    col_o = th.empty(3 * R, dtype=th.int64, device=dev)
+    val_o = th.empty(3 * R, dtype=bary.dtype, device=dev)
+    vi_c, vi_sN, F_ = capi._vi(vi, a.views)
+
+    def matrix_kernel_only():  # the C-ABI entry alone (rows given): what the kernel costs without at::nonzero and the allocations
+        capi._check(capi.lib().drtk_amd_interpolation_matrix(
+            capi.ctypes.c_int(0), capi._p(vi_c), capi._p(index), capi._p(bary), capi._p(row_pixels), capi._i(R), capi._i(a.views), capi._i(F_),
+            capi._i(vi_sN), capi._i(H), capi._i(W), capi._p(col_o), capi._p(val_o), capi._stream(bary, None)), "interpolation_matrix")
+
+    kernels["interpolation_matrix_kernel_only"] = matrix_kernel_only
+    kernels["interpolation_matrix"] = lambda: capi.interpolation_matrix(vi, index, bary)  # + nonzero (host sync), crow, allocations
+    kernels["interpolation_matrix_backward"] = lambda: capi.interpolation_matrix_backward(gvals, vi, index, row_pixels)
+    kernels["normal_matrix_values"] = lambda: capi.interpolation_normal_matrix_values(pair, index, bary, nnz)
+    kernels["normal_matrix_values_backward"] = lambda: capi.interpolation_normal_matrix_values_backward(gnv, pair, index, bary)
+    # wireframe: every edge enabled (bits 28..30 of vi[...,0]) -- the densest line image the mode can be asked for
+    vi_w = vi.clone()
+    vi_w[..., 0] |= 0x70000000
+    kernels["rasterize_wireframe"] = lambda: capi.rasterize(v, vi_w, H, W, wireframe=True)
+    # bytes: the row's pixel id (8) + index (4) + three corner ids (12) + three barycentrics (12) in, three columns (24) +
+    # three values (12) out = 72 per row for the CSR build; backward reads 8 + 4 + 12 + 12 and writes 12 per row + the 12 B/px fill
+    ALG_BYTES.update({
+        "interpolation_matrix_kernel_only": 72 * R, "interpolation_matrix_backward": 48 * R + 12 * NPX,
+        "normal_matrix_values": 16 * NPX + 36 * (R // 7), "normal_matrix_values_backward": 28 * NPX,
+        "rasterize_wireframe": 8 * NPX,
+    })
+    print(f"sparse operators: R = {R} rows ({R / NPX:.2f} of the pixels), A^T A nnz = {nnz}, V = {V}")
 if "mipmap" in a.only:
     # textured shading of the same views: the sphere's own lat/long atlas as uv
     # (smooth, anisotropic towards the limb and the poles), RGB texture with its full pyramid,
@@ -105,7 +149,9 @@ for flags in [int(x) for x in a.flags.split(",")]:
             fn()
         ev1.record()
         th.cuda.synchronize()
-        print(f"{name}{'' if flags == 0 else f' [flags={flags}]'}: {ev0.elapsed_time(ev1) / a.reps:.3f} ms")
+        ms = ev0.elapsed_time(ev1) / a.reps
+        rate = f"   {ALG_BYTES[name] / ms / 1e9:7.2f} TB/s on {ALG_BYTES[name] / 1e9:.3f} GB algorithmic = {ALG_BYTES[name] / ms / 1e9 / 8.0:.3f} of 8 TB/s" if name in ALG_BYTES and flags == 0 else ""
+        print(f"{name}{'' if flags == 0 else f' [flags={flags}]'}: {ms:.3f} ms{rate}")
 set_flags(0)
 
 if os.environ.get("DRTK_ABLATE"):

@@ -19,6 +19,7 @@ ap.add_argument("--tex", type=int, default=4096)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--channels", type=int, default=3, help="texture channels (3 = the textured configuration; 8 / 16: neural textures -- the wave-private backward kernel)")
 ap.add_argument("--bicubic", action="store_true")
+ap.add_argument("--padding", default="border", choices=["zeros", "border", "reflection"], help="padding mode (the textured configuration samples with border)")
 ap.add_argument("--uv", action="store_true", help="also time screen_space_uv_derivative on the same scene (through the C ABI: --lib applies)")
 ap.add_argument("--f64", action="store_true", help="the sampler's inputs in double (the reference dispatches float and double alike)")
 ap.add_argument("--flags", default="0")
@@ -121,9 +122,10 @@ if a.f64:
 for flags in [int(x) for x in a.flags.split(",")]:
     set_flags(flags)
     MODE = 2 if a.bicubic else 0
-    f = timeit(lambda: capi.mipmap_grid_sampler_2d(tex, grid, jac, 8, 1, MODE))
-    b = timeit(lambda: capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, 1, MODE))
-    print(f"flags={flags} C={a.channels}{' bicubic' if a.bicubic else ''}{' f64' if a.f64 else ''}: mipmap fwd {f:.3f} ms   bwd (incl. zero-fill of the pyramid) {b:.3f} ms")
+    PADM = {"zeros": 0, "border": 1, "reflection": 2}[a.padding]
+    f = timeit(lambda: capi.mipmap_grid_sampler_2d(tex, grid, jac, 8, PADM, MODE))
+    b = timeit(lambda: capi.mipmap_grid_sampler_2d_backward(go, tex, grid, jac, 8, PADM, MODE))
+    print(f"flags={flags} C={a.channels}{' bicubic' if a.bicubic else ''}{' f64' if a.f64 else ''} {a.padding}: mipmap fwd {f:.3f} ms   bwd (incl. zero-fill of the pyramid) {b:.3f} ms")
 set_flags(0)
 
 if a.rounds_stats:
