@@ -231,9 +231,9 @@ def rasterize_workspace_bytes(N, F, H, W) -> int:
     return out.value
 
 
-def rasterize_lines_workspace_bytes(N, F, H, W) -> int:
+def rasterize_lines_workspace_bytes(N, H, W) -> int:
     out = ctypes.c_size_t(0)
-    _check(lib().drtk_amd_rasterize_lines_workspace_bytes(_i(N), _i(F), _i(H), _i(W), ctypes.byref(out)), "rasterize")
+    _check(lib().drtk_amd_rasterize_lines_workspace_bytes(_i(N), _i(H), _i(W), ctypes.byref(out)), "rasterize")
     return out.value
 
 
@@ -251,7 +251,7 @@ def rasterize(v, vi, height, width, stream=None, workspace=None, wireframe=False
     else:
         depth = _out(N, height, width, dtype=th.float32, device=v.device)
         index = _out(N, height, width, dtype=th.int32, device=v.device)
-    nbytes = rasterize_lines_workspace_bytes(N, F, height, width) if wireframe else rasterize_workspace_bytes(N, F, height, width)
+    nbytes = rasterize_lines_workspace_bytes(N, height, width) if wireframe else rasterize_workspace_bytes(N, F, height, width)
     ws = workspace if workspace is not None else _out(nbytes, dtype=th.uint8, device=v.device)
     _check(
         lib().drtk_amd_rasterize(

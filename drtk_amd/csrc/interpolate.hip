@@ -40,7 +40,7 @@ struct Vec4<double> {
 // (round 4; before, such images took one pixel per lane: 1.2x the time at 2048 x 2046).
 // (round 6: bounded to 4 waves per SIMD -- 128 registers -- the prefetching instantiation spills 30-38 of its 158)
 #ifndef DRTK_INTERP_FWD_NT
-#define DRTK_INTERP_FWD_NT 0 // 1: index / barycentric quads as non-temporal loads (A/B switch, round 6)
+#define DRTK_INTERP_FWD_NT 1 // index / barycentric quads as non-temporal loads: read once (0.524 -> 0.508 ms, four interleaved rounds on one box, round 6)
 #endif
 template <typename T, int VEC, int CV, bool PREFETCH = false, bool ANYW = false>
 __global__ __launch_bounds__(kBlock) void interpolate_kernel(
@@ -1056,20 +1056,29 @@ int interpolate_backward_impl(
     const bool table = log2_slots >= 4 && !rows_aligned && !DRTK_DBG(debug_flags(), 4096);
 #endif
     const size_t lds = table ? (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) : 0;
-    // chunks of 16 channels (float), 8 where that is all there is (C <= 8: the registers of the other eight planes and of
-    // their attribute rows buy occupancy) and for double
+    // chunks of 16 channels (float; 12 for the element-aligned 11 ... 12, below), 8 for double.  Float chunks of 8 are what
+    // C <= 8 would take -- but the register-scan kernel serves every float C <= DRTK_INTERP_SMALL_MAXC_F32 = 10 since round 5,
+    // so they are instantiated only where a build makes them reachable (a lower DRTK_INTERP_SMALL_MAXC_F32, or
+    // DRTK_INTERP_CH8_ANYC for the unaligned 9 ... 15): the default library carries none of them.
     constexpr int CH = sizeof(T) == 4 ? 16 : 8;
-    const bool ch8 = sizeof(T) == 4 && DRTK_INTERP_CH8 && (C <= 8 || (DRTK_INTERP_CH8_ANYC && !cvec && C < 16));
+    constexpr bool kCh8Reachable = sizeof(T) == 4 && DRTK_INTERP_CH8 && (DRTK_INTERP_SMALL_MAXC_F32 < 8 || DRTK_INTERP_CH8_ANYC);
+    const bool ch8 = kCh8Reachable && (C <= 8 || (DRTK_INTERP_CH8_ANYC && !cvec && C < 16));
     // 9 <= C <= 12 on element-aligned rows: ONE chunk of 12 (the 16-channel chunk's registers put the kernel at 3 waves per
     // SIMD there: 0.81 against 0.63 ms at C = 12, aligned vs not, same loads)
     const bool ch12 = sizeof(T) == 4 && DRTK_INTERP_CH12 && !cvec && C > 8 && C <= DRTK_INTERP_CH12_MAXC && bary_grad;
 #define WIDE(HB, TB, AC)                                                                                                   \
   do {                                                                                                                     \
-    if (ch8)                                                                                                               \
-      DRTK_LAUNCH(                                                                                                         \
-          (interpolate_backward_wide_kernel<T, HB, TB, 8, AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img, \
-          bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots);   \
-    else if (ch12 && AC && HB)                                                                                             \
+    bool launched8_ = false;                                                                                               \
+    if constexpr (kCh8Reachable) {                                                                                         \
+      if (ch8) {                                                                                                           \
+        DRTK_LAUNCH(                                                                                                       \
+            (interpolate_backward_wide_kernel<T, HB, TB, 8, AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img, \
+            bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots); \
+        launched8_ = true;                                                                                                 \
+      }                                                                                                                    \
+    }                                                                                                                      \
+    if (launched8_) break;                                                                                                 \
+    if (ch12 && AC && HB)                                                                                                  \
       DRTK_LAUNCH(                                                                                                         \
           (interpolate_backward_wide_kernel<T, HB, TB, (sizeof(T) == 4 && AC && HB ? 12 : CH), AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img, \
           bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots);   \

@@ -71,6 +71,9 @@ extern "C" __attribute__((visibility("default"))) int drtk_amd_debug_read_mip_du
 #define DRTK_MIP_TILE_DONE(rounds) do { } while (0)
 #endif
 
+#ifndef DRTK_MIP_NT
+#define DRTK_MIP_NT 0 // 1: the Jacobian image and the lean backward's upstream gradient as non-temporal loads (A/B switch, round 6)
+#endif
 namespace drtk_amd {
 namespace {
 
@@ -263,7 +266,11 @@ __device__ __forceinline__ PixelUV<T> load_pixel_uv(
     p.u = g[0], p.v = g[gl.sC];
   }
   if constexpr (sizeof(T) == 4) {
+#if DRTK_MIP_NT
+    const NtQuad<float> j = nt_load4(vt + index * 4);
+#else
     const float4 j = *reinterpret_cast<const float4*>(vt + index * 4);
+#endif
     p.dudx = j.x, p.dvdx = j.y, p.dudy = j.z, p.dvdy = j.w;
   } else {
     const double2 j0 = *reinterpret_cast<const double2*>(vt + index * 4);
@@ -1644,7 +1651,11 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 4 : (CN <= 3 ? DRTK_MIP_T3_OC
   if (valid) {
     const T* gout_px = grad_out + (int64_t(n) * C_total + c0) * HW + (int64_t(py) * W + px);
 #pragma unroll
+#if DRTK_MIP_NT
+    for (int c = 0; c < CN; ++c) go[c] = __builtin_nontemporal_load(gout_px + int64_t(c) * HW);
+#else
     for (int c = 0; c < CN; ++c) go[c] = gout_px[int64_t(c) * HW];
+#endif
   }
   PixelUV<T> uv = {};
   // (the pixel's index is rebuilt where it is needed -- here, at an early exit, after the tap loop -- from a laundered thread id:

@@ -46,7 +46,7 @@ std::vector<Tensor> rasterize_hip(
   auto index_img = out_empty({N, height, width}, v.options().dtype(at::kInt));
   size_t ws_bytes = 0;
   check_status(
-      wireframe ? drtk_amd_rasterize_lines_workspace_bytes(N, F, height, width, &ws_bytes)
+      wireframe ? drtk_amd_rasterize_lines_workspace_bytes(N, height, width, &ws_bytes)
                 : drtk_amd_rasterize_workspace_bytes(N, F, height, width, &ws_bytes),
       "rasterize");
   auto ws = alloc_workspace(ws_bytes, v);

@@ -72,10 +72,13 @@ class _StagedCast(th.autograd.Function):
             r._check_not_in_flight(ctx.index)
             r._begin_round()
             r.segments[ctx.index].add_(g.reshape(-1))
-            if not r._staged_seen:
+            if not r._fallback_queued:
                 # Fallback for the hook above not firing on an undefined gradient (engine behaviour, not API): at the END of
                 # this backward pass every staged leaf that was seen and is not marked ready yet is marked then -- later than
-                # the hook would have (no overlap with the rest of the pass), still from inside backward(), never wrong
+                # the hook would have (no overlap with the rest of the pass), still from inside backward(), never wrong.
+                # Queued once per BACKWARD PASS (the flag is cleared by the callback itself): `_staged_seen` lives for the whole
+                # round, so after accumulation passes under no_sync() had filled it the synchronising pass queued nothing.
+                r._fallback_queued = True
                 th.autograd.Variable._execution_engine.queue_callback(r._staged_leaves_fallback)
             r._staged_seen.add(ctx.index)
             return None, None, None  # the leaf's .grad is written once, by finish(), from the reduced sum
@@ -148,6 +151,7 @@ class SharedGradReducer:
         self._next = 0          # position in `order` of the next group to launch
         self._ready = set()     # parameters whose gradient of this round is final
         self._staged_seen = set()  # staged parameters whose segment was filled through upcast() this round
+        self._fallback_queued = False  # the end-of-backward callback is queued for the backward pass that is running
         self._pending = {}      # group index -> work handle of its in-flight all-reduce
         self._events = []       # (start, end) HIP events on the side stream, one pair per collective of the step
         self._handles = []
@@ -240,6 +244,7 @@ class SharedGradReducer:
         self._on_grad_ready(i)
 
     def _staged_leaves_fallback(self) -> None:
+        self._fallback_queued = False  # (the engine runs this at the end of the pass that queued it)
         if not self._active() or self._defer:
             return
         for i in sorted(self._staged_seen):

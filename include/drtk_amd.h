@@ -99,7 +99,7 @@ const char* drtk_amd_version(void);
  * `workspace` holds the tile bins; query its size first.
  * `wireframe != 0` selects the line mode (rasterize_kernel.cu:170-400: edges whose bit is set in the top
  * nibble of vi[...,0] are drawn by the diamond rule, the triangles themselves only occlude); it needs the
- * workspace of drtk_amd_rasterize_lines_workspace_bytes (tile bins of the padded bounding boxes) instead.
+ * workspace of drtk_amd_rasterize_lines_workspace_bytes (a packed [N,H,W] 64-bit buffer) instead.
  */
 typedef enum {
   DRTK_DEPTH_ORDER_STRICT = 0,  /* s = dinv0 (e0/|den|) + dinv1 (e1/|den|) + dinv2 (e2/|den|): rasterize_kernel.cu:148-153 as written */
@@ -113,7 +113,7 @@ typedef enum {
 int drtk_amd_set_depth_order(int order); /* DRTK_OK, or DRTK_ERR_INVALID_ARGUMENT for anything but the two values */
 int drtk_amd_get_depth_order(void);      /* a drtk_depth_order_t */
 int drtk_amd_rasterize_workspace_bytes(int64_t N, int64_t F, int64_t H, int64_t W, size_t* bytes);
-int drtk_amd_rasterize_lines_workspace_bytes(int64_t N, int64_t F, int64_t H, int64_t W, size_t* bytes);
+int drtk_amd_rasterize_lines_workspace_bytes(int64_t N, int64_t H, int64_t W, size_t* bytes);
 int drtk_amd_rasterize(
     drtk_dtype_t dtype, const void* v, const int32_t* vi, int64_t N, int64_t V, int64_t F,
     int64_t vi_sN, int64_t H, int64_t W, int wireframe, float* depth_img, int32_t* index_img,
@@ -245,6 +245,10 @@ int drtk_amd_interpolation_normal_matrix_values_backward(
  *   reference (:423 vs :641-897).
  * Backward: grad_levels[l] (contiguous [N,C,h,w] whatever level_sN is, zero-filled here) and grad_grid [N,H,W,2]
  * (fully written); no gradient is defined for vt_dxdy_img.
+ * NO ALIASING: grad_grid and grad_levels[] must not overlap any input (grad_out, levels, grid, vt_dxdy_img) nor each other --
+ * textures of more than four channels are processed in several launches of one stream, each adding its part of the grid
+ * gradient to what the previous launch stored (the torch operator allocates fresh outputs; tests/test_gpu_mipmap.py covers
+ * C = 5 ... 16 in both grid layouts).
  * FINITE TEXELS ASSUMED where a weight is exactly zero: the forward pass skips a mip level whose blend weight is
  * exactly 0, the backward pass skips (pixel, level) pairs whose weighted upstream gradient is 0 in every channel and
  * whole tiles without upstream gradient.  The reference evaluates 0 * texel there, so an Inf / NaN texel in a level

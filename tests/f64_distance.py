@@ -57,12 +57,13 @@ def assert_within_f64_distance(got_f32, oracle_f32, oracle_f64, what, k=3.0, rel
 #     A_i = sum_j |term_ij|         (oracle.accumulated_magnitudes(): the same operator summing absolute values),
 # because that -- not the result, which may have cancelled -- is what the rounding errors of the terms and of their sum
 # scale with.  Element i passes iff
-#     |kernel_i - f64_i|  <=  max( k * |oracle_f32_i - f64_i| ,  ulps * u * A_i )
+#     |kernel_i - f64_i|  <=  max( k * |oracle_f32_i - f64_i| ,  ulps * u * A_i ,  floor_rel * max|f64| )
+# (floor_rel: what is not resolved per element -- the tests use 1e-7, the north star's 1e-5 of the output's scale tightened 100 x)
 # `ulps` is per operator (the terms of render backward are themselves differences of rounded quantities: b0 = 1 - b1 - b2,
 # -dL_b0 + dL_b1 ... -- the float32 ORACLE is up to ~300 u A_i from the double result there; interpolate's terms are single
 # products: 3-4 u A_i); the values used by the tests are stated there, each a small multiple of what the float32 oracle
 # itself needs.  An element nothing was accumulated into (A_i = 0) must be exactly what the oracle has (0).
-def elementwise_excess(got_f32, oracle_f32, oracle_f64, magnitudes, ulps, k=3.0):
+def elementwise_excess(got_f32, oracle_f32, oracle_f64, magnitudes, ulps, k=3.0, floor_rel=0.0):
     """max_i |got_i - f64_i| / bound_i  (<= 1 passes), the index of the worst element, and the same ratio for the float32
     oracle against ulps * u * A_i alone (how much of the allowance the reference's own arithmetic uses)."""
     got, o32, o64 = (t.detach().cpu().double() for t in (got_f32, oracle_f32, oracle_f64))
@@ -72,7 +73,7 @@ def elementwise_excess(got_f32, oracle_f32, oracle_f64, magnitudes, ulps, k=3.0)
         return 0.0, -1, 0.0
     err = (got - o64).abs()
     own = (o32 - o64).abs()
-    bound = th.maximum(k * own, ulps * U32 * A)
+    bound = th.maximum(k * own, ulps * U32 * A).clamp(min=floor_rel * float(o64.abs().max()))  # floor_rel: what is not resolved per element
     dead = bound == 0
     ratio = th.where(dead, th.where(err == 0, th.zeros_like(err), th.full_like(err, float("inf"))), err / bound.clamp(min=1e-300))
     worst = int(ratio.flatten().argmax())
@@ -81,11 +82,11 @@ def elementwise_excess(got_f32, oracle_f32, oracle_f64, magnitudes, ulps, k=3.0)
     return float(ratio.flatten()[worst]), worst, own_ratio
 
 
-def assert_elementwise_within(got_f32, oracle_f32, oracle_f64, magnitudes, ulps, what, k=3.0):
+def assert_elementwise_within(got_f32, oracle_f32, oracle_f64, magnitudes, ulps, what, k=3.0, floor_rel=0.0):
     assert bool(th.isfinite(got_f32).all()) or not bool(th.isfinite(oracle_f64).all()), f"{what}: non-finite output"
-    excess, worst, own_ratio = elementwise_excess(got_f32, oracle_f32, oracle_f64, magnitudes, ulps, k)
+    excess, worst, own_ratio = elementwise_excess(got_f32, oracle_f32, oracle_f64, magnitudes, ulps, k, floor_rel)
     if excess > 1.0:
         g, o32, o64, A = (t.detach().cpu().double().flatten()[worst] for t in (got_f32, oracle_f32, oracle_f64, magnitudes))
         raise AssertionError(f"{what}: element {worst}: kernel {float(g):.9e}, f64 {float(o64):.9e}, oracle f32 {float(o32):.9e}, accumulated magnitude "
-                             f"{float(A):.3e}: |kernel - f64| = {abs(float(g - o64)):.3e} is {excess:.2f} x max({k:g} |oracle_f32 - f64|, {ulps:g} u A)")
+                             f"{float(A):.3e}: |kernel - f64| = {abs(float(g - o64)):.3e} is {excess:.2f} x max({k:g} |oracle_f32 - f64|, {ulps:g} u A, {floor_rel:g} max|f64|)")
     return excess, own_ratio

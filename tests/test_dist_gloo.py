@@ -190,6 +190,29 @@ def _worker(rank, world, port, out_dir):
     red.finish()
     assert launched == [0]
     out.update({"castonly_grad": c16.grad.clone()})
+    for h in red._handles:
+        h.remove()
+
+    # (i) the end-of-backward fallback ITSELF, after accumulation passes: the leaf's hook is taken away (the case the fallback
+    # exists for), two passes accumulate under no_sync() -- they fill `_staged_seen` for the round -- and the synchronising
+    # pass must still queue the callback and launch the group from inside backward() (round 5 queued it only while
+    # `_staged_seen` was empty: after no_sync() passes nothing was queued and the overlap was lost silently)
+    d16 = th.full((4,), 0.25, dtype=th.float16, requires_grad=True)
+    red = ddist.SharedGradReducer([d16], dtype=th.float32)
+    for h in red._handles:
+        h.remove()  # no leaf hook: only the fallback can mark the leaf ready
+    launched = []
+    launch = red._launch
+    red._launch = lambda g, launch=launch: (launched.append(g), launch(g))[1]
+    with red.no_sync():
+        for _ in range(2):
+            ((red.upcast(d16) ** 2).sum() * float(rank + 1)).backward()
+            assert launched == [] and not red._fallback_queued
+    ((red.upcast(d16) ** 2).sum() * float(rank + 1)).backward()
+    assert launched == [0], "after no_sync() passes the synchronising pass did not launch the group from its end-of-backward fallback"
+    red.finish()
+    assert launched == [0]
+    out.update({"fallback_accum_grad": d16.grad.clone()})
     ddist.barrier_and_sync()
     th.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     th.distributed.destroy_process_group()
@@ -259,6 +282,8 @@ def test_two_ranks_match_single_process(tmp_path):
         assert th.equal(r["extra16_grad"], th.full((3,), 3.0, dtype=th.float16))
         # (g) sum over ranks r of  2 * 0.5 * (r + 1)  +  2  +  3   =  (1 + 2) + 2 * 5
         assert th.equal(r["mixed_f32"], th.full((5,), 13.0)) and th.equal(r["mixed_grad"], th.full((5,), 13.0, dtype=th.float16))
+        # (i) three passes of d/dx x^2 * (r + 1) at x = 0.25, summed over ranks 0 and 1: 3 * 2 * 0.25 * (1 + 2)
+        assert th.equal(r["fallback_accum_grad"], th.full((4,), 4.5, dtype=th.float16))
 
 
 def _shard_worker(rank, world, port, out_dir, n_views, H, W):

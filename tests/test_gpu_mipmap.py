@@ -307,6 +307,34 @@ def test_a_one_by_one_last_level_followed_by_poison_in_memory(C):
                     close(a, b, f"grad level {i}")
 
 
+@pytest.mark.parametrize("layout", ["pixel_major", "channel_major"])
+@pytest.mark.parametrize("C", [5, 8, 13, 16])
+def test_wide_textures_take_the_tiled_backward_once_per_block_of_four_channels(C, layout):
+    """C > 4: the lean tile kernel is launched once per block of four channels (tails of 1, 2, 3 channels included); every launch
+    after the first ADDS its part of the grid gradient to what the previous ones stored (read-modify-write, in stream order --
+    include/drtk_amd.h: grad_grid must not alias an input).  Both layouts of the grid gradient: [N,H,W,2] pairs, and the
+    channel-first image seen through permute(0, 2, 3, 1) (two strided stores per pixel); zeros, border and reflection
+    padding, the adaptive tap count; against the oracle."""
+    import oracle as O
+    from drtk_amd import capi
+
+    H, W = 36, 52
+    tex, grid, vt, gout = mipmap_inputs(5100 + C, 2, C, 64, 4, H, W, jscale=0.04)
+    dgrid = dev(grid)
+    if layout == "channel_major":
+        dgrid = dgrid.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)  # [N,2,H,W] storage
+        assert dgrid.stride(3) == H * W and th.equal(dgrid.cpu(), grid)
+    for padding in (0, 1, 2):
+        want = O.mipmap_grid_sampler_2d(tex, grid, vt, 8, padding, 0, False, False, False)
+        close(capi.mipmap_grid_sampler_2d(dev(tex), dgrid, dev(vt), 8, padding, 0, False, False, False), want, f"forward, padding {padding}")
+        wl, wg = O.mipmap_grid_sampler_2d_backward(gout, tex, grid, vt, 8, padding, 0, False, False, False)
+        gl, gg = capi.mipmap_grid_sampler_2d_backward(dev(gout), dev(tex), dgrid, dev(vt), 8, padding, 0, False, False, False)
+        assert gg.stride() == dgrid.stride()
+        close(gg, wg, f"grad grid, padding {padding}", atol=2e-5)
+        for i, (a, b) in enumerate(zip(gl, wl)):
+            close(a, b, f"grad level {i}, padding {padding}")
+
+
 def test_one_texture_shared_by_all_views_is_sampled_in_place():
     """A [1,C,h,w] pyramid expanded to N views (batch stride 0) -- one texture, many cameras -- gives the results of its
     materialised copy, through the C ABI (`level_sN` = 0) and through the torch op, forward and backward; the level

@@ -59,10 +59,8 @@ def test_c_abi_argument_validation_without_gpu():
                               ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(1), ctypes.c_void_p(16),
                               ctypes.c_void_p(16), z, ctypes.c_size_t(0), z)
     assert rc == -2  # DRTK_ERR_WORKSPACE_TOO_SMALL
-    # wireframe workspace = tile bins of the padded bounding boxes: counters per tile + 36 bytes per (view, triangle)
-    assert L.drtk_amd_rasterize_lines_workspace_bytes(ctypes.c_int64(2), ctypes.c_int64(100), ctypes.c_int64(8), ctypes.c_int64(8), ctypes.byref(out)) == 0
-    assert 36 * 2 * 100 <= out.value <= 36 * 2 * 100 + 16 * 256
-    assert L.drtk_amd_rasterize_lines_workspace_bytes(ctypes.c_int64(2), ctypes.c_int64(-1), ctypes.c_int64(8), ctypes.c_int64(8), ctypes.byref(out)) == -1
+    assert L.drtk_amd_rasterize_lines_workspace_bytes(ctypes.c_int64(2), ctypes.c_int64(8), ctypes.c_int64(8), ctypes.byref(out)) == 0
+    assert out.value == 2 * 8 * 8 * 8
     rc = L.drtk_amd_rasterize(ctypes.c_int(0), z, z, ctypes.c_int64(1), ctypes.c_int64(1 << 28), ctypes.c_int64(0),
                               ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(0), z, z, z,
                               ctypes.c_size_t(0), z)
