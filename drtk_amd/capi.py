@@ -132,6 +132,8 @@ EXPORTS = [
     "drtk_amd_interpolate",
     "drtk_amd_interpolate_masked",
     "drtk_amd_interpolate_backward",
+    "drtk_amd_interpolate_backward_workspace_bytes",
+    "drtk_amd_interpolate_backward_ws",
     "drtk_amd_edge_grad_backward_workspace_bytes",
     "drtk_amd_edge_grad_backward",
     "drtk_amd_edge_grad_backward_fused_workspace_bytes",
@@ -320,7 +322,8 @@ def interpolate_masked(attrs, vi, index_img, bary_img, stream=None):
 
 @_on_tensor_device
 def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires_grad=True,
-                         bary_requires_grad=True, stream=None):
+                         bary_requires_grad=True, stream=None, workspace=None):
+    """workspace=False: the entry point's unpadded route (no scratch buffer), for A/B and for the parity tests of both routes."""
     grad_out = grad_out.contiguous()
     attrs = attrs.contiguous()
     index_img = index_img.contiguous()
@@ -330,10 +333,22 @@ def interpolate_backward(grad_out, attrs, vi, index_img, bary_img, vert_requires
     vi_c, vi_sN, F = _vi(vi, N)
     ag = _out(N, V, C, dtype=attrs.dtype, device=attrs.device) if vert_requires_grad else None
     bg = _out(N, 3, H, W, dtype=attrs.dtype, device=attrs.device) if bary_requires_grad else None
+    ws, nbytes = None, 0
+    if os.environ.get("DRTK_CAPI_NO_INTERP_WS"):  # A/B of the two routes from the command line (profiles/shape_bench.py)
+        workspace = False
+    if vert_requires_grad and workspace is not False:  # the optional scratch of the padded-row route (include/drtk_amd.h)
+        out = ctypes.c_size_t(0)
+        _check(lib().drtk_amd_interpolate_backward_workspace_bytes(ctypes.c_int(_dt(attrs)), _i(N), _i(V), _i(C), ctypes.byref(out)), "interpolate_backward")
+        nbytes = int(out.value)
+        if nbytes:
+            ws = _out((nbytes + 3) // 4, dtype=th.float32, device=attrs.device)
+            assert ws.data_ptr() % 64 == 0 or os.environ.get("DRTK_CAPI_GUARD"), "torch allocations are 256-byte aligned"
+            if ws.data_ptr() % 64 != 0:  # (guarded allocations are only element-aligned: no workspace then)
+                ws, nbytes = None, 0
     _check(
-        lib().drtk_amd_interpolate_backward(
+        lib().drtk_amd_interpolate_backward_ws(
             ctypes.c_int(_dt(attrs)), _p(grad_out), _p(attrs), _p(vi_c), _p(index_img), _p(bary_img), _i(N), _i(V),
-            _i(C), _i(F), _i(vi_sN), _i(H), _i(W), _p(ag), _p(bg), _stream(attrs, stream)),
+            _i(C), _i(F), _i(vi_sN), _i(H), _i(W), _p(ag), _p(bg), _p(ws), ctypes.c_size_t(nbytes), _stream(attrs, stream)),
         "interpolate_backward")
     return ag, bg
 

@@ -39,9 +39,6 @@ struct Vec4<double> {
 template <typename T>
 using Quad = T __attribute__((ext_vector_type(4), aligned(sizeof(T))));
 
-#ifndef DRTK_EDGE_NT_PRIVATE
-#define DRTK_EDGE_NT_PRIVATE 0 // 1: the rows only one wave reads as non-temporal loads (A/B switch, round 6)
-#endif
 // ---------------------------------------------------------------------------------------------
 // Pass A
 // ---------------------------------------------------------------------------------------------
@@ -51,20 +48,12 @@ struct Row {
   T next; // pixel x + VEC (first pixel of the next lane)
 };
 
-template <typename T, int VEC, bool NT = false>
+template <typename T, int VEC>
 __device__ __forceinline__ Row<T, VEC> load_row(
     const T* __restrict__ plane, int64_t row_off, int x, int W, bool x_ok, int lane) {
   Row<T, VEC> r;
   if (x_ok) {
-    if constexpr (VEC == 4 && NT) {
-      if (x + 4 <= W) {
-        const NtQuad<T> q = nt_load4(plane + row_off + x); // (element alignment is enough for the hardware; rows of the NT variant are 16-byte aligned anyway)
-        r.v[0] = q.x, r.v[1] = q.y, r.v[2] = q.z, r.v[3] = q.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.v[j] = x + j < W ? plane[row_off + x + j] : T(0);
-      }
-    } else if constexpr (VEC == 4) {
+    if constexpr (VEC == 4) {
       if (x + 4 <= W) {
         // (as non-temporal loads -- both images are read once per launch -- the fused route ran 0.90 instead of 0.74 ms,
         // round 6: the row below a wave's strip is its sibling wave's first row and comes out of the cache the hint gives up)
@@ -168,14 +157,7 @@ __global__ __launch_bounds__(WAVES * kWave) void edge_dots_kernel(
 #pragma unroll
     for (int r = 0; r <= R; ++r) {
       const bool y_ok = (y0 + r) < H; // wave-uniform
-#if DRTK_EDGE_NT_PRIVATE
-      // rows 1 .. R-1 of a wave's strip are read by this wave alone (row 0 is the halo of the wave above, row R this wave's halo)
-      if (r >= 1 && r < R && (W % 4 == 0)) {
-        ri[r] = load_row<T, VEC, true>(ip, int64_t(y0 + r) * W, x, W, x_ok && y_ok, lane);
-        rg[r] = load_row<T, VEC, true>(gp, int64_t(y0 + r) * W, x, W, x_ok && y_ok, lane);
-        continue;
-      }
-#endif
+      // (round 6: rows 1 .. R-1, read by this wave alone, as non-temporal loads: 0.763 vs 0.750 ms for the fused route -- no)
       ri[r] = load_row<T, VEC>(ip, int64_t(y0 + r) * W, x, W, x_ok && y_ok, lane);
       rg[r] = load_row<T, VEC>(gp, int64_t(y0 + r) * W, x, W, x_ok && y_ok, lane);
     }

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : C
     const T* __restrict__ grad_out, const T* __restrict__ attrs, const int32_t* __restrict__ vi,
     const int32_t* __restrict__ index_img, const T* __restrict__ bary_img, int64_t V, int C,
     int64_t vi_sN, int H, int W, int tiles_x, T* __restrict__ attr_grad, T* __restrict__ bary_grad,
-    int dbg, int strip, int log2_slots) {
+    int dbg, int strip, int log2_slots, int CG) { // CG: elements between the rows of attr_grad (C, or the padded pitch of the workspace)
   using V4 = typename Vec4<T>::type;
   static_assert(CH % 4 == 0 && CH >= 8 && CH <= 16, "chunks of 8 or 16 channels");
   constexpr int kWaves = kBlock / kWave;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : C
   const int y0 = tyi * kTileRows + wave * kPasses;
   const T* attrs_n = attrs + int64_t(n) * V * C;
   const int32_t* vi_n = vi + int64_t(n) * vi_sN;
-  T* attr_grad_n = attr_grad + int64_t(n) * V * C;
+  T* attr_grad_n = attr_grad + int64_t(n) * V * CG;
   const T* go_n = grad_out + int64_t(n) * C * HW;
   const T* bary_n = bary_img + int64_t(n) * 3 * HW;
   T* bgrad_n = HAS_BARY ? bary_grad + int64_t(n) * 3 * HW : nullptr;
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : C
       const T* sb = s_b[wave];
       // (the table + bary variant sits at its register bound: it keeps the unpipelined reads)
       scatter_runs_rows<T, TableAcc, DRTK_INTERP_WIDE_ONLY, TABLE, 16, !(TABLE && HAS_BARY)>(
-          heads, cov, TABLE ? s_slot[wave] : nullptr, s_vid[wave], 3 * cc, cc, t_vals, C, attr_grad_n, C, c0, sg, sb, dbg,
+          heads, cov, TABLE ? s_slot[wave] : nullptr, s_vid[wave], 3 * cc, cc, t_vals, C, attr_grad_n, CG, c0, sg, sb, dbg,
           TABLE ? c0 : 0);
     }
     // 6. bary gradient: interpolate_kernel.cu:238-246 accumulation order (channels ascending, over all chunks)
@@ -935,11 +935,32 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 8 ? DRTK_INTERP_F64_WAVES : C
         const int32_t key = t_keys[sl];
         if (key >= 0) {
           const T xv = static_cast<T>(t_vals[e]);
-          if (xv != T(0)) atomic_add_global(attr_grad_n + int64_t(key) * C + c, xv);
+          if (xv != T(0)) atomic_add_global(attr_grad_n + int64_t(key) * CG + c, xv);
         }
       }
     }
   }
+}
+
+// rows of CG elements -> rows of C (the padded gradient workspace of the wide pipeline back into attr_grad)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void compact_rows_kernel(const T* __restrict__ ws, T* __restrict__ out, int64_t count, int C, int CG) {
+  const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const int64_t r = i / C;
+  out[i] = ws[r * CG + (i - r * C)];
+}
+
+// elements between the rows of the padded gradient workspace: whole 64-byte segments
+template <typename T>
+inline int64_t padded_row(int64_t C) {
+  const int64_t seg = 64 / int64_t(sizeof(T));
+  return (C + seg - 1) / seg * seg;
+}
+template <typename T>
+inline bool rows_are_segments(int64_t C) {
+  const size_t row_bytes = sizeof(T) * C;
+  return row_bytes % 64 == 0 || 64 % row_bytes == 0;
 }
 
 template <typename T>
@@ -990,11 +1011,23 @@ template <typename T>
 int interpolate_backward_impl(
     const T* grad_out, const T* attrs, const int32_t* vi, const int32_t* index_img,
     const T* bary_img, int64_t N, int64_t V, int64_t C, int64_t vi_sN, int64_t H, int64_t W,
-    T* attr_grad, T* bary_grad, hipStream_t stream) {
-  if (attr_grad && N * V * C > 0) {
-    if (fill_bytes_async(attr_grad, 0, sizeof(T) * N * V * C, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
-  }
+    T* attr_grad, T* bary_grad, T* ws, size_t ws_bytes, hipStream_t stream) {
   const int64_t HW = H * W;
+  // Round 6: where the rows of attr_grad are not whole 64-byte segments (C = 12, 20, 24 ...; every C that is not a multiple of
+  // four) the run sums of the wide pipeline went through the workgroup's vertex table, which costs about a quarter more than
+  // the per-run atomics aligned rows take (C = 12 0.61 ms against 0.48 for its bytes at C = 16's rate; C = 13 ... 15 0.745).
+  // With a workspace the gradient is accumulated in rows PADDED to whole segments -- every such C takes the aligned rows'
+  // path -- and compacted into attr_grad afterwards (N V C elements: 21 MB at C = 13 on the bench mesh).
+  const bool pad_possible = attr_grad && ws && !rows_are_segments<T>(C) && N * V * C > 0 &&
+      ws_bytes >= sizeof(T) * size_t(N * V * padded_row<T>(C)) && padded_row<T>(C) < (int64_t(1) << 30);
+  bool padded = false; // decided below, with the pipeline; the zero-fill goes where the atomics will
+  auto zero_grad = [&](bool to_ws) -> int {
+    if (!attr_grad || N * V * C == 0) return DRTK_OK;
+    return to_ws ? fill_bytes_async(ws, 0, sizeof(T) * N * V * padded_row<T>(C), stream) : fill_bytes_async(attr_grad, 0, sizeof(T) * N * V * C, stream);
+  };
+  if (N * HW == 0 || C == 0) {
+    if (zero_grad(false) != DRTK_OK) return DRTK_ERR_LAUNCH;
+  }
   if (N * HW == 0) return DRTK_OK;
   if (C == 0) {
     if (bary_grad && fill_bytes_async(bary_grad, 0, sizeof(T) * N * 3 * HW, stream) != DRTK_OK) return DRTK_ERR_LAUNCH;
@@ -1033,6 +1066,18 @@ int interpolate_backward_impl(
   // wide path: the vertex gradient (+ bary gradient) for any C >= 5, float and double (round 5; round 4: C % 4 == 0,
   // C >= 8, float only -- every other shape took the generic kernel, a chain of dependent waits per row)
   const bool wide = attr_grad && !small_c && HW * int64_t(sizeof(T)) < (int64_t(1) << 32) && !DRTK_DBG(debug_flags(), 128);
+#ifndef DRTK_INTERP_PAD
+#define DRTK_INTERP_PAD 1
+#endif
+  // ... measured (profiles/r06/interp_bwd_by_C*.json, same box, padded / table route, ms): with both gradients C = 11 0.616 / 0.665,
+  // 12 0.554 / 0.617, 13 0.693 / 0.726, 15 0.702 / 0.735 -- but attributes only 0.497 / 0.468 at C = 11 (the lighter kernel hides
+  // the table better than the atomics), and with more than one chunk the tail chunk's few channels are a request of their own
+  // per run and corner where the table merges a vertex's chunks: C = 17 1.093 / 1.023, 20 1.071 / 0.860 (attributes only 1.039 /
+  // 0.668).  So: one chunk, both gradients, float.
+  padded = wide && pad_possible && DRTK_INTERP_PAD && bary_grad && sizeof(T) == 4 && C <= 16;
+  if (zero_grad(padded) != DRTK_OK) return DRTK_ERR_LAUNCH;
+  T* const grad_dst = padded ? ws : attr_grad;
+  const int CG = static_cast<int>(padded ? padded_row<T>(C) : C);
   // (the bary gradient alone stays with the generic kernel: no scatter, covered pixels only -- 0.95 of the HBM peak on
   // SURVEY 8d's bytes at the bench coverage; a forward-shaped streaming kernel with four pixels per lane, which cannot
   // skip the background of a partly covered quad, was measured slower: 0.55 vs 0.40 ms at C = 16)
@@ -1048,8 +1093,7 @@ int interpolate_backward_impl(
     // and barriers cost more than the fire-and-forget atomics they replace (C = 16: 0.63 -> 0.70 ms)
     int log2_slots = 7;
     while (log2_slots > 0 && (sizeof(TableAcc) * C + 4) * (size_t(1) << log2_slots) > DRTK_INTERP_TABLE_BYTES) --log2_slots;
-    const size_t row_bytes = sizeof(T) * C;
-    const bool rows_aligned = row_bytes % 64 == 0 || 64 % row_bytes == 0;
+    const bool rows_aligned = padded || rows_are_segments<T>(C);
 #ifdef DRTK_INTERP_NO_TABLE
     const bool table = false;
 #else
@@ -1073,7 +1117,7 @@ int interpolate_backward_impl(
       if (ch8) {                                                                                                           \
         DRTK_LAUNCH(                                                                                                       \
             (interpolate_backward_wide_kernel<T, HB, TB, 8, AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img, \
-            bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots); \
+            bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, grad_dst, bary_grad, debug_flags(), strip, log2_slots, CG); \
         launched8_ = true;                                                                                                 \
       }                                                                                                                    \
     }                                                                                                                      \
@@ -1081,11 +1125,11 @@ int interpolate_backward_impl(
     if (ch12 && AC && HB)                                                                                                  \
       DRTK_LAUNCH(                                                                                                         \
           (interpolate_backward_wide_kernel<T, HB, TB, (sizeof(T) == 4 && AC && HB ? 12 : CH), AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img, \
-          bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots);   \
+          bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, grad_dst, bary_grad, debug_flags(), strip, log2_slots, CG);   \
     else                                                                                                                   \
       DRTK_LAUNCH(                                                                                                         \
           (interpolate_backward_wide_kernel<T, HB, TB, CH, AC>), grid, block, lds, stream, grad_out, attrs, vi, index_img, \
-          bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, attr_grad, bary_grad, debug_flags(), strip, log2_slots);   \
+          bary_img, V, (int)C, vi_sN, (int)H, (int)W, tiles_x, grad_dst, bary_grad, debug_flags(), strip, log2_slots, CG);   \
   } while (0)
 #define WIDE_T(HB, AC) \
   if (table) WIDE(HB, true, AC); else WIDE(HB, false, AC)
@@ -1134,6 +1178,11 @@ int interpolate_backward_impl(
   }
 #undef LAUNCH
   DRTK_RETURN_IF_LAUNCH_FAILED();
+  if (padded) {
+    const int64_t count = N * V * C;
+    DRTK_LAUNCH((compact_rows_kernel<T>), dim3(static_cast<unsigned>(ceil_div(count, kBlock))), dim3(kBlock), 0, stream, ws, attr_grad, count, (int)C, CG);
+    DRTK_RETURN_IF_LAUNCH_FAILED();
+  }
   return DRTK_OK;
 }
 
@@ -1184,10 +1233,22 @@ extern "C" int drtk_amd_interpolate_masked(
   return interpolate_entry(dtype, attrs, vi, index_img, bary_img, N, V, C, F, vi_sN, H, W, out, 1, stream);
 }
 
-extern "C" int drtk_amd_interpolate_backward(
+extern "C" int drtk_amd_interpolate_backward_workspace_bytes(drtk_dtype_t dtype, int64_t N, int64_t V, int64_t C, size_t* bytes) {
+  if (!bytes || N < 0 || V < 0 || C < 0 || (dtype != DRTK_F32 && dtype != DRTK_F64)) return DRTK_ERR_INVALID_ARGUMENT;
+  const bool f32 = dtype == DRTK_F32;
+  const bool segs = f32 ? rows_are_segments<float>(C) : rows_are_segments<double>(C);
+  const int64_t row = f32 ? padded_row<float>(C) : padded_row<double>(C);
+  // only the wide pipeline's one-chunk float shapes pad (interpolate_backward_impl: 11 <= C <= 15); anything else needs no workspace
+  const bool pads = f32 && C > DRTK_INTERP_SMALL_MAXC_F32 && C <= 16;
+  *bytes = (!segs && pads && N * V > 0) ? dtype_size(dtype) * size_t(N * V * row) : 0;
+  return DRTK_OK;
+}
+
+extern "C" int drtk_amd_interpolate_backward_ws(
     drtk_dtype_t dtype, const void* grad_out, const void* attrs, const int32_t* vi,
     const int32_t* index_img, const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F,
-    int64_t vi_sN, int64_t H, int64_t W, void* attr_grad, void* bary_grad, drtk_stream_t stream) {
+    int64_t vi_sN, int64_t H, int64_t W, void* attr_grad, void* bary_grad, void* workspace, size_t workspace_bytes,
+    drtk_stream_t stream) {
   if (bad_common(N, V, C, F, vi_sN, H, W)) return DRTK_ERR_INVALID_ARGUMENT;
   if (!attr_grad && !bary_grad) {
     // A null output is one that was not requested OR is empty (N*V*C == 0 / N*H*W == 0; an empty tensor has no
@@ -1198,18 +1259,27 @@ extern "C" int drtk_amd_interpolate_backward(
   if (N * H * W * C > 0 && (!grad_out || !index_img || !bary_img)) return DRTK_ERR_INVALID_ARGUMENT;
   if ((N * V * C > 0 && !attrs) || (F > 0 && !vi)) return DRTK_ERR_INVALID_ARGUMENT;
   if (dtype != DRTK_F32 && dtype != DRTK_F64) return DRTK_ERR_INVALID_ARGUMENT;
+  if (workspace && reinterpret_cast<uintptr_t>(workspace) % 64 != 0) return DRTK_ERR_INVALID_ARGUMENT; // rows of whole 64-byte segments
   const size_t es = dtype_size(dtype);
-  DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_interpolate_backward(
+  // (slices of views reuse the workspace: each call leaves nothing in it)
+  DRTK_FOR_VIEW_SLICES(N, n0, n, drtk_amd_interpolate_backward_ws(
       dtype, advance(grad_out, n0 * C * H * W, es), advance(attrs, n0 * V * C, es), advance_typed(vi, n0 * vi_sN),
       advance_typed(index_img, n0 * H * W), advance(bary_img, n0 * 3 * H * W, es), n, V, C, F, vi_sN, H, W,
-      advance(attr_grad, n0 * V * C, es), advance(bary_grad, n0 * 3 * H * W, es), stream))
+      advance(attr_grad, n0 * V * C, es), advance(bary_grad, n0 * 3 * H * W, es), workspace, workspace_bytes, stream))
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case DRTK_F32:
-      return interpolate_backward_impl<float>(static_cast<const float*>(grad_out), static_cast<const float*>(attrs), vi, index_img, static_cast<const float*>(bary_img), N, V, C, vi_sN, H, W, static_cast<float*>(attr_grad), static_cast<float*>(bary_grad), s);
+      return interpolate_backward_impl<float>(static_cast<const float*>(grad_out), static_cast<const float*>(attrs), vi, index_img, static_cast<const float*>(bary_img), N, V, C, vi_sN, H, W, static_cast<float*>(attr_grad), static_cast<float*>(bary_grad), static_cast<float*>(workspace), workspace_bytes, s);
     case DRTK_F64:
-      return interpolate_backward_impl<double>(static_cast<const double*>(grad_out), static_cast<const double*>(attrs), vi, index_img, static_cast<const double*>(bary_img), N, V, C, vi_sN, H, W, static_cast<double*>(attr_grad), static_cast<double*>(bary_grad), s);
+      return interpolate_backward_impl<double>(static_cast<const double*>(grad_out), static_cast<const double*>(attrs), vi, index_img, static_cast<const double*>(bary_img), N, V, C, vi_sN, H, W, static_cast<double*>(attr_grad), static_cast<double*>(bary_grad), static_cast<double*>(workspace), workspace_bytes, s);
     default:
       return DRTK_ERR_INVALID_ARGUMENT;
   }
+}
+
+extern "C" int drtk_amd_interpolate_backward(
+    drtk_dtype_t dtype, const void* grad_out, const void* attrs, const int32_t* vi,
+    const int32_t* index_img, const void* bary_img, int64_t N, int64_t V, int64_t C, int64_t F,
+    int64_t vi_sN, int64_t H, int64_t W, void* attr_grad, void* bary_grad, drtk_stream_t stream) {
+  return drtk_amd_interpolate_backward_ws(dtype, grad_out, attrs, vi, index_img, bary_img, N, V, C, F, vi_sN, H, W, attr_grad, bary_grad, nullptr, 0, stream);
 }

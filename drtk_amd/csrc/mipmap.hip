@@ -71,9 +71,6 @@ extern "C" __attribute__((visibility("default"))) int drtk_amd_debug_read_mip_du
 #define DRTK_MIP_TILE_DONE(rounds) do { } while (0)
 #endif
 
-#ifndef DRTK_MIP_NT
-#define DRTK_MIP_NT 0 // 1: the Jacobian image and the lean backward's upstream gradient as non-temporal loads (A/B switch, round 6)
-#endif
 namespace drtk_amd {
 namespace {
 
@@ -266,11 +263,7 @@ __device__ __forceinline__ PixelUV<T> load_pixel_uv(
     p.u = g[0], p.v = g[gl.sC];
   }
   if constexpr (sizeof(T) == 4) {
-#if DRTK_MIP_NT
-    const NtQuad<float> j = nt_load4(vt + index * 4);
-#else
     const float4 j = *reinterpret_cast<const float4*>(vt + index * 4);
-#endif
     p.dudx = j.x, p.dvdx = j.y, p.dudy = j.z, p.dvdy = j.w;
   } else {
     const double2 j0 = *reinterpret_cast<const double2*>(vt + index * 4);
@@ -1651,11 +1644,7 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 4 : (CN <= 3 ? DRTK_MIP_T3_OC
   if (valid) {
     const T* gout_px = grad_out + (int64_t(n) * C_total + c0) * HW + (int64_t(py) * W + px);
 #pragma unroll
-#if DRTK_MIP_NT
-    for (int c = 0; c < CN; ++c) go[c] = __builtin_nontemporal_load(gout_px + int64_t(c) * HW);
-#else
-    for (int c = 0; c < CN; ++c) go[c] = gout_px[int64_t(c) * HW];
-#endif
+    for (int c = 0; c < CN; ++c) go[c] = gout_px[int64_t(c) * HW]; // (as non-temporal loads, with the Jacobian image: 1.283 vs 1.290 ms, round 6 -- nothing)
   }
   PixelUV<T> uv = {};
   // (the pixel's index is rebuilt where it is needed -- here, at an early exit, after the tap loop -- from a laundered thread id:
@@ -2408,6 +2397,9 @@ __device__ __forceinline__ void wave_minmax2(int x, int y, bool on, int& x0, int
   x1 = wave_max_i32(on ? x : INT32_MIN), y1 = wave_max_i32(on ? y : INT32_MIN);
 }
 
+#ifndef DRTK_BICUBIC_ROWS
+#define DRTK_BICUBIC_ROWS 1
+#endif
 // MODE 0: bilinear (2 x 2 texels per tap); MODE 2: bicubic (4 x 4: mipmap_grid_sampler_kernel.cu:806-861) -- the same windows with
 // a span of four cells, interior taps (sixteen consecutive texels inside the level) windowed, the others corner by corner.
 template <typename T, int PAD, bool ALIGN, int MODE = 0>
@@ -2624,6 +2616,32 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (MODE == 2 ? 2 : DR
               const T gOut = go[c] * alpha;
               if (gOut == T(0)) continue; // every term below would be +-0 * finite
               const GlobalPtr<const T> pc = inp + c * plane;
+              if (DRTK_BICUBIC_ROWS && sizeof(T) == 4 && interior && !DRTK_DBG(dbg, 2)) { // (double: 12 registers spilled with the rows in flight)
+                // Round 6: the sixteen texels of an interior footprint as FOUR 16-byte row loads (element-aligned), like the
+                // forward -- they were sixteen predicated 4-byte loads, each in its own exec-mask region with its own wait
+                // (6.87 ms for RGB on the textured benchmark's inputs against 1.29 bilinear).  Same products, same order.
+                typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+                Quad4 row[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) row[r] = *(GlobalPtr<const Quad4>)(pc + (by + r) * w + bx);
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+#pragma unroll
+                  for (int j2 = 0; j2 < 4; ++j2) {
+                    const T wgt = gOut * xc[i2] * yc[j2];
+                    if (DRTK_DBG(dbg, 1)) {
+                    } else if (cell >= 0) {
+                      lds_add(win + cell + c * kWaveCells + j2 * stride + i2, static_cast<double>(wgt));
+                    } else if (!defer) {
+                      atomic_add_g1(gp + c * plane + ((by + j2) * w + bx + i2), wgt);
+                    }
+                    const T val = i2 == 0 ? row[j2].x : i2 == 1 ? row[j2].y : i2 == 2 ? row[j2].z : row[j2].w;
+                    gix -= gOut * val * (xg[i2] * yc[j2]);
+                    giy -= gOut * val * (yg[j2] * xc[i2]);
+                  }
+                }
+                continue;
+              }
 #pragma unroll
               for (int i2 = 0; i2 < 4; ++i2) {
 #pragma unroll

@@ -9,9 +9,6 @@
 #include "common.hpp"
 #include "segscatter.hpp"
 
-#ifndef DRTK_RENDER_NT
-#define DRTK_RENDER_NT 0 // 1: index / upstream-gradient loads non-temporal (A/B switch, round 6)
-#endif
 namespace drtk_amd {
 namespace {
 
@@ -139,11 +136,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
       for (int j = 0; j < 4; ++j) tr[j] = pix0 + j < HW ? idx_p[j] : -1;
     }
   } else if constexpr (VEC == 4) {
-#if DRTK_RENDER_NT
-    const NtQuad<int32_t> t4 = nt_load4(idx_p);
-#else
-    const int4 t4 = *reinterpret_cast<const int4*>(idx_p);
-#endif
+    const int4 t4 = *reinterpret_cast<const int4*>(idx_p); // (non-temporal index / upstream-gradient loads in this file: within the noise, round 6)
     tr[0] = t4.x;
     tr[1] = t4.y;
     tr[2] = t4.z;
@@ -263,11 +256,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) void render_backwar
   // triangle's vertex ids before the reduction -- both dependent gathers fly under the current row.
   auto load_tr = [&](int pass) -> int32_t {
     const int yy = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
-#if DRTK_RENDER_NT
-    return (x < W && yy < H) ? __builtin_nontemporal_load(index_img + int64_t(n) * HW + int64_t(yy) * W + x) : -1;
-#else
     return (x < W && yy < H) ? index_img[int64_t(n) * HW + int64_t(yy) * W + x] : -1;
-#endif
   };
   auto load_face = [&](int32_t t, int32_t (&f)[3]) {
     f[0] = f[1] = f[2] = 0;
@@ -304,13 +293,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) void render_backwar
       const bool dinv_clamped = r.depth_inverse_eps != r.depth_inverse;
 
       const T* gb = grad_bary_img + int64_t(n) * 3 * HW + pix;
-#if DRTK_RENDER_NT
-      const T dL_B0 = __builtin_nontemporal_load(gb), dL_B1 = __builtin_nontemporal_load(gb + HW), dL_B2 = __builtin_nontemporal_load(gb + 2 * HW);
-      const T gD = __builtin_nontemporal_load(grad_depth_img + int64_t(n) * HW + pix);
-#else
       const T dL_B0 = gb[0], dL_B1 = gb[HW], dL_B2 = gb[2 * HW];
       const T gD = grad_depth_img[int64_t(n) * HW + pix];
-#endif
       // render_kernel.cu:225 : *grad_depth + dot(dL_bary_3D * d_inv, bary)
       const T dL_depth = gD + dL_B0 * r.dinv0 * r.b0 +
           dL_B1 * r.dinv1 * r.b1 + dL_B2 * r.dinv2 * r.b2;

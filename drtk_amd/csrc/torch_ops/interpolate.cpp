@@ -95,11 +95,15 @@ std::tuple<Tensor, Tensor> interpolate_backward_hip(
   // interpolate_kernel.cu:657-663
   Tensor vert_grad = vert_requires_grad ? out_empty({N, V, C}, a.options()) : Tensor();
   Tensor bary_grad = bary_requires_grad ? out_empty({N, 3, H, W}, bary_img.options()) : Tensor();
+  // the optional scratch of the padded-row route (attribute rows that are not whole 64-byte segments: include/drtk_amd.h)
+  size_t ws_bytes = 0;
+  if (vert_requires_grad) check_status(drtk_amd_interpolate_backward_workspace_bytes(dt, N, V, C, &ws_bytes), "interpolate_backward");
+  Tensor ws = ws_bytes ? alloc_workspace(ws_bytes, a) : Tensor();
   check_status(
-      drtk_amd_interpolate_backward(
+      drtk_amd_interpolate_backward_ws(
           dt, go_c.data_ptr(), a_c.data_ptr(), via.ptr, idx_c.data_ptr<int32_t>(), bary_c.data_ptr(), N, V,
           C, F, via.sN, H, W, vert_requires_grad ? vert_grad.data_ptr() : nullptr,
-          bary_requires_grad ? bary_grad.data_ptr() : nullptr, current_stream(a)),
+          bary_requires_grad ? bary_grad.data_ptr() : nullptr, ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, current_stream(a)),
       "interpolate_backward");
   return {vert_grad, bary_grad};
 }

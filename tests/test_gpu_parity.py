@@ -858,6 +858,19 @@ def test_interpolate_backward_channel_counts_and_gradient_requests(C, width):
     for got in (bg, bg1):  # per-pixel sums in the reference's order: far inside the bar
         assert float((got.cpu() - bg_o).abs().max()) <= 1e-6 * float(bg_o.abs().max())
     assert float(bg.cpu()[(i_o == -1)[:, None].expand_as(bg_o)].abs().sum()) == 0.0  # background written as exact zeros
+    # the entry point WITHOUT its optional scratch buffer (drtk_amd_interpolate_backward; workspace=False): where the rows of
+    # attr_grad are not whole 64-byte segments the default route above accumulated in padded rows and compacted them (round 6),
+    # this one takes the workgroup's vertex table -- both against the oracle, and against each other to summation order
+    ag_u, bg_u = capi.interpolate_backward(*args, True, True, workspace=False)
+    close(ag_u, ag_o, f"attr grad, unpadded route C={C}")
+    close(ag_u, ag.cpu(), f"attr grad, the two routes C={C}")
+    assert th.equal(bg_u, bg), "the bary gradient does not depend on the route"
+    # the f64 pipeline has its own segment size (8 doubles per 64 bytes)
+    if C in (9, 12, 13, 20):
+        a6, b6 = capi.interpolate_backward(*(t.double() if t.is_floating_point() else t for t in args), True, True)
+        a6_o, b6_o = O.interpolate_backward(go.double(), attr.double(), vi, i_o, rb_o.double())
+        close(a6, a6_o, f"attr grad f64 C={C}", atol=1e-10, rtol=1e-10)
+        close(b6, b6_o, f"bary grad f64 C={C}", atol=1e-10, rtol=1e-10)
 
 
 @pytest.mark.parametrize("dtype", [th.float32, th.float64])
