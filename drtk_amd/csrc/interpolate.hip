@@ -39,6 +39,9 @@ struct Vec4<double> {
 // element's alignment only, and the last lane of a view whose pixel count is not a multiple of four goes pixel by pixel
 // (round 4; before, such images took one pixel per lane: 1.2x the time at 2048 x 2046).
 // (round 6: bounded to 4 waves per SIMD -- 128 registers -- the prefetching instantiation spills 30-38 of its 158)
+#ifndef DRTK_INTERP_FWD_DIAG
+#define DRTK_INTERP_FWD_DIAG 0 // 1 / 2: diagnostic builds of the prefetching forward kernel (profiles/NOTES.md R6.12); never the product
+#endif
 #ifndef DRTK_INTERP_FWD_NT
 #define DRTK_INTERP_FWD_NT 1 // index / barycentric quads as non-temporal loads: read once (0.524 -> 0.508 ms, four interleaved rounds on one box, round 6)
 #endif
@@ -173,8 +176,13 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (tr[j] != -1) {
+#if DRTK_INTERP_FWD_DIAG == 2 // (diagnostic build: no attribute gathers -- the stream alone)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) q[j][k] = V4{B0[j], B1[j], B2[j], T(c0 + k)};
+#else
 #pragma unroll
           for (int k = 0; k < 3; ++k) q[j][k] = *reinterpret_cast<const V4*>(attrs_n + off[j][k] + c0);
+#endif
         }
       }
     };
@@ -197,7 +205,11 @@ __global__ __launch_bounds__(kBlock) void interpolate_kernel(
       }
 #pragma unroll
       for (int cc = 0; cc < CV; ++cc) {
+#if DRTK_INTERP_FWD_DIAG == 1 // (diagnostic build: the planes are computed and not stored -- reads and gathers alone)
+        if (r[cc][0] == T(123456.75) && r[cc][3] == T(-98765.25)) store4(out_p + int64_t(c0 + cc) * HW, r[cc][0], r[cc][1], r[cc][2], r[cc][3]);
+#else
         store4(out_p + int64_t(c0 + cc) * HW, r[cc][0], r[cc][1], r[cc][2], r[cc][3]);
+#endif
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {

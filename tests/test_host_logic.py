@@ -61,6 +61,22 @@ def test_c_abi_argument_validation_without_gpu():
     assert rc == -2  # DRTK_ERR_WORKSPACE_TOO_SMALL
     assert L.drtk_amd_rasterize_lines_workspace_bytes(ctypes.c_int64(2), ctypes.c_int64(8), ctypes.c_int64(8), ctypes.byref(out)) == 0
     assert out.value == 2 * 8 * 8 * 8
+    # interpolate backward's OPTIONAL scratch buffer: rows padded to 64 bytes for float attributes of 11 ... 15 channels, nothing else
+    i64 = ctypes.c_int64
+    for dtype, C, want in ((0, 13, 8 * 1000 * 16 * 4), (0, 11, 8 * 1000 * 16 * 4), (0, 12, 8 * 1000 * 16 * 4), (0, 15, 8 * 1000 * 16 * 4), (0, 16, 0), (0, 10, 0),
+                           (0, 3, 0), (0, 17, 0), (0, 20, 0), (0, 0, 0), (1, 13, 0), (1, 12, 0)):
+        assert L.drtk_amd_interpolate_backward_workspace_bytes(ctypes.c_int(dtype), i64(8), i64(1000), i64(C), ctypes.byref(out)) == 0
+        assert out.value == want, (dtype, C, out.value, want)
+    assert L.drtk_amd_interpolate_backward_workspace_bytes(ctypes.c_int(0), i64(0), i64(1000), i64(13), ctypes.byref(out)) == 0 and out.value == 0
+    assert L.drtk_amd_interpolate_backward_workspace_bytes(ctypes.c_int(0), i64(-1), i64(1000), i64(13), ctypes.byref(out)) == -1
+    assert L.drtk_amd_interpolate_backward_workspace_bytes(ctypes.c_int(7), i64(1), i64(1), i64(13), ctypes.byref(out)) == -1
+    # ... which must be 64-byte aligned when given (whole segments), and may always be absent
+    a16 = ctypes.c_void_p(16)
+    def ibw(ws, nbytes):
+        return L.drtk_amd_interpolate_backward_ws(ctypes.c_int(0), a16, a16, a16, a16, a16, i64(1), i64(0), i64(13), i64(1), i64(0), i64(0), i64(4),
+                                                  ctypes.c_void_p(64), ctypes.c_void_p(64), ctypes.c_void_p(ws), ctypes.c_size_t(nbytes), z)
+    assert ibw(4096 + 16, 1 << 20) == -1          # misaligned workspace
+    assert ibw(0, 0) == 0 and ibw(4096, 1 << 20) == 0  # V = 0, H = 0: nothing to fill or launch, both spellings accepted
     rc = L.drtk_amd_rasterize(ctypes.c_int(0), z, z, ctypes.c_int64(1), ctypes.c_int64(1 << 28), ctypes.c_int64(0),
                               ctypes.c_int64(0), ctypes.c_int64(4), ctypes.c_int64(4), ctypes.c_int(0), z, z, z,
                               ctypes.c_size_t(0), z)
