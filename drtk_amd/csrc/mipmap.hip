@@ -368,6 +368,20 @@ __device__ __forceinline__ Cubic<T> bicubic_footprint(T x, T y, int H, int W, in
   const T ix_nw = floor(ix), iy_nw = floor(iy);
   c.tx = ix - ix_nw;
   c.ty = iy - iy_nw;
+  // Round 6: a footprint whose sixteen texels lie inside the level -- nearly all -- needs none of the eight padding
+  // transforms below: clip, reflect and the integer-range guard map an in-range INTEGER coordinate to itself exactly
+  // (reflection: (k + 1/2) - 1/2 with fmod(k + 1/2, size) == k + 1/2 and no flip), so the indices are nw - 1 ... nw + 2.
+  // Each transform is ~20 instructions (branches on the padding mode, an isfinite through double): 160 per (tap, level).
+  // (the forward kernel under reflection padding goes from four to three waves per SIMD with it -- 138 registers -- and is
+  // still 17 % faster, 1.66 -> 1.38 ms: a reflected index is an fmod, a division and a floor)
+  if (W >= 4 && H >= 4 && fabs(ix) < T(1e9) && fabs(iy) < T(1e9)) { // (the comparisons are false for NaN)
+    const int kx = static_cast<int>(ix_nw), ky = static_cast<int>(iy_nw);
+    if (static_cast<unsigned>(kx - 1) < static_cast<unsigned>(W - 3) && static_cast<unsigned>(ky - 1) < static_cast<unsigned>(H - 3)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c.xi[i] = kx - 1 + i, c.yi[i] = ky - 1 + i;
+      return c;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int xv = static_cast<int>(compute_coordinates<T>(ix_nw - 1 + i, W, padding, align_corners));
@@ -447,7 +461,7 @@ constexpr int kChBlock = 4; // channels accumulated in registers per sweep over 
 
 // PAD: the padding mode as a compile-time constant (see the tile kernels of the backward pass).
 template <typename T, int MODE, int PAD>
-__global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
+__global__ __launch_bounds__(kBlock, (MODE == 2 && sizeof(T) == 4 && PAD != 2) ? 4 : 1) void mipmap_forward_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grid, GridLayout gl, const T* __restrict__ vt, int64_t count, int C,
     int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, T* __restrict__ out, int strip) {
   constexpr int padding = PAD;
@@ -567,13 +581,21 @@ __global__ __launch_bounds__(kBlock) void mipmap_forward_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) co[r] = row[r].x * cx[0] + row[r].y * cx[1] + row[r].z * cx[2] + row[r].w * cx[3];
               } else {
-#pragma unroll
+                // (a footprint on the border of its level, rare: row by row in a loop that is NOT unrolled -- the four rows'
+                // sixteen predicated loads in flight at once were part of what this kernel's registers were for; same sums)
+                T sum = T(0);
+#pragma unroll 1
                 for (int r = 0; r < 4; ++r) {
+                  const int yr = r == 0 ? cb.yi[0] : r == 1 ? cb.yi[1] : r == 2 ? cb.yi[2] : cb.yi[3];
+                  const T cyr = r == 0 ? cy[0] : r == 1 ? cy[1] : r == 2 ? cy[2] : cy[3];
                   T xv[4];
 #pragma unroll
-                  for (int k = 0; k < 4; ++k) xv[k] = (cb.yi[r] >= 0 && cb.xi[k] >= 0) ? p[cb.yi[r] * w + cb.xi[k]] : T(0);
-                  co[r] = xv[0] * cx[0] + xv[1] * cx[1] + xv[2] * cx[2] + xv[3] * cx[3];
+                  for (int k = 0; k < 4; ++k) xv[k] = (yr >= 0 && cb.xi[k] >= 0) ? p[yr * w + cb.xi[k]] : T(0);
+                  const T cor = xv[0] * cx[0] + xv[1] * cx[1] + xv[2] * cx[2] + xv[3] * cx[3];
+                  sum = r == 0 ? cor * cyr : sum + cor * cyr;
                 }
+                acc[cc] += sum * alpha;
+                continue;
               }
               acc[cc] += (co[0] * cy[0] + co[1] * cy[1] + co[2] * cy[2] + co[3] * cy[3]) * alpha;
             }
@@ -2397,11 +2419,14 @@ __device__ __forceinline__ void wave_minmax2(int x, int y, bool on, int& x0, int
   x1 = wave_max_i32(on ? x : INT32_MIN), y1 = wave_max_i32(on ? y : INT32_MIN);
 }
 
+#ifndef DRTK_BICUBIC_COMPACT_SLOW
+#define DRTK_BICUBIC_COMPACT_SLOW 1
+#endif
 #ifndef DRTK_BICUBIC_ROWS
 #define DRTK_BICUBIC_ROWS 1
 #endif
 #ifndef DRTK_MIP_BICUBIC_OCC
-#define DRTK_MIP_BICUBIC_OCC 2
+#define DRTK_MIP_BICUBIC_OCC 3 // (round 6: the compact border path fits 168 registers; 2 until then)
 #endif
 // MODE 0: bilinear (2 x 2 texels per tap); MODE 2: bicubic (4 x 4: mipmap_grid_sampler_kernel.cu:806-861) -- the same windows with
 // a span of four cells, interior taps (sixteen consecutive texels inside the level) windowed, the others corner by corner.
@@ -2648,6 +2673,31 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (MODE == 2 ? DRTK_M
                   const T sc = row[j2].x * xc[0] + row[j2].y * xc[1] + row[j2].z * xc[2] + row[j2].w * xc[3];
                   gix -= gy * sx;
                   giy -= (gOut * yg[j2]) * sc;
+                }
+                continue;
+              }
+              if constexpr (DRTK_BICUBIC_COMPACT_SLOW && sizeof(T) == 4) {
+                // a footprint that touches the border of its level (rare): the sixteen cells in a loop that is NOT unrolled,
+                // coefficients and indices picked by selects -- the unrolled form below (sixteen predicated loads and their
+                // products in flight) is what kept this kernel at 225-243 registers = two waves per SIMD
+                auto sel4 = [](const auto (&a)[4], int k) { return k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]; };
+#pragma unroll 1
+                for (int e = 0; e < 16; ++e) {
+                  const int i2 = e >> 2, j2 = e & 3;
+                  const int xi = sel4(cb.xi, i2), yi = sel4(cb.yi, j2);
+                  const bool ok = xi >= 0 && yi >= 0;
+                  const int o = ok ? yi * w + xi : 0;
+                  const T cxw = sel4(xc, i2), cyw = sel4(yc, j2);
+                  const T wgt = gOut * cxw * cyw;
+                  if (DRTK_DBG(dbg, 1)) {
+                  } else if (cell >= 0) { // (an interior footprint whose rows were not taken above: the ablation build only)
+                    lds_add(win + cell + c * kWaveCells + j2 * stride + i2, static_cast<double>(wgt));
+                  } else if (ok && !defer) {
+                    atomic_add_g1(gp + c * plane + o, wgt);
+                  }
+                  const T val = (ok && !DRTK_DBG(dbg, 2)) ? pc[o] : T(0);
+                  gix -= gOut * val * (sel4(xg, i2) * cyw);
+                  giy -= gOut * val * (sel4(yg, j2) * cxw);
                 }
                 continue;
               }
