@@ -146,6 +146,14 @@ __device__ __forceinline__ T reflect_coord(T in, int twice_low, int twice_high, 
   *grad_in = static_cast<T>(-mult);
   return span - extra + mn;
 }
+__device__ __forceinline__ float tmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double tmin(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float tmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double tmax(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float tabs(float a) { return fabsf(a); }
+__device__ __forceinline__ double tabs(double a) { return fabs(a); }
 // reflect_coord for the lean kernels: the same value and multiplier, the long form only when a lane of the wave needs it.
 // With a = |in - low| < span no flip occurs: fmod(a, span) == a exactly and floor(a / span) == 0, so the reference's
 // `extra + low` is `a + low` -- two additions instead of an fmod, a division and a floor.  (Taps further than one texture
@@ -173,7 +181,7 @@ __device__ __forceinline__ void reflect_clip_lean(T ixu, T iyu, int w, int h, bo
   const T ry = align_corners ? reflect_coord_lean(iyu, 0, 2 * (h - 1), &gy) : reflect_coord_lean(iyu, -1, 2 * h - 1, &gy);
   const T wm1 = static_cast<T>(w - 1), hm1 = static_cast<T>(h - 1);
   mx = ((rx > T(0)) & (rx < wm1)) ? mx * gx : T(0), my = ((ry > T(0)) & (ry < hm1)) ? my * gy : T(0);
-  ix = fminf(fmaxf(rx, T(0)), wm1), iy = fminf(fmaxf(ry, T(0)), hm1);
+  ix = tmin(tmax(rx, T(0)), wm1), iy = tmin(tmax(ry, T(0)), hm1);
 }
 template <typename T>
 __device__ __forceinline__ T safe_int_range(T x) {
@@ -657,14 +665,16 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // and the view's base pointers re-read from the LDS table inside the tap loop (three LDS reads per (tap, level)) instead of
 // living in twelve registers per lane: 62-64 registers = EIGHT waves, 0.59 ms (kernel_bench's minified scenes 0.97 -> 0.80 and
 // 1.23 -> 1.10); four channels per sweep: 70-72 = seven.
+#ifndef DRTK_MIP_FWD_OCC_F64
+#define DRTK_MIP_FWD_OCC_F64 4 // double: waves per SIMD the lean forward is compiled for
+#endif
 #ifndef DRTK_MIP_FWD_OCC
 #define DRTK_MIP_FWD_OCC 8
 #endif
-template <int PAD, int CB>
-__global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap_forward_lean_kernel(
-    LevelTable lv, int mipmaps, const float* __restrict__ grid, GridLayout gl, const float* __restrict__ vt, int C,
-    int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, float* __restrict__ out, int strip) {
-  using T = float;
+template <typename T, int PAD, int CB>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? DRTK_MIP_FWD_OCC_F64 : (CB <= 3 ? DRTK_MIP_FWD_OCC : 7)) void mipmap_forward_lean_kernel(
+    LevelTable lv, int mipmaps, const T* __restrict__ grid, GridLayout gl, const T* __restrict__ vt, int C,
+    int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, T* __restrict__ out, int strip) {
   static_assert(PAD >= 0 && PAD <= 2, "zeros, border or reflection padding");
   static_assert(CB >= 1 && CB <= 4, "channels per sweep over the taps (C is a multiple of CB)");
   constexpr int padding = PAD;
@@ -687,9 +697,10 @@ __global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap
   const int n_lv = mipmaps > 1 ? 2 : 1;
   // the levels' weights a / n and (1 - a) / n: continuous quantities, computed in float from one reciprocal (the reference
   // divides the second one in double, :486: a 16-instruction sequence at a quarter of the float rate, for the last ulp)
+  // (double: the reference's two divisions, :485-486 -- the once-per-pixel cost is nothing beside the taps)
   const T rn = T(1) / static_cast<T>(max(t.n, 1));
-  const T alpha_1 = valid ? t.a * rn : T(0);
-  const T alpha_2 = valid ? (T(1) - t.a) * rn : T(0);
+  const T alpha_1 = !valid ? T(0) : sizeof(T) == 8 ? t.a / static_cast<T>(max(t.n, 1)) : t.a * rn;
+  const T alpha_2 = !valid ? T(0) : sizeof(T) == 8 ? (T(1) - t.a) / static_cast<T>(max(t.n, 1)) : (T(1) - t.a) * rn;
   // level slot s = 0: level d1 with weight alpha_2; s = 1: level d1 + 1 with alpha_1.  A slot whose weight is exactly
   // zero -- the coarser level of every magnified pixel -- is dead (as in the kernels above).
   const bool live[2] = {bool(valid & (alpha_2 != T(0))), bool(valid & (n_lv == 2) & (alpha_1 != T(0)))};
@@ -730,16 +741,16 @@ __global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap
         // made finite first (a clamp that cannot move a tap whose cell lies inside the level), so that the weights of the
         // lanes that do not count -- no tap, a tap on or beyond the border, a NaN -- are finite and their products with
         // alpha = 0 vanish; those lanes' real contribution, if any, comes from the branch below.
-        T ix = ((x + 1.f) * lwf[s] - 1) / 2, iy = ((y + 1.f) * lhf[s] - 1) / 2;
+        T ix = ((x + T(1)) * lwf[s] - 1) / 2, iy = ((y + T(1)) * lhf[s] - 1) / 2;
         bool sane = true; // (reflection: a coordinate the short pipeline must not touch goes to the corner-by-corner branch)
         if (padding == 1) {
-          ix = fminf(fmaxf(ix, T(0)), lwf[s] - T(1)), iy = fminf(fmaxf(iy, T(0)), lhf[s] - T(1)); // == clip_coord but NaN -> 0
+          ix = tmin(tmax(ix, T(0)), lwf[s] - T(1)), iy = tmin(tmax(iy, T(0)), lhf[s] - T(1)); // == clip_coord but NaN -> 0
         } else if (padding == 2) {
-          sane = (fabsf(ix) < T(1e9f)) & (fabsf(iy) < T(1e9f)); // (false for NaN)
+          sane = (tabs(ix) < T(1e9f)) & (tabs(iy) < T(1e9f)); // (false for NaN)
           T unused_x = T(1), unused_y = T(1);
           reflect_clip_lean<T>(sane ? ix : T(0), sane ? iy : T(0), lw[s], lh[s], align_corners, ix, iy, unused_x, unused_y);
         } else {
-          ix = fminf(fmaxf(ix, T(-4)), T(2e9f)), iy = fminf(fmaxf(iy, T(-4)), T(2e9f));
+          ix = tmin(tmax(ix, T(-4)), T(2e9f)), iy = tmin(tmax(iy, T(-4)), T(2e9f));
         }
         const T fx_floor = floor(ix), fy_floor = floor(iy);
         const int ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
@@ -768,10 +779,10 @@ __global__ __launch_bounds__(kBlock, CB <= 3 ? DRTK_MIP_FWD_OCC : 7) void mipmap
           }
 #pragma unroll
           for (int cc = 0; cc < CB; ++cc) {
-            acc[cc] = __builtin_fmaf(top[cc].x, w_nw, acc[cc]);
-            acc[cc] = __builtin_fmaf(top[cc].y, w_ne, acc[cc]);
-            acc[cc] = __builtin_fmaf(bot[cc].x, w_sw, acc[cc]);
-            acc[cc] = __builtin_fmaf(bot[cc].y, w_se, acc[cc]);
+            acc[cc] = tfma(top[cc].x, w_nw, acc[cc]);
+            acc[cc] = tfma(top[cc].y, w_ne, acc[cc]);
+            acc[cc] = tfma(bot[cc].x, w_sw, acc[cc]);
+            acc[cc] = tfma(bot[cc].y, w_se, acc[cc]);
           }
         }
         if (__ballot(on & !interior) != 0) {
@@ -1574,6 +1585,9 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #ifndef DRTK_MIP_T3_OCC
 #define DRTK_MIP_T3_OCC 5
 #endif
+#ifndef DRTK_MIP_T3_OCC_F64
+#define DRTK_MIP_T3_OCC_F64 3 // double: tiles per CU the lean backward is compiled for
+#endif
 #ifndef DRTK_MIP_T3_OCC4
 #define DRTK_MIP_T3_OCC4 5 // four channels per pass: 96 registers, windows of 2 x 384 accumulators (24.6 KB): C = 4 / 8 / 16 1.62 / 3.17 / 6.33 -> 1.51 / 2.92 / 5.90 ms
 #endif
@@ -1607,14 +1621,13 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 template <int CN>
 constexpr int lean_slot_cells() { return CN == 4 ? DRTK_MIP_T3_SLOT_CELLS4 : CN == 3 ? DRTK_MIP_T3_SLOT_CELLS : DRTK_MIP_T3_SLOT_CELLS12; }
 static_assert(DRTK_MIP_T3_SLOT_CELLS % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS4 % 128 == 0 && DRTK_MIP_T3_SLOT_CELLS12 % 128 == 0, "whole rows at every slot width (16 ... 128 cells), cells in pairs");
-template <int PAD, bool ALIGN, int CN>
+template <typename T, int PAD, bool ALIGN, int CN>
 // (reflection padding, round 6: the reflect + clip of both axes takes the kernel 2-4 registers over the 96 of five tiles per CU;
 // compiled for four -- 128 registers, no spill; the windows keep the five-tile size)
-__global__ __launch_bounds__(kMipBlock, PAD == 2 ? 4 : (CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_OCC4)) void mipmap_backward_lean_kernel(
-    LevelTable lv, int mipmaps, const float* __restrict__ grad_out, const float* __restrict__ grid, GridLayout gl,
-    const float* __restrict__ vt, int H, int W, int tiles_x, int max_aniso,
-    bool force_max_aniso, bool clip_grad, float* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg, int C_total, int c0) {
-  using T = float;
+__global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? DRTK_MIP_T3_OCC_F64 : PAD == 2 ? 4 : (CN <= 3 ? DRTK_MIP_T3_OCC : DRTK_MIP_T3_OCC4)) void mipmap_backward_lean_kernel(
+    LevelTable lv, int mipmaps, const T* __restrict__ grad_out, const T* __restrict__ grid, GridLayout gl,
+    const T* __restrict__ vt, int H, int W, int tiles_x, int max_aniso,
+    bool force_max_aniso, bool clip_grad, T* __restrict__ grad_grid, GridLayout ggl, int strip, int dbg, int C_total, int c0) {
   static_assert(PAD >= 0 && PAD <= 2, "zeros, border or reflection padding");
   static_assert(CN >= 1 && CN <= 4, "texture channels");
   constexpr int C = CN;
@@ -1880,12 +1893,12 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 4 : (CN <= 3 ? DRTK_MIP_T3_OC
         bool sane = true; // (reflection: a coordinate the short pipeline must not touch goes to the corner-by-corner branch)
         if (padding == 1) { // clip_coord: clamped coordinates have a zero gradient
           mx = ((ixu > T(0)) & (ixu < wm1)) ? mx : T(0), my = ((iyu > T(0)) & (iyu < hm1)) ? my : T(0);
-          ix = fminf(fmaxf(ixu, T(0)), wm1), iy = fminf(fmaxf(iyu, T(0)), hm1);
+          ix = tmin(tmax(ixu, T(0)), wm1), iy = tmin(tmax(iyu, T(0)), hm1);
         } else if (padding == 2) { // reflect_coord, then clip_coord (source_index's order)
-          sane = (fabsf(ixu) < T(1e9f)) & (fabsf(iyu) < T(1e9f));
+          sane = (tabs(ixu) < T(1e9f)) & (tabs(iyu) < T(1e9f));
           reflect_clip_lean<T>(sane ? ixu : T(0), sane ? iyu : T(0), w, h, align_corners, ix, iy, mx, my);
         } else { // (made finite; a tap whose cell lies inside the level is not moved)
-          ix = fminf(fmaxf(ixu, T(-4)), T(2e9f)), iy = fminf(fmaxf(iyu, T(-4)), T(2e9f));
+          ix = tmin(tmax(ixu, T(-4)), T(2e9f)), iy = tmin(tmax(iyu, T(-4)), T(2e9f));
         }
         const T fx_floor = floor(ix), fy_floor = floor(iy);
         const int ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
@@ -2099,13 +2112,13 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 4 : (CN <= 3 ? DRTK_MIP_T3_OC
     T ix, iy;
     bool sane = true;
     if (padding == 1) {
-      ix = fminf(fmaxf(ixu, T(0)), wm1), iy = fminf(fmaxf(iyu, T(0)), hm1);
+      ix = tmin(tmax(ixu, T(0)), wm1), iy = tmin(tmax(iyu, T(0)), hm1);
     } else if (padding == 2) {
-      sane = (fabsf(ixu) < T(1e9f)) & (fabsf(iyu) < T(1e9f));
+      sane = (tabs(ixu) < T(1e9f)) & (tabs(iyu) < T(1e9f));
       T unused_x = T(1), unused_y = T(1);
       reflect_clip_lean<T>(sane ? ixu : T(0), sane ? iyu : T(0), w, h, align_corners, ix, iy, unused_x, unused_y);
     } else {
-      ix = fminf(fmaxf(ixu, T(-4)), T(2e9f)), iy = fminf(fmaxf(iyu, T(-4)), T(2e9f));
+      ix = tmin(tmax(ixu, T(-4)), T(2e9f)), iy = tmin(tmax(iyu, T(-4)), T(2e9f));
     }
     const T fx_floor = floor(ix), fy_floor = floor(iy);
     ix_nw = static_cast<int>(fx_floor), iy_nw = static_cast<int>(fy_floor);
@@ -2118,8 +2131,8 @@ __global__ __launch_bounds__(kMipBlock, PAD == 2 ? 4 : (CN <= 3 ? DRTK_MIP_T3_OC
   // (evaluated where a round needs it: a register less across the tap loop)
   auto tap_span = [&]() -> int {
     const T step = T(2) / static_cast<T>(t.n + 1);
-    const T sp = fmaxf(fabsf(static_cast<T>(t.du)) * static_cast<T>(s_w[t.d1]), fabsf(static_cast<T>(t.dv)) * static_cast<T>(s_h[t.d1])) * step * T(0.5);
-    return static_cast<int>(fminf(T(16), T(258) / fmaxf(sp, T(1)))) + 1;
+    const T sp = tmax(tabs(static_cast<T>(t.du)) * static_cast<T>(s_w[t.d1]), tabs(static_cast<T>(t.dv)) * static_cast<T>(s_h[t.d1])) * step * T(0.5);
+    return static_cast<int>(tmin(T(16), T(258) / tmax(sp, T(1)))) + 1;
   };
   int ref_now = ref, npend_before = 0;
   for (int round = 1;; ++round) {
@@ -2991,15 +3004,20 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d(
 #ifndef DRTK_MIP_FWD_LEAN
 #define DRTK_MIP_FWD_LEAN 1
 #endif
-#define LAUNCH_L(PAD, CB)                                                                                      \
+#ifndef DRTK_MIP_FWD_LEAN_F64
+#define DRTK_MIP_FWD_LEAN_F64 1 // double takes the lean forward too (round 6)
+#endif
+#define LAUNCH_L(T, PAD, CB)                                                                                      \
   DRTK_LAUNCH(                                                                                                 \
-      (mipmap_forward_lean_kernel<PAD, CB>), dim3(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N)), \
-      dim3(kBlock), 0, s, lv, mipmaps, static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)C, \
-      H * W, max_aniso, force_max_aniso != 0, clip_grad != 0, static_cast<float*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
-#define LAUNCH_LC(PAD)                                                                    \
-  if (C % 4 == 0) LAUNCH_L(PAD, 4); else if (C % 3 == 0) LAUNCH_L(PAD, 3); else if (C % 2 == 0) LAUNCH_L(PAD, 2); else LAUNCH_L(PAD, 1)
+      (mipmap_forward_lean_kernel<T, PAD, CB>), dim3(static_cast<unsigned>(ceil_div(H * W, kBlock)), static_cast<unsigned>(N)), \
+      dim3(kBlock), 0, s, lv, mipmaps, static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)C, \
+      H * W, max_aniso, force_max_aniso != 0, clip_grad != 0, static_cast<T*>(out), xcd_strip(ceil_div(16 * W, kBlock)))
+#define LAUNCH_LC(T, PAD)                                                                  \
+  if (C % 4 == 0) LAUNCH_L(T, PAD, 4); else if (C % 3 == 0) LAUNCH_L(T, PAD, 3); else if (C % 2 == 0) LAUNCH_L(T, PAD, 2); else LAUNCH_L(T, PAD, 1)
   if (dtype == DRTK_F32 && interpolation_mode == 0 && N <= kMaxViewsPerLaunch && DRTK_MIP_FWD_LEAN && lean_planes_ok(lv, mipmaps)) {
-    if (padding_mode == 0) { LAUNCH_LC(0); } else if (padding_mode == 1) { LAUNCH_LC(1); } else { LAUNCH_LC(2); }
+    if (padding_mode == 0) { LAUNCH_LC(float, 0); } else if (padding_mode == 1) { LAUNCH_LC(float, 1); } else { LAUNCH_LC(float, 2); }
+  } else if (dtype == DRTK_F64 && interpolation_mode == 0 && N <= kMaxViewsPerLaunch && DRTK_MIP_FWD_LEAN && DRTK_MIP_FWD_LEAN_F64 && lean_planes_ok(lv, mipmaps)) {
+    if (padding_mode == 0) { LAUNCH_LC(double, 0); } else if (padding_mode == 1) { LAUNCH_LC(double, 1); } else { LAUNCH_LC(double, 2); }
   } else if (dtype == DRTK_F32) {
     if (interpolation_mode == 0) { LAUNCH(float, 0); } else { LAUNCH(float, 2); }
   } else {
@@ -3055,19 +3073,22 @@ extern "C" int drtk_amd_mipmap_grid_sampler_2d_backward(
 #ifndef DRTK_MIP_BWD_LEAN
 #define DRTK_MIP_BWD_LEAN 1
 #endif
+#ifndef DRTK_MIP_BWD_LEAN_F64
+#define DRTK_MIP_BWD_LEAN_F64 1 // double takes the lean tile kernel too (round 6; before: tiled2 at 240-256 registers)
+#endif
 #ifndef DRTK_MIP_BWD_LEAN_WIDE
 #define DRTK_MIP_BWD_LEAN_WIDE 1 // C > 4: the lean tile kernel once per block of four channels instead of the wave-private kernel
 #endif
-    if constexpr (sizeof(T) == 4 && DRTK_MIP_BWD_LEAN) {
+    if constexpr ((sizeof(T) == 4 || DRTK_MIP_BWD_LEAN_F64) && DRTK_MIP_BWD_LEAN) {
       if (interpolation_mode == 0 && C >= 1 && N <= 65535 && !DRTK_DBG(debug_flags(), 512) &&
-          (C <= 4 || DRTK_MIP_BWD_LEAN_WIDE) && lean_planes_ok(lv, mipmaps)) { // float, bilinear, zeros / border padding: the lean tap loop, four channels a launch
+          (C <= 4 || DRTK_MIP_BWD_LEAN_WIDE) && lean_planes_ok(lv, mipmaps)) { // bilinear, any padding, float and double: the lean tap loop, four channels a launch
         const int tiles_x = static_cast<int>(ceil_div(W, kTileW)), tiles_y = static_cast<int>(ceil_div(H, kTileH));
 #define LEANK(PAD, ALIGN, CN)                                                                                           \
   DRTK_LAUNCH(                                                                                                          \
-      (mipmap_backward_lean_kernel<PAD, ALIGN, CN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
-      dim3(kMipBlock), sizeof(double) * CN * kWinLevels * lean_slot_cells<CN>(), s, lv, mipmaps, static_cast<const float*>(grad_out), \
-      static_cast<const float*>(grid), gl, static_cast<const float*>(vt_dxdy_img), (int)H, (int)W, tiles_x, max_aniso, \
-      force_max_aniso != 0, clip_grad != 0, static_cast<float*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags(), (int)C, c0)
+      (mipmap_backward_lean_kernel<T, PAD, ALIGN, CN>), dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(N)), \
+      dim3(kMipBlock), sizeof(double) * CN * kWinLevels * lean_slot_cells<CN>(), s, lv, mipmaps, static_cast<const T*>(grad_out), \
+      static_cast<const T*>(grid), gl, static_cast<const T*>(vt_dxdy_img), (int)H, (int)W, tiles_x, max_aniso, \
+      force_max_aniso != 0, clip_grad != 0, static_cast<T*>(grad_grid), ggl, xcd_strip(tiles_x), debug_flags(), (int)C, c0)
 #define LEANC(PAD, ALIGN)                                                                       \
   switch (cn) {                                                                                 \
     case 1: LEANK(PAD, ALIGN, 1); break;                                                        \

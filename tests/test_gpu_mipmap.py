@@ -14,8 +14,6 @@ DEV = "cuda:0"
 def close(a, ref, what, atol=1e-5, rtol=1e-5):
     a, ref = a.detach().cpu().double(), ref.detach().cpu().double()
     assert a.shape == ref.shape, (what, a.shape, ref.shape)
-    if ref.dtype == th.float64 and atol == 1e-5:
-        pass
     tol = atol + rtol * float(ref.abs().max()) if ref.numel() else atol
     err = float((a - ref).abs().max()) if ref.numel() else 0.0
     assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
@@ -220,19 +218,23 @@ def test_non_finite_texels_under_a_zero_weight_stay_out_of_the_result():
     close(gl[0], gl_clean[0].cpu(), "gradient of level 0 (sums of float atomics: equal to rounding)")
 
 
+@pytest.mark.parametrize("dtype", [th.float32, th.float64])
 @pytest.mark.parametrize("padding", [0, 1])
 @pytest.mark.parametrize("C", [1, 3, 4, 5])
-def test_a_non_finite_texel_reaches_only_the_pixels_that_sample_it(padding, C):
+def test_a_non_finite_texel_reaches_only_the_pixels_that_sample_it(padding, C, dtype):
     """Round 5's lean kernels let every lane WITHOUT an interior tap (fewer taps than its wave, a border tap, a NaN
     coordinate, a dead level) run its wave's loads at offset 0 of a level with weight 0: a NaN or Inf in texel (0,0) or
     (1,0) of a level became `NaN * 0` in pixels that never sample it.  The reference touches only the texels it samples:
     with a poisoned texel (0,0) on the two finest levels the NaN pattern of the output equals the oracle's, the other
-    pixels are equal to rounding, and the gradients of the pixels that do not sample it stay finite."""
+    pixels are equal to rounding, and the gradients of the pixels that do not sample it stay finite.  (Double runs the
+    same lean kernels since round 6; its bars are double's.)"""
     import oracle as O
     from drtk_amd import capi
 
     H, W = 40, 56
     tex, grid, vt, gout = mipmap_inputs(4100 + 10 * padding + C, 2, C, 64, 4, H, W, jscale=0.03)
+    tex, grid, vt, gout = [t.to(dtype) for t in tex], grid.to(dtype), vt.to(dtype), gout.to(dtype)
+    tol = dict(atol=1e-5, rtol=1e-5) if dtype == th.float32 else dict(atol=1e-12, rtol=1e-12)
     grid = grid.clone()
     grid[:, :, : W // 2] = grid[:, :, : W // 2].abs().clamp(0.05, 1.15)  # left half: away from texel (0,0), some taps beyond the border
     grid[0, :4, :4] = float("nan")                                      # and a few NaN coordinates
@@ -249,7 +251,7 @@ def test_a_non_finite_texel_reaches_only_the_pixels_that_sample_it(padding, C):
     # (a level of weight exactly 0 is skipped by the kernels and multiplied in by the reference: only ever MORE finite pixels here)
     assert not bool((gn & ~wn).any()), f"{int((gn & ~wn).sum())} pixels are non-finite that never sample the poisoned texel"
     ok = ~wn & ~gn
-    close(got[ok], want[ok], "forward, pixels that do not sample the poisoned texel")
+    close(got[ok], want[ok], "forward, pixels that do not sample the poisoned texel", **tol)
     clean = capi.mipmap_grid_sampler_2d(dev(tex), dev(grid), dev(vt), 8, padding, 0, False, False, False).cpu()
     assert th.equal(got[:, :, :, : W // 2], clean[:, :, :, : W // 2]), "pixels away from the poisoned texel: bit-equal to the finite texture's"
     # backward: the grid gradient of a pixel that samples the texel is non-finite in the reference too; the others are finite
@@ -260,14 +262,15 @@ def test_a_non_finite_texel_reaches_only_the_pixels_that_sample_it(padding, C):
     # (where the upstream gradient is zero the reference still forms 0 * texel for the grid gradient: NaN on the pixels that
     # sample the poisoned texel; the kernels count the texels of a zero upstream gradient as 0 -- include/drtk_amd.h)
     assert bool(th.isfinite(wg[:, :, : W // 2]).all()), "scene: the reference's grid gradient is finite where the upstream gradient lives"
-    close(gg[:, :, : W // 2], wg[:, :, : W // 2], "grad grid", atol=2e-5)
+    close(gg[:, :, : W // 2], wg[:, :, : W // 2], "grad grid", atol=2 * tol["atol"], rtol=tol["rtol"])
     assert float(gg[:, :, W // 2:].abs().max()) == 0.0
     for i, (a, b) in enumerate(zip(gl, wl)):
-        close(a, b, f"grad level {i}")
+        close(a, b, f"grad level {i}", **tol)
 
 
+@pytest.mark.parametrize("dtype", [th.float32, th.float64])
 @pytest.mark.parametrize("C", [1, 2, 3, 4, 5])
-def test_a_one_by_one_last_level_followed_by_poison_in_memory(C):
+def test_a_one_by_one_last_level_followed_by_poison_in_memory(C, dtype):
     """A full pyramid (16, 8, 4, 2, 1) carved from ONE buffer, the 1 x 1 level last, NaN (and the bits of int32 -1) right
     behind it: on a 1 x 1 level the pair at offset 0 of the last channel of the last view ends one element beyond the
     tensor -- round 5's lean kernels read it on every lane without an interior tap (every tap of a 1 x 1 level is a border
@@ -279,16 +282,18 @@ def test_a_one_by_one_last_level_followed_by_poison_in_memory(C):
     sizes = [16, 8, 4, 2, 1]
     g = th.Generator().manual_seed(900 + C)
     n_el = [N * C * s * s for s in sizes]
-    for poison in (float("nan"), th.tensor([-1], dtype=th.int32).view(th.float32).item()):
-        buf = th.full((sum(n_el) + 64,), poison, dtype=th.float32)
+    ibits = th.int32 if dtype == th.float32 else th.int64
+    tol = dict(atol=1e-5, rtol=1e-5) if dtype == th.float32 else dict(atol=1e-12, rtol=1e-12)
+    for poison in (float("nan"), th.tensor([-1], dtype=ibits).view(dtype).item()):
+        buf = th.full((sum(n_el) + 64,), poison, dtype=dtype)
         tex, off = [], 0
         for s, n in zip(sizes, n_el):
-            buf[off: off + n] = th.rand(n, generator=th.Generator().manual_seed(17 * s + C))
+            buf[off: off + n] = th.rand(n, generator=th.Generator().manual_seed(17 * s + C)).to(dtype)
             tex.append(buf[off: off + n].view(N, C, s, s))
             off += n
-        grid = th.rand(N, H, W, 2, generator=g) * 2.2 - 1.1
-        vt = th.randn(N, H, W, 2, 2, generator=g) * (0.25 + 4.0 * th.rand(N, H, W, 1, 1, generator=g))
-        gout = th.rand(N, C, H, W, generator=g) * 2 - 1
+        grid = (th.rand(N, H, W, 2, generator=g) * 2.2 - 1.1).to(dtype)
+        vt = (th.randn(N, H, W, 2, 2, generator=g) * (0.25 + 4.0 * th.rand(N, H, W, 1, 1, generator=g))).to(dtype)
+        gout = (th.rand(N, C, H, W, generator=g) * 2 - 1).to(dtype)
         dbuf = buf.to(DEV)
         dtex, off = [], 0
         for s, n in zip(sizes, n_el):
@@ -299,12 +304,12 @@ def test_a_one_by_one_last_level_followed_by_poison_in_memory(C):
                 want = O.mipmap_grid_sampler_2d([t.clone() for t in tex], grid, vt, 4, padding, 0, False, force, False)
                 got = capi.mipmap_grid_sampler_2d(dtex, dev(grid), dev(vt), 4, padding, 0, False, force, False)
                 assert bool(th.isfinite(got).all()), "the poison behind the 1 x 1 level leaked into the output"
-                close(got, want, "forward")
+                close(got, want, "forward", **tol)
                 wl, wg = O.mipmap_grid_sampler_2d_backward(gout, [t.clone() for t in tex], grid, vt, 4, padding, 0, False, force, False)
                 gl, gg = capi.mipmap_grid_sampler_2d_backward(dev(gout), dtex, dev(grid), dev(vt), 4, padding, 0, False, force, False)
-                close(gg, wg, "grad grid", atol=2e-5)
+                close(gg, wg, "grad grid", atol=2 * tol["atol"], rtol=tol["rtol"])
                 for i, (a, b) in enumerate(zip(gl, wl)):
-                    close(a, b, f"grad level {i}")
+                    close(a, b, f"grad level {i}", **tol)
 
 
 @pytest.mark.parametrize("layout", ["pixel_major", "channel_major"])
