@@ -222,10 +222,61 @@ __global__ __launch_bounds__(kBlock) void render_kernel(
   }
 }
 
+// The nine vertex-position gradients of one covered pixel (render_kernel.cu:220-262) from the shared forward quantities
+// `r` and the upstream gradients of the three barycentrics and the depth: g = {v0.x, v0.y, v0.z, v1.x, ..., v2.z}.
+template <typename T>
+__device__ __forceinline__ void render_backward_pixel(const RenderPix<T>& r, T dL_B0, T dL_B1, T dL_B2, T gD, T (&g)[9]) {
+  const bool den_clamped = r.den != r.den_raw;
+  const bool dinv_clamped = r.depth_inverse_eps != r.depth_inverse;
+
+  // render_kernel.cu:225 : *grad_depth + dot(dL_bary_3D * d_inv, bary)
+  const T dL_depth = gD + dL_B0 * r.dinv0 * r.b0 +
+      dL_B1 * r.dinv1 * r.b1 + dL_B2 * r.dinv2 * r.b2;
+  // (1 / s^2 as depth^2 and 1 / z_k^2 as dinv_k^2 -- four quarter-rate reciprocals less per pixel -- measured nothing:
+  // 0.2035 vs 0.2040 ms, round 6)
+  const T dL_dinv_s =
+      dinv_clamped ? T(0) : quotient<false>(-dL_depth, r.depth_inverse * r.depth_inverse);
+
+  const T dL_dinv0 = dL_B0 * r.b0 * r.depth + dL_dinv_s * r.b0;
+  const T dL_dinv1 = dL_B1 * r.b1 * r.depth + dL_dinv_s * r.b1;
+  const T dL_dinv2 = dL_B2 * r.b2 * r.depth + dL_dinv_s * r.b2;
+  g[2] = r.z0c ? T(0) : quotient<false>(-dL_dinv0, r.z0e * r.z0e);
+  g[5] = r.z1c ? T(0) : quotient<false>(-dL_dinv1, r.z1e * r.z1e);
+  g[8] = r.z2c ? T(0) : quotient<false>(-dL_dinv2, r.z2e * r.z2e);
+
+  const T dL_b0 = dL_B0 * r.dinv0 * r.depth + dL_dinv_s * r.dinv0;
+  const T dL_b1 = dL_B1 * r.dinv1 * r.depth + dL_dinv_s * r.dinv1;
+  const T dL_b2 = dL_B2 * r.dinv2 * r.depth + dL_dinv_s * r.dinv2;
+  const T dL_b12x = -dL_b0 + dL_b1;
+  const T dL_b12y = -dL_b0 + dL_b2;
+  const T prex = quotient<false>(dL_b12x, r.den);
+  const T prey = quotient<false>(dL_b12y, r.den);
+  const T dL_den = den_clamped ? T(0) : -(prex * r.b1 + prey * r.b2);
+
+  const T dL_vp0x = prex * r.v02y - prey * r.v01y;
+  const T dL_vp0y = -prex * r.v02x + prey * r.v01x;
+  const T dL_v02x = -prex * r.vp0y - dL_den * r.v01y;
+  const T dL_v02y = prex * r.vp0x + dL_den * r.v01x;
+  const T dL_v01x = prey * r.vp0y + dL_den * r.v02y;
+  const T dL_v01y = -prey * r.vp0x - dL_den * r.v02x;
+
+  g[0] = -dL_v02x - dL_v01x - dL_vp0x;
+  g[1] = -dL_v02y - dL_v01y - dL_vp0y;
+  g[3] = dL_v01x;
+  g[4] = dL_v01y;
+  g[6] = dL_v02x;
+  g[7] = dL_v02y;
+}
+
 // Backward: a workgroup owns a 64 x 16 pixel tile; each of its 4 waves walks 4 adjacent rows of 64 pixels.  Lane = pixel:
 // the nine per-pixel terms stay in registers, a segmented scan over the 16-lane rows leaves each run's sums in its
 // last lane (segscatter.hpp: run_sums_rows16), and only those lanes update the wave's vertex table -- so every vertex
 // costs one global atomic per component per 64 x 4 pixel tile.  No LDS staging, no barrier inside the loop.
+// (Round 6: the same tile with FOUR pixels per lane -- five 16-byte loads per lane, one scan per 256 pixels, corner ids and
+// vertices kept across a lane's pixels, ~25 % fewer instructions -- was built and is parity-green, and runs 0.226-0.237 ms
+// against this kernel's 0.223-0.232 on the benchmark shape: its three dependent round trips per tile at five waves per
+// SIMD cost what the instructions save.  Kernel text, ablation and the K-tiles-per-wave variants:
+// profiles/r06/render_backward_quad.hip.txt.)
 template <typename T>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) void render_backward_kernel(
     const T* __restrict__ v, const int32_t* __restrict__ vi, const int32_t* __restrict__ index_img,
@@ -289,49 +340,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) void render_backwar
     } else if (tr != -1) {
       RenderPix<T> r;
       render_pix<T, false>(v_n, cur[0], cur[1], cur[2], x, y, r);
-      const bool den_clamped = r.den != r.den_raw;
-      const bool dinv_clamped = r.depth_inverse_eps != r.depth_inverse;
-
       const T* gb = grad_bary_img + int64_t(n) * 3 * HW + pix;
-      const T dL_B0 = gb[0], dL_B1 = gb[HW], dL_B2 = gb[2 * HW];
-      const T gD = grad_depth_img[int64_t(n) * HW + pix];
-      // render_kernel.cu:225 : *grad_depth + dot(dL_bary_3D * d_inv, bary)
-      const T dL_depth = gD + dL_B0 * r.dinv0 * r.b0 +
-          dL_B1 * r.dinv1 * r.b1 + dL_B2 * r.dinv2 * r.b2;
-      // (1 / s^2 as depth^2 and 1 / z_k^2 as dinv_k^2 -- four quarter-rate reciprocals less per pixel -- measured nothing:
-      // 0.2035 vs 0.2040 ms, round 6)
-      const T dL_dinv_s =
-          dinv_clamped ? T(0) : quotient<false>(-dL_depth, r.depth_inverse * r.depth_inverse);
-
-      const T dL_dinv0 = dL_B0 * r.b0 * r.depth + dL_dinv_s * r.b0;
-      const T dL_dinv1 = dL_B1 * r.b1 * r.depth + dL_dinv_s * r.b1;
-      const T dL_dinv2 = dL_B2 * r.b2 * r.depth + dL_dinv_s * r.b2;
-      g[2] = r.z0c ? T(0) : quotient<false>(-dL_dinv0, r.z0e * r.z0e);
-      g[5] = r.z1c ? T(0) : quotient<false>(-dL_dinv1, r.z1e * r.z1e);
-      g[8] = r.z2c ? T(0) : quotient<false>(-dL_dinv2, r.z2e * r.z2e);
-
-      const T dL_b0 = dL_B0 * r.dinv0 * r.depth + dL_dinv_s * r.dinv0;
-      const T dL_b1 = dL_B1 * r.dinv1 * r.depth + dL_dinv_s * r.dinv1;
-      const T dL_b2 = dL_B2 * r.dinv2 * r.depth + dL_dinv_s * r.dinv2;
-      const T dL_b12x = -dL_b0 + dL_b1;
-      const T dL_b12y = -dL_b0 + dL_b2;
-      const T prex = quotient<false>(dL_b12x, r.den);
-      const T prey = quotient<false>(dL_b12y, r.den);
-      const T dL_den = den_clamped ? T(0) : -(prex * r.b1 + prey * r.b2);
-
-      const T dL_vp0x = prex * r.v02y - prey * r.v01y;
-      const T dL_vp0y = -prex * r.v02x + prey * r.v01x;
-      const T dL_v02x = -prex * r.vp0y - dL_den * r.v01y;
-      const T dL_v02y = prex * r.vp0x + dL_den * r.v01x;
-      const T dL_v01x = prey * r.vp0y + dL_den * r.v02y;
-      const T dL_v01y = -prey * r.vp0x - dL_den * r.v02x;
-
-      g[0] = -dL_v02x - dL_v01x - dL_vp0x;
-      g[1] = -dL_v02y - dL_v01y - dL_vp0y;
-      g[3] = dL_v01x;
-      g[4] = dL_v01y;
-      g[6] = dL_v02x;
-      g[7] = dL_v02y;
+      render_backward_pixel<T>(r, gb[0], gb[HW], gb[2 * HW], grad_depth_img[int64_t(n) * HW + pix], g);
     }
     if (pass + 1 < kTileRows / kWaves) load_face(tr_next, vn);
 
