@@ -641,7 +641,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
              max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-// ---- Forward, bilinear, float, zeros / border padding: the LEAN kernel (round 5) -------------------------------------
+// ---- Forward, bilinear, any padding, float and double: the LEAN kernel (round 5; reflection and double: round 6) ---------
 // What the counters of rounds 3-4 meant, read with the right cost model (profiles/r05/micro_valu_issue.txt: a wave64 VALU
 // instruction occupies its SIMD for ~2.3 cycles, f64 / conversions / 64-bit adds / DPP 4.2, transcendentals 8, and scalar
 // instructions take issue slots too): SQ_ACTIVE_INST_ANY of mipmap_forward_kernel is 420 M quad-cycles per launch = 1.64 M
@@ -658,7 +658,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 //   * lanes whose tap is not interior (or that have no tap i) get offset 0 and weight 0 and run the same loads and fmas -- no
 //     exec-mask regions in the loop; the border taps themselves (rare) are added by a branch the wave only takes if it has one;
 //   * 32-bit texel offsets from per-pixel level bases.
-// Reflection padding, double and bicubic stay with the kernels above.
+// Bicubic stays with the kernels above.  Double (round 6): the same kernel on `T` -- 62-102 registers, 4-8 waves.
 // Waves per SIMD (late round 5).  The kernel is a chain of gathers per tap and lives on waves in flight, like the backward on
 // tiles in flight: the compiler's own choice was 100 registers = FOUR waves per SIMD (the allocation granule puts five at
 // <= 96).  Asked for five it fits 84-94 without a spill: 0.70 -> 0.65 ms on the textured benchmark.  With the per-level sizes
@@ -1567,7 +1567,8 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
   }
 }
 
-// ---- Backward, bilinear, float, zeros / border padding, C <= 4: the tile kernel with the LEAN tap loop (round 5) -------
+// ---- Backward, bilinear, any padding, any C, float and double: the tile kernel with the LEAN tap loop (round 5; reflection
+// and double: round 6) ----------------------------------------------------------------------------------------------------
 // mipmap_backward_tiled2_kernel's placement, shaped window slots, rounds and flush, with the tap loop rewritten the way
 // the lean forward was (one straight line per (tap, level) for the whole wave: no Quad, no per-corner logic, regrouped
 // products, texture channels a template parameter) -- for the instructions, and for the REGISTERS: the tile kernels sat at
@@ -1586,7 +1587,7 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? 1 : (PAD == 2 ? 2 : DRT
 #define DRTK_MIP_T3_OCC 5
 #endif
 #ifndef DRTK_MIP_T3_OCC_F64
-#define DRTK_MIP_T3_OCC_F64 3 // double: tiles per CU the lean backward is compiled for
+#define DRTK_MIP_T3_OCC_F64 3 // double: 126-152 registers = three tiles per CU (asked for four it spills 4-17 of them)
 #endif
 #ifndef DRTK_MIP_T3_OCC4
 #define DRTK_MIP_T3_OCC4 5 // four channels per pass: 96 registers, windows of 2 x 384 accumulators (24.6 KB): C = 4 / 8 / 16 1.62 / 3.17 / 6.33 -> 1.51 / 2.92 / 5.90 ms
@@ -2402,8 +2403,6 @@ __global__ __launch_bounds__(kMipBlock, sizeof(T) == 8 ? DRTK_MIP_T3_OCC_F64 : P
     }
   }
 }
-
-// ---- Backward, bilinear, f32, any C: WAVE-PRIVATE windows (round 4) -------------------------------------------------
 
 // ---- Backward, bilinear, f32, any C: WAVE-PRIVATE windows (round 4) -------------------------------------------------
 // Round 4's tile kernel was bound by its chain of dependent round trips at 3 waves per SIMD: 48 KB of

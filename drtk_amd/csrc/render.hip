@@ -305,6 +305,8 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 8 : 4) void render_backwar
 
   // software pipeline over the 4 rows: index of row p+1 is requested at the top of row p, its
   // triangle's vertex ids before the reduction -- both dependent gathers fly under the current row.
+  // (All four rows' indices and ids requested up front, the loop unrolled -- 62 registers, still eight waves: 0.210-0.218
+  // against 0.215-0.234 ms on one box, within the noise of the comparison; not kept, round 6.)
   auto load_tr = [&](int pass) -> int32_t {
     const int yy = tyi * kTileRows + wave * (kTileRows / kWaves) + pass;
     return (x < W && yy < H) ? index_img[int64_t(n) * HW + int64_t(yy) * W + x] : -1;
