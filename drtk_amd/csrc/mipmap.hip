@@ -468,8 +468,14 @@ constexpr int kChBlock = 4; // channels accumulated in registers per sweep over 
 // group's quads and texels take the kernel from 110 to 258 / 434 registers, and this kernel lives on occupancy.)
 
 // PAD: the padding mode as a compile-time constant (see the tile kernels of the backward pass).
+#ifndef DRTK_MIP_BICUBIC_FWD_OCC
+#define DRTK_MIP_BICUBIC_FWD_OCC 6 // float bicubic: 76-78 registers (asked for seven it spills 2-3)
+#endif
+#ifndef DRTK_MIP_BICUBIC_FWD_LDS_LEVELS
+#define DRTK_MIP_BICUBIC_FWD_LDS_LEVELS 1
+#endif
 template <typename T, int MODE, int PAD>
-__global__ __launch_bounds__(kBlock, (MODE == 2 && sizeof(T) == 4 && PAD != 2) ? 4 : 1) void mipmap_forward_kernel(
+__global__ __launch_bounds__(kBlock, (MODE == 2 && sizeof(T) == 4 && (PAD != 2 || DRTK_MIP_BICUBIC_FWD_LDS_LEVELS)) ? DRTK_MIP_BICUBIC_FWD_OCC : 1) void mipmap_forward_kernel(
     LevelTable lv, int mipmaps, const T* __restrict__ grid, GridLayout gl, const T* __restrict__ vt, int64_t count, int C,
     int64_t HW, int max_aniso, bool force_max_aniso, bool clip_grad, T* __restrict__ out, int strip) {
   constexpr int padding = PAD;
@@ -510,13 +516,25 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 && sizeof(T) == 4 && PAD != 2) ?
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s >= n_lv) break;
-        const int h = lv_h[s], w = lv_w[s];
-        const int64_t plane = int64_t(h) * w;
-        const GlobalPtr<const T> base = lv_base[s] + c0 * plane;
         const T alpha = s == 0 ? alpha_2 : alpha_1;
         // A level whose weight is exactly zero -- the second level of every magnified pixel (a == 0) -- contributes
         // +-0 * texel to every channel: skipped, texels are taken to be finite (as in the backward pass).
         if (alpha == T(0)) continue;
+#if DRTK_MIP_BICUBIC_FWD_LDS_LEVELS
+        // (bicubic, round 6: the level's size and the view's base pointer re-read from the LDS table per (tap, level) instead
+        // of living in registers across the tap loop, as in the lean forward: float 104-128 -> 76-78 registers = SIX waves per
+        // SIMD instead of four, 1.15 -> 1.00 ms on the textured benchmark; double 144-184 -> 108-110 = four instead of 2-3)
+        const bool reread = MODE == 2;
+        const int d_s = t.d1 + s;
+        const int h = reread ? s_h[d_s] : lv_h[s], w = reread ? s_w[d_s] : lv_w[s];
+        const int64_t plane = int64_t(h) * w;
+        const GlobalPtr<const T> base =
+            (reread ? (GlobalPtr<const T>)(static_cast<const T*>(s_ptr[d_s]) + n * s_sn[d_s]) : lv_base[s]) + c0 * plane;
+#else
+        const int h = lv_h[s], w = lv_w[s];
+        const int64_t plane = int64_t(h) * w;
+        const GlobalPtr<const T> base = lv_base[s] + c0 * plane;
+#endif
         if constexpr (MODE == 0) {
           const Quad<T> q = bilinear_quad<T>(x, y, h, w, padding, align_corners);
           if ((q.o_nw | q.o_ne | q.o_sw | q.o_se) >= 0) {
