@@ -322,6 +322,53 @@ def test_kernels_use_correctly_rounded_roots_and_quotients():
     assert "-fno-hip-fp32-correctly-rounded-divide-sqrt" not in build_py and "-ffast-math" not in build_py
 
 
+def test_no_cross_lane_operation_sits_behind_a_short_circuit():
+    """`(lane & 15) == 0 || tr != __shfl_up(x, 1)` evaluates the shuffle only on the lanes whose first operand is false:
+    the others are switched off for the ds_bpermute, and a lane that reads from one of them gets 0 instead of that lane's
+    value (found while bringing up the four-pixel-lane render backward, profiles/NOTES.md R6.7: one pixel pattern in one
+    fixture).  The same holds for `&&` and `?:`.  Cross-lane values are computed into a variable first, by every lane."""
+    # operations that MOVE a value between lanes (a ballot behind a wave-uniform condition is harmless: switched-off lanes
+    # contribute the 0 they should)
+    cross = re.compile(r"(__shfl\w*|__builtin_amdgcn_(update_dpp|mov_dpp|ds_bpermute|ds_permute|readlane)|dpp_row_sh[lr]\w*|dpp_i32|"
+                       r"wave_(min|max)_i32)\s*[<(]")
+
+    def guarded(code, pos):
+        """Is there a `||`, `&&` or `?` to the left of code[pos] in the same statement that decides whether it is evaluated?
+        (operators inside parenthesised groups that are already closed -- other calls' arguments -- do not)"""
+        depth = 0
+        i = pos - 1
+        while i >= 0:
+            ch = code[i]
+            if ch == ")":
+                depth += 1
+            elif ch == "(":
+                depth = max(depth - 1, 0) if depth else 0
+            elif depth == 0:
+                if ch in ";{}" or ch == ",":
+                    return False
+                if ch == "?" or code[i - 1:i + 1] in ("||", "&&"):
+                    return True
+            i -= 1
+        return False
+
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "drtk_amd", "csrc")):
+        for f in files:
+            if not f.endswith((".hip", ".hpp")):
+                continue
+            for no, line in enumerate(open(os.path.join(dirpath, f), errors="ignore"), 1):
+                code = line.split("//")[0]
+                if any(guarded(code, m.start()) for m in cross.finditer(code)):
+                    bad.append(f"{f}:{no}: {line.strip()}")
+    assert not bad, "\n".join(bad)
+    # the check checks: the line that had the bug, a select, and two harmless neighbours
+    for text, call, want in (("const bool b0 = (lane & 15) == 0 || tr[0] != __shfl_up(tr[3], 1);", "__shfl_up", True),
+                             ("x = on ? dpp_row_shr<1>(v) : 0;", "dpp_row_shr", True),
+                             ("x0 = wave_min_i32(on ? x : M), y0 = wave_min_i32(on ? y : M);", "y0 = wave_min_i32", False),
+                             ("const int32_t left = __shfl_up(tr[3], 1); const bool b0 = first || tr[0] != left;", "__shfl_up", False)):
+        assert guarded(text, text.index(call) + (len("y0 = ") if call.startswith("y0") else 0)) == want, text
+
+
 def test_only_the_cpu_baseline_leg_and_the_smoke_check_use_the_oracle():
     """Outside tests/ and oracle/ itself: bench.py may reach into oracle/ only inside cpu_baseline() (the reported
     baseline, never the thing measured), __graft_entry__.py only to build the checker and in smoke(); the profiling
