@@ -566,12 +566,15 @@ __global__ __launch_bounds__(kBlock) void edge_gather4_kernel(
 #define DRTK_PAIR_ROWS 2
 #endif
 // Image rows per wave of edge_scatter_pairs_kernel (its tile: 256 x kPairRows pixels).  The kernel is bound by the
-// dependent loads of each 64-pair round (list -> index -> corners -> vertices) at 2-3 waves per SIMD, and its waves'
+// dependent loads of each 64-pair round (list -> index -> corners -> vertices) at six waves per SIMD (80 registers), and its waves'
 // work varies with the number of pairs in their tile: more, shorter waves keep more rounds in flight and even out the
 // tail.  Fused route on one box (kernel_bench): 4 rows 0.799-0.804 ms, 2 rows 0.759-0.762, 1 row 0.800 (the halo row
 // doubles the index traffic and the lists get short), 8 rows 0.830; 1M triangles at 2 x 4096^2: 0.468 -> 0.409 ms.
 // Narrower tiles instead (2 pixels per lane, 128 x 2 or 128 x 4): 0.80-0.84 ms against 0.72-0.76 -- the 8-byte index
 // loads and half-empty pair rounds cost more than the extra waves bring.
+// (Round 6: the tile's index rows staged in LDS so that a round's two triangle ids are LDS reads -- one of the three dependent
+// round trips less -- for 12.5 KB more LDS and four more registers: five waves per SIMD instead of six, 0.771-0.780 against
+// 0.750-0.759 ms, 250k triangles 0.819 against 0.791.  Slower; not kept.)
 constexpr int kPairRows = DRTK_PAIR_ROWS;
 template <typename T>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void edge_scatter_pairs_kernel(
